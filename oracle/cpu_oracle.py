@@ -1,0 +1,186 @@
+"""TEST INFRASTRUCTURE ONLY — ctypes access to the CPU checkers.
+
+  CpuSolver("orc64")  our fp64 C restatement      (oracle/libtinympc_oracle.so)
+  CpuSolver("orc32")  same loop in fp32 + fp64 cache
+  CpuSolver("ref")    the reference's own vendored TinyMPC snapshot compiled from
+                      /root/reference (oracle/_ref/libtinympc_ref.so), when built
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PORT_LIB = os.path.join(_HERE, "libtinympc_oracle.so")
+REF_LIB = os.path.join(_HERE, "_ref", "libtinympc_ref.so")
+
+_c_dp = ctypes.POINTER(ctypes.c_double)
+_c_ip = ctypes.POINTER(ctypes.c_int)
+
+
+def build(port=True, ref=True):
+    """Compile the checkers (gcc/g++ only).  `_ref` is skipped where /root/reference is absent."""
+    if port:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "port"])
+    if ref and os.path.isdir("/root/reference/src/codegen_src/tinympc"):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "_ref"])
+
+
+def have_ref():
+    return os.path.isfile(REF_LIB)
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(_c_dp)
+
+
+def _f(a):
+    return None if a is None else np.asfortranarray(np.asarray(a, dtype=np.float64))
+
+
+_libs = {}
+
+
+def _load(kind):
+    path = REF_LIB if kind == "ref" else PORT_LIB
+    if path not in _libs:
+        if not os.path.isfile(path):
+            raise FileNotFoundError(f"{path} not built (run oracle.cpu_oracle.build())")
+        _libs[path] = ctypes.CDLL(path)
+    return _libs[path]
+
+
+class CpuSolver:
+    """One CPU solver instance (single problem), same call sequence as the reference's API."""
+
+    def __init__(self, kind, A, B, Q, R, rho, N):
+        assert kind in ("orc64", "orc32", "ref")
+        self.kind = kind
+        self.lib = _load(kind)
+        self.p = kind + "_"
+        self.nx, self.nu, self.N = A.shape[0], B.shape[1], N
+        fn = getattr(self.lib, self.p + "create")
+        fn.restype = ctypes.c_void_p
+        A, B, Q, R = _f(A), _f(B), _f(Q), _f(R)
+        self.h = ctypes.c_void_p(fn(_dp(A), _dp(B), _dp(Q), _dp(R), ctypes.c_double(rho),
+                                    self.nx, self.nu, N))
+        if not self.h:
+            raise RuntimeError("create failed")
+
+    def _call(self, name, *args):
+        fn = getattr(self.lib, self.p + name)
+        return fn(self.h, *args)
+
+    def close(self):
+        if self.h:
+            self._call("destroy")
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def update_settings(self, abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100,
+                        check_termination=1, en_state_bound=0, en_input_bound=0):
+        self._call("update_settings", ctypes.c_double(abs_pri_tol), ctypes.c_double(abs_dua_tol),
+                   int(max_iter), int(check_termination), int(en_state_bound), int(en_input_bound))
+
+    def set_bound_constraints(self, x_min, x_max, u_min, u_max):
+        a = [_f(m) for m in (x_min, x_max, u_min, u_max)]
+        self._call("set_bound_constraints", *[_dp(m) for m in a])
+
+    def set_x0(self, x0):
+        x0 = _f(x0)
+        self._call("set_x0", _dp(x0))
+
+    def set_x_ref(self, xr):
+        xr = _f(xr)
+        self._call("set_x_ref", _dp(xr))
+
+    def set_u_ref(self, ur):
+        ur = _f(ur)
+        self._call("set_u_ref", _dp(ur))
+
+    def set_cache_terms(self, Kinf, Pinf, Quu_inv, AmBKt):
+        a = [_f(m) for m in (Kinf, Pinf, Quu_inv, AmBKt)]
+        self._call("set_cache_terms", *[_dp(m) for m in a])
+
+    def reset(self):
+        self._call("reset")
+
+    def solve(self):
+        return int(self._call("solve"))
+
+    def get_solution(self):
+        nx, nu, N = self.nx, self.nu, self.N
+        x = np.zeros((nx, N), order="F")
+        u = np.zeros((nu, N - 1), order="F")
+        it, so = ctypes.c_int(), ctypes.c_int()
+        res = np.zeros(4)
+        self._call("get_solution", _dp(x), _dp(u), ctypes.byref(it), ctypes.byref(so), _dp(res))
+        return dict(x=x, u=u, iter=it.value, solved=so.value, res=res)
+
+    def get_cache(self):
+        nx, nu = self.nx, self.nu
+        K = np.zeros((nu, nx), order="F")
+        P = np.zeros((nx, nx), order="F")
+        Qi = np.zeros((nu, nu), order="F")
+        Am = np.zeros((nx, nx), order="F")
+        self._call("get_cache", _dp(K), _dp(P), _dp(Qi), _dp(Am))
+        return dict(Kinf=K, Pinf=P, Quu_inv=Qi, AmBKt=Am)
+
+    def get_state(self):
+        nx, nu, N = self.nx, self.nu, self.N
+        d = np.zeros((nu, N - 1), order="F")
+        y = np.zeros((nu, N - 1), order="F")
+        z = np.zeros((nu, N - 1), order="F")
+        g = np.zeros((nx, N), order="F")
+        v = np.zeros((nx, N), order="F")
+        self._call("get_state", _dp(d), _dp(y), _dp(g), _dp(v), _dp(z))
+        return dict(d=d, y=y, g=g, v=v, z=z)
+
+
+def solve_batch(kind, prob, x0, xref=None, uref=None, abs_pri_tol=1e-3, abs_dua_tol=1e-3,
+                max_iter=100, check_termination=1, nthreads=1, want_outputs=True):
+    """Cold-start batch on the CPU checker.  x0: (nx, B).  xref/uref: None (zeros), shared
+    (nx,N)/(nu,N-1), or per-instance (nx,N,B)/(nu,N-1,B).  Returns dict incl. wall seconds."""
+    lib = _load(kind)
+    fn = getattr(lib, kind + "_solve_batch")
+    fn.restype = ctypes.c_double
+    nx, nu, N = prob.nx, prob.nu, prob.N
+    x0 = _f(x0)
+    B = x0.shape[1]
+    per_inst = int((xref is not None and np.ndim(xref) == 3) or (uref is not None and np.ndim(uref) == 3))
+    if per_inst:
+        xref = np.zeros((nx, N, B), order="F") if xref is None else xref
+        uref = np.zeros((nu, N - 1, B), order="F") if uref is None else uref
+        if np.ndim(xref) == 2:
+            xref = np.repeat(np.asarray(xref)[:, :, None], B, axis=2)
+        if np.ndim(uref) == 2:
+            uref = np.repeat(np.asarray(uref)[:, :, None], B, axis=2)
+    xref, uref = _f(xref), _f(uref)
+    use_bounds = int(prob.has_bounds())
+    bnd = [_f(m) for m in (prob.x_min, prob.x_max, prob.u_min, prob.u_max)]
+    if want_outputs:
+        xo = np.zeros((nx, N, B), order="F")
+        uo = np.zeros((nu, N - 1, B), order="F")
+        it = np.zeros(B, dtype=np.int32)
+        so = np.zeros(B, dtype=np.int32)
+        res = np.zeros((B, 4))
+    else:
+        xo = uo = it = so = res = None
+    A, Bm, Q, R = _f(prob.A), _f(prob.B), _f(prob.Q), _f(prob.R)
+    secs = fn(_dp(A), _dp(Bm), _dp(Q), _dp(R), ctypes.c_double(prob.rho), nx, nu, N,
+              *[_dp(m) for m in bnd], use_bounds, ctypes.c_double(abs_pri_tol),
+              ctypes.c_double(abs_dua_tol), int(max_iter), int(check_termination), int(B),
+              _dp(x0), _dp(xref), _dp(uref), per_inst, _dp(xo), _dp(uo),
+              None if it is None else it.ctypes.data_as(_c_ip),
+              None if so is None else so.ctypes.data_as(_c_ip), _dp(res), int(nthreads))
+    if secs < 0:
+        raise RuntimeError("solve_batch failed")
+    return dict(x=xo, u=uo, iter=it, solved=so, res=res, seconds=secs)

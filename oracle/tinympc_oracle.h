@@ -1,0 +1,59 @@
+/* TEST INFRASTRUCTURE ONLY — CPU restatement ("port") of the reference's TinyMPC
+ * ADMM solve path.  Never linked, imported or executed by the product path.
+ *
+ * Two instantiations of the same plain-loop C code (tinympc_oracle_body.inc):
+ *   orc64_*  all arithmetic in fp64 — restates the reference exactly
+ *            (reference: src/codegen_src/tinympc/types.hpp:15 `typedef double tinytype`)
+ *   orc32_*  ADMM loop in fp32, fed the fp64-computed Riccati cache rounded once to
+ *            fp32 — the arithmetic model of the HIP kernel
+ *
+ * Parity pin: orc64 is checked against golden vectors produced by the compiled
+ * reference snapshot (oracle/_ref, oracle/make_golden.py -> tests/golden/*.json)
+ * to <= 1e-12 in tests/test_oracle.py.
+ *
+ * All matrices are column-major fp64 at this API, like the reference's C-ABI
+ * (reference: src/bindings.cpp:21-27, src/TinyMPC.jl:77-83).
+ */
+#ifndef TINYMPC_ORACLE_H
+#define TINYMPC_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_DECLARE(P)                                                                          \
+    void *P##create(const double *A, const double *B, const double *Q, const double *R,        \
+                    double rho, int nx, int nu, int N);                                        \
+    void P##destroy(void *h);                                                                  \
+    void P##update_settings(void *h, double abs_pri_tol, double abs_dua_tol, int max_iter,     \
+                            int check_termination, int en_state_bound, int en_input_bound);   \
+    void P##set_bound_constraints(void *h, const double *xmin, const double *xmax,            \
+                                  const double *umin, const double *umax);                    \
+    void P##set_x0(void *h, const double *x0);                                                 \
+    void P##set_x_ref(void *h, const double *xref);                                            \
+    void P##set_u_ref(void *h, const double *uref);                                            \
+    void P##set_cache_terms(void *h, const double *Kinf, const double *Pinf,                  \
+                            const double *Quu_inv, const double *AmBKt);                      \
+    void P##reset(void *h);                                                                    \
+    int P##solve(void *h);                                                                     \
+    void P##get_solution(void *h, double *x, double *u, int *iter, int *solved, double *res4); \
+    void P##get_cache(void *h, double *Kinf, double *Pinf, double *Quu_inv, double *AmBKt);    \
+    void P##get_state(void *h, double *d, double *y, double *g, double *v, double *z);         \
+    void P##set_state(void *h, const double *d, const double *y, const double *g,             \
+                      const double *v, const double *z);                                      \
+    double P##solve_batch(const double *A, const double *B, const double *Q, const double *R, \
+                          double rho, int nx, int nu, int N, const double *xmin,              \
+                          const double *xmax, const double *umin, const double *umax,         \
+                          int use_bounds, double abs_pri_tol, double abs_dua_tol,             \
+                          int max_iter, int check_termination, int batch, const double *x0,   \
+                          const double *xref, const double *uref, int per_instance_ref,       \
+                          double *x_out, double *u_out, int *iter_out, int *solved_out,       \
+                          double *res_out, int nthreads);
+
+ORC_DECLARE(orc64_)
+ORC_DECLARE(orc32_)
+
+#ifdef __cplusplus
+}
+#endif
+#endif
