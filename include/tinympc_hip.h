@@ -1,0 +1,169 @@
+/* libtinympc_hip.so — C-ABI of the MI355X batched TinyMPC ADMM engine.
+ *
+ * Drop-in boundary: the reference's Julia module reaches its solver through
+ * `ccall((:sym, libtinympc_jl), Int32, ...)` into src/bindings.cpp
+ * (reference: src/TinyMPC.jl:12-14, src/bindings.cpp:15-490).  This header
+ * declares
+ *   (1) the same symbol names with the SAME argument lists and return
+ *       conventions as bindings.cpp, operating on one process-global solver, so
+ *       the unmodified TinyMPC.jl can ccall this library instead; the batch
+ *       dimension rides on the (rows, cols) arguments the reference already
+ *       passes (x0 as nx x B, x_ref as nx x N*B, ...), and
+ *   (2) a handle-based extension (`tinympc_*`) adding what a batched, device-
+ *       resident engine needs: batch size, per-instance status, cold reset,
+ *       device-pointer I/O and stream-ordered solves.
+ *
+ * Conventions (as bindings.cpp): every matrix is column-major fp64 passed as
+ * pointer + (rows, cols); inputs are borrowed for the call only; outputs are
+ * written into caller-allocated buffers; return 0 = OK, -1 = error (message on
+ * stderr); solve_mpc passes the solver status through (0 all converged, 1 some
+ * instance hit max_iter).  Plain C, no torch / HIP types except the opaque
+ * stream handle (void*).  The library has no CPU fallback: every entry point
+ * that computes fails with -1 when no HIP device is usable.
+ */
+#ifndef TINYMPC_HIP_H
+#define TINYMPC_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* (1) process-global solver: the reference's own entry points               */
+/* ------------------------------------------------------------------------- */
+
+/* replaces bindings.cpp:21-73 setup_solver.  fdyn must be all zero (the affine
+ * term exists only in the un-vendored TinyMPC submodule) —
+ * a non-zero fdyn returns -1.  Batch starts at 1; see set_batch_size. */
+int setup_solver(double *A_data, int A_rows, int A_cols, double *B_data, int B_rows, int B_cols,
+                 double *fdyn_data, int fdyn_rows, int fdyn_cols, double *Q_data, int Q_rows,
+                 int Q_cols, double *R_data, int R_rows, int R_cols, double rho, int nx, int nu,
+                 int N, int verbose);
+
+/* replaces bindings.cpp:75-96.  x0 is nx x 1 (broadcast to every instance) or nx x batch. */
+int set_x0(double *x0_data, int x0_rows, int x0_cols, int verbose);
+/* replaces bindings.cpp:98-119.  nx x N (shared by the batch) or nx x (N*batch). */
+int set_x_ref(double *x_ref_data, int x_ref_rows, int x_ref_cols, int verbose);
+/* replaces bindings.cpp:121-142.  nu x (N-1) (shared) or nu x ((N-1)*batch). */
+int set_u_ref(double *u_ref_data, int u_ref_rows, int u_ref_cols, int verbose);
+/* replaces bindings.cpp:144-159.  0: every instance converged, 1: some hit max_iter, -1: error. */
+int solve_mpc(int verbose);
+/* replace bindings.cpp:161-203.  Buffers hold nx*N*batch / nu*(N-1)*batch doubles;
+ * rows = nx / nu, cols = N*batch / (N-1)*batch (Julia: reshape to (nx, N, batch)). */
+int get_states(double *states_buffer, int *rows, int *cols);
+int get_controls(double *controls_buffer, int *rows, int *cols);
+/* replaces bindings.cpp:205-208 */
+void cleanup_solver(void);
+/* replaces bindings.cpp:336-376.  en_*_soc / en_*_linear must be 0 and adaptive_rho must be 0
+ * (out of scope this round; non-zero returns -1).  check_termination <= 0 means "never check"
+ * (the reference divides by it, admm.cpp:91). */
+int update_settings(double abs_pri_tol, double abs_dua_tol, int max_iter, int check_termination,
+                    int en_state_bound, int en_input_bound, int en_state_soc, int en_input_soc,
+                    int en_state_linear, int en_input_linear, int adaptive_rho,
+                    double adaptive_rho_min, double adaptive_rho_max,
+                    int adaptive_rho_enable_clipping, int verbose);
+/* replaces bindings.cpp:378-411.  Bounds are per knot (nx x N, nu x (N-1)), shared by the batch;
+ * enables en_state_bound and en_input_bound on success. */
+int set_bound_constraints(double *x_min_data, int x_min_rows, int x_min_cols, double *x_max_data,
+                          int x_max_rows, int x_max_cols, double *u_min_data, int u_min_rows,
+                          int u_min_cols, double *u_max_data, int u_max_rows, int u_max_cols,
+                          int verbose);
+/* replaces bindings.cpp:262-293 */
+int set_cache_terms(double *Kinf_data, int Kinf_rows, int Kinf_cols, double *Pinf_data,
+                    int Pinf_rows, int Pinf_cols, double *Quu_inv_data, int Quu_inv_rows,
+                    int Quu_inv_cols, double *AmBKt_data, int AmBKt_rows, int AmBKt_cols,
+                    int verbose);
+/* replaces bindings.cpp:228-259 */
+int print_problem_data(int verbose);
+/* replace bindings.cpp:413-490: accepted only when every block is empty; otherwise -1
+ * (SOC / linear constraints live in the absent submodule — parity unpinned). */
+int set_linear_constraints(double *Alin_x_data, int Alin_x_rows, int Alin_x_cols,
+                           double *blin_x_data, int blin_x_len, double *Alin_u_data,
+                           int Alin_u_rows, int Alin_u_cols, double *blin_u_data, int blin_u_len,
+                           int verbose);
+int set_cone_constraints(int *Acu_data, int Acu_len, int *qcu_data, int qcu_len, double *cu_data,
+                         int cu_len, int *Acx_data, int Acx_len, int *qcx_data, int qcx_len,
+                         double *cx_data, int cx_len, int verbose);
+
+/* --- batch extensions on the global solver (no counterpart in bindings.cpp) --- */
+/* Re-shapes the global solver to `batch` instances; per-instance inputs/state are reset. */
+int set_batch_size(int batch);
+int get_batch_size(void);
+/* Per-instance iteration count, solved flag and the 4 residuals
+ * (pri_state, dua_state, pri_input, dua_input) — the batched form of
+ * solution->iter / solution->solved / work->*_residual_* (types.hpp:32-37,128-131).
+ * Any pointer may be NULL. */
+int get_status(int *iter, int *solved, double *residuals4);
+/* Cold start: zero d, y, g, v, z of every instance (what tiny_setup leaves, tiny_api.cpp:73-88). */
+int reset_workspace(void);
+
+/* ------------------------------------------------------------------------- */
+/* (2) handle API                                                            */
+/* ------------------------------------------------------------------------- */
+typedef struct tinympc_solver tinympc_solver;
+
+/* device < 0: current HIP device. */
+int tinympc_create(tinympc_solver **out, const double *A, const double *B, const double *Q,
+                   const double *R, double rho, int nx, int nu, int N, int batch, int device,
+                   int verbose);
+void tinympc_destroy(tinympc_solver *s);
+int tinympc_update_settings(tinympc_solver *s, double abs_pri_tol, double abs_dua_tol,
+                            int max_iter, int check_termination, int en_state_bound,
+                            int en_input_bound);
+int tinympc_set_bound_constraints(tinympc_solver *s, const double *x_min, const double *x_max,
+                                  const double *u_min, const double *u_max);
+int tinympc_set_cache_terms(tinympc_solver *s, const double *Kinf, const double *Pinf,
+                            const double *Quu_inv, const double *AmBKt);
+int tinympc_get_cache_terms(tinympc_solver *s, double *Kinf, double *Pinf, double *Quu_inv,
+                            double *AmBKt);
+int tinympc_set_x0(tinympc_solver *s, const double *x0, int cols);       /* cols: 1 | batch */
+int tinympc_set_x_ref(tinympc_solver *s, const double *x_ref, int cols); /* cols: N | N*batch */
+int tinympc_set_u_ref(tinympc_solver *s, const double *u_ref, int cols); /* N-1 | (N-1)*batch */
+int tinympc_reset(tinympc_solver *s);
+/* warm_start: 0 = every solve starts from the zero workspace and keeps no state (benchmark
+ * configs); 1 = the workspace (d, y, g, v, z) persists between solves like the reference's
+ * (SURVEY.md 3.5).  Default 1. */
+int tinympc_set_warm_start(tinympc_solver *s, int warm_start);
+int tinympc_solve(tinympc_solver *s);
+int tinympc_get_states(tinympc_solver *s, double *buf);
+int tinympc_get_controls(tinympc_solver *s, double *buf);
+int tinympc_get_status(tinympc_solver *s, int *iter, int *solved, double *residuals4);
+/* Warm-start state of every instance, instance-major: d,y,z [batch][N-1][nu]; g,v [batch][N][nx]. */
+int tinympc_get_workspace(tinympc_solver *s, double *d, double *y, double *g, double *v, double *z);
+int tinympc_set_workspace(tinympc_solver *s, const double *d, const double *y, const double *g,
+                          const double *v, const double *z);
+
+/* --- device-resident I/O (fp32, instance-major), for callers that keep data in HBM --- */
+/* Device pointers owned by the solver; valid until destroy / re-batch.
+ *   x0 [batch][nx]; x_ref [batch][N][nx] (or [N][nx] when shared); u_ref likewise;
+ *   states [batch][N][nx]; controls [batch][N-1][nu]; iter/solved [batch] int32;
+ *   residuals [batch][4]; gstat: 8 x uint32 (max residual bits [0..3], unsolved count [4]). */
+int tinympc_device_buffers(tinympc_solver *s, void **x0, void **x_ref, void **u_ref,
+                           void **states, void **controls, void **iter, void **solved,
+                           void **residuals, void **gstat);
+/* Declare how the device-side reference buffers are to be read: 0 zero, 1 shared, 2 per instance. */
+int tinympc_set_ref_mode(tinympc_solver *s, int ref_mode);
+/* Enqueue one batched solve on `hip_stream` (NULL = default stream) without synchronising;
+ * results are in the device buffers when the stream reaches this point. */
+int tinympc_solve_async(tinympc_solver *s, void *hip_stream);
+/* After the stream has been synchronised: 0 all converged / 1 otherwise (reads gstat). */
+int tinympc_solve_status(tinympc_solver *s);
+/* Name of the kernel path that the last solve used: "quad<nx,nu,N>" or "generic". */
+const char *tinympc_kernel_name(tinympc_solver *s);
+/* Algorithmic HBM bytes and FLOPs of one solve of the whole batch (SURVEY.md 8d formulas);
+ * flops assume `iters` ADMM iterations per instance. */
+double tinympc_algorithmic_bytes(tinympc_solver *s);
+double tinympc_algorithmic_flops(tinympc_solver *s, int iters);
+const char *tinympc_last_error(void);
+/* Host-only fp64 part of setup() — the infinite-horizon Riccati precompute of
+ * tiny_precompute_and_set_cache (tiny_api.cpp:124-190, incl. the rho-twice quirk of
+ * tiny_setup :90-91,113).  Needs no GPU.  Outputs column-major: Kinf nu x nx, Pinf nx x nx,
+ * Quu_inv nu x nu, AmBKt nx x nx.  Returns 0, or -1 if R + B'PB is singular. */
+int tinympc_host_precompute(const double *A, const double *B, const double *Q, const double *R,
+                            double rho, int nx, int nu, double *Kinf, double *Pinf,
+                            double *Quu_inv, double *AmBKt);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TINYMPC_HIP_H */

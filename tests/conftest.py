@@ -1,0 +1,30 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_built():
+    """The CPU checkers (test infrastructure).  Builds the C restatement if needed."""
+    from oracle import cpu_oracle
+    if not os.path.isfile(cpu_oracle.PORT_LIB):
+        cpu_oracle.build(port=True, ref=False)
+    return cpu_oracle
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    """The product library; built by __graft_entry__.build().  GPU tests fail loudly without it."""
+    import tinympc_julia_amd as t
+    if not os.path.isfile(t.LIB_PATH):
+        t.build()
+    return t.load_library()

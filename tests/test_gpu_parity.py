@@ -1,0 +1,412 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the reference's golden
+vectors and against the fp64 CPU oracle on seeded batches.
+
+Tolerance: the fp32 kernel must satisfy
+    max|a - b| <= 1e-5 * ||ref||_inf   per trajectory (x and u separately, per instance).
+"""
+import numpy as np
+import pytest
+
+import tinympc_julia_amd as t
+from tests.util import FP32_TOL, cm, load_golden, nrel, nrel_batch, problem_of
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup_global(prob, settings, batch=1):
+    s = t.TinyMPCSolver()
+    ct = settings.get("check_termination", 1)
+    t.setup(s, prob.A, prob.B, np.zeros(prob.nx), prob.Q, prob.R, prob.rho, prob.nx, prob.nu, prob.N,
+            batch=batch, abs_pri_tol=settings["abs_pri_tol"], abs_dua_tol=settings["abs_dua_tol"],
+            max_iter=settings["max_iter"], check_termination=ct)
+    if prob.has_bounds():
+        t.set_bound_constraints(s, prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    return s
+
+
+def _check_instance(sol_x, sol_u, exp, nx, nu, N, tol=FP32_TOL):
+    ex, eu = cm(exp["x"], nx, N), cm(exp["u"], nu, N - 1)
+    assert nrel(sol_x, ex) <= tol, f"x err {nrel(sol_x, ex):.3e}"
+    assert nrel(sol_u, eu) <= tol, f"u err {nrel(sol_u, eu):.3e}"
+
+
+SINGLE = ["G1_cartpole_one_solve", "G3a_test_basic_unconstrained", "G3b_test_basic_bounds",
+          "G3c_test_settings_pritol5", "G3d_test_settings_maxiter1", "G4_cartpole_state_bound",
+          "G4b_cartpole_state_bound_active"]
+
+
+@pytest.mark.parametrize("name", SINGLE)
+def test_golden_single(hip_lib, name):
+    """The reference's own scripts/tests as batch-1 solves through the drop-in entry points."""
+    g = load_golden(name)
+    prob = problem_of(g)
+    s = _setup_global(prob, g["settings"])
+    if g["xref"] is not None:
+        t.set_x_ref(s, cm(g["xref"], prob.nx, prob.N))
+    if g["uref"] is not None:
+        t.set_u_ref(s, cm(g["uref"], prob.nu, prob.N - 1))
+    t.set_x0(s, np.array(g["x0"]))
+    status = t.solve(s)
+    sol = t.get_solution(s)
+    st = t.get_status(s)
+    exp = g["expect"]
+    assert status == exp["status"]
+    assert sol["states"].shape == (prob.nx, prob.N)        # tests/test_basic.jl:42-44
+    assert sol["controls"].shape == (prob.nu, prob.N - 1)
+    assert int(st["iter"][0]) == exp["iter"]
+    assert int(st["solved"][0]) == exp["solved"]
+    _check_instance(sol["states"], sol["controls"], exp, prob.nx, prob.nu, prob.N)
+    ref_res = np.array(exp["res"])
+    assert np.allclose(st["residuals"][0], ref_res, rtol=2e-3, atol=2e-6)
+    if name == "G3b_test_basic_bounds":                    # tests/test_basic.jl:66-68
+        assert np.all(sol["controls"] >= -1.0) and np.all(sol["controls"] <= 1.0)
+    t.cleanup()
+
+
+BATCHES = ["G2_cartpole_box_fixed100", "G6_quadrotor_box_fixed100", "G6b_quadrotor_tol",
+           "G7_rocket_box_fixed100"]
+
+
+@pytest.mark.parametrize("name", BATCHES)
+def test_golden_batch(hip_lib, name):
+    g = load_golden(name)
+    prob = problem_of(g)
+    B = g["batch"]
+    s = _setup_global(prob, g["settings"], batch=B)
+    if g["xref"] is not None:
+        t.set_x_ref(s, cm(g["xref"], prob.nx, prob.N))
+    if g["uref"] is not None:
+        t.set_u_ref(s, cm(g["uref"], prob.nu, prob.N - 1))
+    t.set_x0(s, cm(g["x0"], prob.nx, B))
+    status = t.solve(s)
+    sol = t.get_solution(s)
+    st = t.get_status(s)
+    assert status == max(e["status"] for e in g["expect"])
+    for b, exp in enumerate(g["expect"]):
+        assert int(st["iter"][b]) == exp["iter"], f"instance {b}"
+        assert int(st["solved"][b]) == exp["solved"]
+        _check_instance(sol["states"][:, :, b], sol["controls"][:, :, b], exp, prob.nx, prob.nu, prob.N)
+    t.cleanup()
+
+
+@pytest.mark.parametrize("name", ["G5_cartpole_mpc_warm", "G5b_cartpole_mpc_warm_bounded"])
+def test_golden_mpc_warm_start(hip_lib, name):
+    """Closed loop of examples/cartpole_example_mpc.jl:35-51: the workspace persists between solves."""
+    g = load_golden(name)
+    prob = problem_of(g)
+    s = _setup_global(prob, g["settings"])
+    t.set_x0(s, np.array(g["x0"]))
+    t.set_x_ref(s, np.zeros((prob.nx, prob.N)))
+    t.set_u_ref(s, np.zeros((prob.nu, prob.N - 1)))
+    for k, step in enumerate(g["steps"]):
+        # feed the reference's own x0 sequence so one step's rounding does not leak into the next
+        t.set_x0(s, np.array(step["x0"]))
+        status = t.solve(s)
+        sol = t.get_solution(s)
+        st = t.get_status(s)
+        assert status == step["status"], f"step {k}"
+        assert int(st["iter"][0]) == step["iter"], f"step {k}"
+        _check_instance(sol["states"], sol["controls"], step, prob.nx, prob.nu, prob.N, tol=2e-5)
+    t.cleanup()
+
+
+def test_golden_mpc_workspace_state(hip_lib):
+    """d, y, g, v, z after each warm-started solve match the reference's workspace, incl. the
+    converged-exit case where v, z keep the PREVIOUS iteration's slack (admm.cpp:181-197)."""
+    g = load_golden("G5_cartpole_mpc_warm")
+    prob = problem_of(g)
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=1)
+    bs.update_settings(**g["settings"])
+    nx, nu, N = prob.nx, prob.nu, prob.N
+    for k, step in enumerate(g["steps"]):
+        bs.set_x0(np.array(step["x0"]))
+        assert bs.solve() == step["status"]
+        ws = bs.get_workspace()
+        for key, r, c in (("d", nu, N - 1), ("y", nu, N - 1), ("z", nu, N - 1), ("g", nx, N), ("v", nx, N)):
+            ref = cm(step["state_after"][key], r, c)
+            scale = max(np.abs(ref).max(), 1e-2)
+            assert np.abs(ws[key][:, :, 0] - ref).max() <= 5e-5 * scale, f"step {k} {key}"
+    bs.close()
+
+
+@pytest.mark.parametrize("name,iters", [("G8a_cartpole_trace", 100), ("G8b_quadrotor_trace", 60)])
+def test_golden_residual_trace(hip_lib, name, iters):
+    """Per-iteration residuals / iter counts: cold solves with max_iter = k (tol 0), k = 1..K,
+    run as ONE batch of K identical instances is not possible (max_iter is per solve), so a few
+    representative k are solved."""
+    g = load_golden(name)
+    prob = problem_of(g)
+    nx, nu = prob.nx, prob.nu
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=1)
+    bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    bs.set_warm_start(False)
+    bs.set_x0(np.array(g["x0"]))
+    for k in (1, 2, 3, 5, 10, 25, iters):
+        tr = g["trace"][k - 1]
+        assert tr["k"] == k
+        bs.update_settings(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=k, check_termination=1,
+                           en_state_bound=1, en_input_bound=1)
+        assert bs.solve() == tr["status"] == 1
+        st = bs.get_status()
+        assert int(st["iter"][0]) == tr["iter"] == k
+        ref = np.array(tr["res"])
+        assert np.allclose(st["residuals"][0], ref, rtol=5e-3, atol=1e-5 * max(1.0, np.abs(ref).max()))
+        sol = bs.get_solution()
+        assert np.abs(sol["controls"][:, 0, 0] - np.array(tr["u0"])).max() <= FP32_TOL * max(
+            1.0, np.abs(np.array(tr["u0"])).max())
+    bs.close()
+
+
+def _oracle_batch(oracle_built, prob, x0, **kw):
+    return oracle_built.solve_batch("orc64", prob, x0, **kw)
+
+
+@pytest.mark.parametrize("family,batch", [("cartpole", 1000), ("quadrotor", 300)])
+def test_seeded_batch_vs_oracle(hip_lib, oracle_built, family, batch):
+    """BASELINE configs 2 and 3 at a size the oracle finishes in seconds; ragged batch (not a
+    multiple of 16 instances per wavefront / 64 per workgroup)."""
+    if family == "cartpole":
+        prob, x0 = t.problems.cartpole(20, u_bound=0.5), t.problems.cartpole_x0(batch, seed=0)
+    else:
+        prob, x0 = t.problems.quadrotor(30), t.problems.quadrotor_x0(batch, seed=1)
+    ref = _oracle_batch(oracle_built, prob, x0, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=100, nthreads=8)
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=batch)
+    bs.update_settings(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=100, check_termination=1)
+    bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    bs.set_warm_start(False)
+    bs.set_x0(x0)
+    assert bs.solve() == 1
+    sol, st = bs.get_solution(), bs.get_status()
+    assert np.all(st["iter"] == 100) and np.all(st["solved"] == 0)
+    ex, eu = nrel_batch(sol["states"], ref["x"]), nrel_batch(sol["controls"], ref["u"])
+    assert ex.max() <= FP32_TOL, f"x worst {ex.max():.3e}"
+    assert eu.max() <= FP32_TOL, f"u worst {eu.max():.3e}"
+    assert np.allclose(st["residuals"], ref["res"], rtol=1e-2, atol=1e-5)
+    bs.close()
+
+
+def test_tolerance_terminated_batch_vs_oracle(hip_lib, oracle_built):
+    """Per-instance early exit: every instance freezes at its own convergence (admm.cpp:181-193)."""
+    B = 200
+    prob, x0 = t.problems.quadrotor(30), t.problems.quadrotor_x0(B, seed=3)
+    ref = _oracle_batch(oracle_built, prob, x0, abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, nthreads=8)
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+    bs.update_settings(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1)
+    bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    bs.set_x0(x0)
+    status = bs.solve()
+    sol, st = bs.get_solution(), bs.get_status()
+    assert status == int(np.any(ref["solved"] == 0))
+    same = st["iter"] == ref["iter"]
+    # an instance whose residual sits within fp32 rounding of the tolerance may stop one check
+    # earlier or later; everything else must match exactly
+    assert same.mean() >= 0.97, f"only {same.mean():.3f} of iteration counts agree"
+    assert np.all(np.abs(st["iter"] - ref["iter"]) <= 1)
+    ex, eu = nrel_batch(sol["states"], ref["x"]), nrel_batch(sol["controls"], ref["u"])
+    assert ex[same].max() <= FP32_TOL and eu[same].max() <= FP32_TOL
+    assert np.array_equal(st["solved"][same], ref["solved"][same])
+    bs.close()
+
+
+def test_refs_shared_and_per_instance(hip_lib, oracle_built):
+    """Reference tracking: shared (nx,N) refs and per-instance (nx,N,B) refs (rocket box sub-problem)."""
+    B = 40
+    prob = t.problems.rocket(10)
+    x0 = t.problems.rocket_x0(B, seed=2)
+    xr, ur = t.problems.rocket_refs(10)
+    kw = dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=60)
+    ref_sh = _oracle_batch(oracle_built, prob, x0, xref=xr, uref=ur, **kw)
+    rng = np.random.default_rng(5)
+    xr3 = np.repeat(xr[:, :, None], B, axis=2) * (1.0 + 0.1 * rng.standard_normal((1, 1, B)))
+    ur3 = np.repeat(ur[:, :, None], B, axis=2) + rng.standard_normal((3, 9, B))
+    ref_pi = _oracle_batch(oracle_built, prob, x0, xref=xr3, uref=ur3, **kw)
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+    assert bs.kernel_name == "quad<6,3,10>"
+    bs.update_settings(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=60, check_termination=1)
+    bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    bs.set_warm_start(False)
+    bs.set_x0(x0)
+    bs.set_x_ref(xr)
+    bs.set_u_ref(ur)
+    bs.solve()
+    sol = bs.get_solution()
+    assert nrel_batch(sol["states"], ref_sh["x"]).max() <= FP32_TOL
+    assert nrel_batch(sol["controls"], ref_sh["u"]).max() <= FP32_TOL
+    bs.set_x_ref(xr3)
+    bs.set_u_ref(ur3)
+    bs.solve()
+    sol = bs.get_solution()
+    assert nrel_batch(sol["states"], ref_pi["x"]).max() <= FP32_TOL
+    assert nrel_batch(sol["controls"], ref_pi["u"]).max() <= FP32_TOL
+    bs.close()
+
+
+@pytest.mark.parametrize("shape", ["cartpole_N15", "random_3x2_N7", "rocket_N50"])
+def test_generic_kernel_vs_oracle(hip_lib, oracle_built, shape):
+    """Shapes without a specialised instantiation run on the generic HIP kernel (never on the CPU)."""
+    rng = np.random.default_rng(11)
+    B = 70
+    xref = uref = None
+    if shape == "cartpole_N15":
+        prob = t.problems.cartpole(15, u_bound=0.5)
+        x0 = t.problems.cartpole_x0(B, seed=4)
+    elif shape == "rocket_N50":
+        prob = t.problems.rocket(50)
+        x0 = t.problems.rocket_x0(B, seed=2)
+        xref, uref = t.problems.rocket_refs(50)
+    else:
+        A = np.eye(3) + 0.1 * rng.standard_normal((3, 3))
+        Bm = rng.standard_normal((3, 2))
+        prob = t.problems.Problem("rand", A, Bm, np.diag([5.0, 2.0, 1.0]), np.diag([1.0, 2.0]), 2.0, 7)
+        prob.x_min, prob.x_max = np.full((3, 7), -2.0), np.full((3, 7), 2.0)
+        prob.u_min, prob.u_max = np.full((2, 6), -0.3), np.full((2, 6), 0.3)
+        x0 = np.asfortranarray(rng.uniform(-1, 1, (3, B)))
+    kw = dict(abs_pri_tol=1e-4, abs_dua_tol=1e-4, max_iter=80)
+    ref = _oracle_batch(oracle_built, prob, x0, xref=xref, uref=uref, **kw)
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+    assert bs.kernel_name == "generic"
+    bs.update_settings(check_termination=1, **kw)
+    bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    bs.set_x0(x0)
+    if xref is not None:
+        bs.set_x_ref(xref)
+        bs.set_u_ref(uref)
+    bs.solve()
+    sol, st = bs.get_solution(), bs.get_status()
+    same = st["iter"] == ref["iter"]
+    assert same.mean() >= 0.95 and np.all(np.abs(st["iter"] - ref["iter"]) <= 1)
+    assert nrel_batch(sol["states"], ref["x"])[same].max() <= FP32_TOL
+    assert nrel_batch(sol["controls"], ref["u"])[same].max() <= FP32_TOL
+    bs.close()
+
+
+@pytest.mark.parametrize("family", ["cartpole", "quadrotor"])
+def test_full_size_properties(hip_lib, oracle_built, family):
+    """BASELINE.json sizes (batch 65 536): size-independent properties.
+    (a) replication: the batch is 1024 copies of 64 distinct x0; every copy must be bit-identical
+        to its twin wherever it sits in the grid, and the 64 distinct solutions match the oracle;
+    (b) feasibility: every control inside the box (the reference's own assertion, test_basic.jl:66-68);
+    (c) determinism: a second solve returns the same bits."""
+    B, D = 65536, 64
+    if family == "cartpole":
+        prob, base = t.problems.cartpole(20, u_bound=0.5), t.problems.cartpole_x0(D, seed=0)
+    else:
+        prob, base = t.problems.quadrotor(30), t.problems.quadrotor_x0(D, seed=1)
+    x0 = np.asfortranarray(np.tile(base, (1, B // D)))
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+    bs.update_settings(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=100, check_termination=1)
+    bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    bs.set_warm_start(False)
+    bs.set_x0(x0)
+    assert bs.solve() == 1
+    sol = bs.get_solution()
+    X = sol["states"].reshape(prob.nx, prob.N, B // D, D)
+    U = sol["controls"].reshape(prob.nu, prob.N - 1, B // D, D)
+    assert np.array_equal(X, np.broadcast_to(X[:, :, :1, :], X.shape))
+    assert np.array_equal(U, np.broadcast_to(U[:, :, :1, :], U.shape))
+    assert U.max() <= 0.5 and U.min() >= -0.5
+    ref = _oracle_batch(oracle_built, prob, base, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=100, nthreads=8)
+    assert nrel_batch(X[:, :, 0, :], ref["x"]).max() <= FP32_TOL
+    assert nrel_batch(U[:, :, 0, :], ref["u"]).max() <= FP32_TOL
+    st = bs.get_status()
+    assert np.all(st["iter"] == 100)
+    bs.solve()
+    sol2 = bs.get_solution()
+    assert np.array_equal(sol2["states"], sol["states"]) and np.array_equal(sol2["controls"], sol["controls"])
+    bs.close()
+
+
+def test_edge_cases(hip_lib, oracle_built):
+    prob = t.problems.cartpole(20, u_bound=0.5)
+    # batch = 1, 3 (less than a quad row of a wavefront), 17 (one instance into the 2nd wavefront), 65
+    for B in (1, 3, 17, 65):
+        x0 = t.problems.cartpole_x0(B, seed=9)
+        ref = _oracle_batch(oracle_built, prob, x0, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=30)
+        bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+        bs.update_settings(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=30, check_termination=1)
+        bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        bs.set_x0(x0)
+        assert bs.solve() == 1
+        sol = bs.get_solution()
+        assert nrel_batch(sol["states"], ref["x"]).max() <= FP32_TOL
+        assert nrel_batch(sol["controls"], ref["u"]).max() <= FP32_TOL
+        bs.close()
+    # check_termination = 0: the reference traps (admm.cpp:91); here it means "never check":
+    # runs max_iter iterations, status 1, residual fields untouched (zero after setup)
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=2)
+    bs.update_settings(abs_pri_tol=10.0, abs_dua_tol=10.0, max_iter=5, check_termination=0)
+    bs.set_x0(t.problems.cartpole_x0(2, seed=1))
+    assert bs.solve() == 1
+    st = bs.get_status()
+    assert np.all(st["iter"] == 5) and np.all(st["solved"] == 0) and np.all(st["residuals"] == 0)
+    # check_termination = 3: residuals are evaluated on iterations 3, 6, ... only
+    ref = oracle_built.solve_batch("orc64", prob, t.problems.cartpole_x0(2, seed=1), abs_pri_tol=1e-3,
+                                   abs_dua_tol=1e-3, max_iter=50, check_termination=3)
+    bs.update_settings(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=50, check_termination=3,
+                       en_state_bound=1, en_input_bound=1)
+    bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    bs.reset()
+    bs.solve()
+    st = bs.get_status()
+    assert np.array_equal(st["iter"], ref["iter"]) and np.all(st["iter"] % 3 == 0)
+    # max_iter = 0: no iteration runs, status 1 (admm.cpp:125,206)
+    bs.update_settings(max_iter=0)
+    assert bs.solve() == 1
+    assert np.all(bs.get_status()["iter"] == 0)
+    bs.close()
+
+
+def test_error_behaviour(hip_lib):
+    """bindings.cpp error convention: -1 + message, never a crash; Julia-side wrappers raise."""
+    t.cleanup()
+    lib = t.load_library()
+    assert lib.solve_mpc(0) == -1                       # "Solver not initialized" (bindings.cpp:146-148)
+    s = t.TinyMPCSolver()
+    with pytest.raises(t.TinyMPCError):
+        t.set_x0(s, np.zeros(4))                        # "Solver not setup" (TinyMPC.jl:116)
+    prob = t.problems.cartpole(10)
+    with pytest.raises(t.TinyMPCError):                 # non-zero fdyn is refused, not ignored
+        t.setup(s, prob.A, prob.B, np.array([0, 0, 0.1, 0]), prob.Q, prob.R, 1.0, 4, 1, 10)
+    t.setup(s, prob.A, prob.B, np.zeros(4), prob.Q, prob.R, 1.0, 4, 1, 10)
+    with pytest.raises(t.TinyMPCError):
+        t.set_x0(s, np.zeros(5))                        # wrong length
+    with pytest.raises(t.TinyMPCError):
+        t.set_x_ref(s, np.zeros((4, 7)))                # wrong horizon
+    with pytest.raises(t.TinyMPCError):
+        t.update_settings(s, en_input_soc=True)         # SOC is refused, not silently dropped
+    with pytest.raises(t.TinyMPCError):
+        t.set_cone_constraints(s, [0], [3], [0.25], [], [], [])
+    assert t.set_cone_constraints(s, [], [], [], [], [], []) == 0
+    # update_settings resets en_*_bound like the reference (TinyMPC.jl:181-207 gotcha)
+    t.set_bound_constraints(s, np.full((4, 10), -1e17), np.full((4, 10), 1e17), np.full((1, 9), -0.1),
+                            np.full((1, 9), 0.1))
+    t.set_x0(s, np.array([0.5, 0, 0, 0]))
+    t.solve(s)
+    assert np.abs(t.get_solution(s)["controls"]).max() <= 0.1 + 1e-7
+    t.update_settings(s)                                # all defaults: bounds disabled again
+    t.reset_workspace(s)
+    t.solve(s)
+    assert np.abs(t.get_solution(s)["controls"]).max() > 0.5
+    t.cleanup()
+
+
+def test_set_cache_terms(hip_lib, oracle_built):
+    """tests/test_cache.jl: user-supplied cache matrices are used by the next solve."""
+    prob = t.problems.cartpole(10)
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=1)
+    c = bs.get_cache_terms()
+    K2 = c["Kinf"] * 1.05
+    bs.set_cache_terms(K2, c["Pinf"], c["Quu_inv"], c["AmBKt"])
+    bs.update_settings(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=20)
+    bs.set_x0(np.array([0.5, 0, 0, 0]))
+    bs.solve()
+    sol = bs.get_solution()
+    o = oracle_built.CpuSolver("orc64", prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N)
+    o.set_cache_terms(K2, c["Pinf"], c["Quu_inv"], c["AmBKt"])
+    o.update_settings(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=20)
+    o.set_x0([0.5, 0, 0, 0])
+    o.solve()
+    r = o.get_solution()
+    assert nrel(sol["states"][:, :, 0], r["x"]) <= FP32_TOL
+    assert nrel(sol["controls"][:, :, 0], r["u"]) <= FP32_TOL
+    bs.close()

@@ -1,0 +1,54 @@
+// Shared host/device definitions for the fused ADMM kernels.
+#pragma once
+#include <stdint.h>
+
+namespace tmpc {
+
+// How reference trajectories reach the kernel.
+enum RefMode : int {
+    REF_ZERO = 0,          // Xref = Uref = 0 (what tiny_setup leaves, tiny_api.cpp:102-103)
+    REF_SHARED = 1,        // one (nx,N)/(nu,N-1) pair broadcast over the batch
+    REF_PER_INSTANCE = 2,  // [B][N][nx] / [B][N-1][nu]
+};
+
+// Slots of the per-solve device status block (uint32 each).
+//   [0..3] max over instances of (pri_x, dua_x, pri_u, dua_u), float bits (non-negative
+//          floats order like unsigned ints, so atomicMax on the bits is a float max)
+//   [4]    number of instances that hit max_iter without converging
+//   [5]    number of instances whose solution contains a non-finite value
+enum { GSTAT_WORDS = 8 };
+
+// generic (runtime-shape) kernel limits
+constexpr int GEN_MAX_NX = 64;
+constexpr int GEN_MAX_NU = 32;
+
+struct AdmmParams {
+    // family constants (device pointers)
+    const float *coef;    // lane-role-major coefficient pack, layout in QuadShape / generic kernel
+    const float *bounds;  // per-knot bounds pack
+    // per-instance inputs
+    const float *x0;    // [B][nx]
+    const float *xref;  // REF_SHARED: [N][nx]   REF_PER_INSTANCE: [B][N][nx]
+    const float *uref;  // REF_SHARED: [N-1][nu] REF_PER_INSTANCE: [B][N-1][nu]
+    // per-instance outputs
+    float *xout;   // [B][N][nx]    projected slack vnew (admm.cpp:187,204)
+    float *uout;   // [B][N-1][nu]  projected slack znew (admm.cpp:188,205)
+    int *iter;     // [B]
+    int *solved;   // [B]
+    float *res;    // [B][4] pri_x, dua_x, pri_u, dua_u
+    // warm-start state, persists between solves: d,y,z [B][N-1][nu]; g,v [B][N][nx]
+    float *sd, *sy, *sz, *sg, *sv;
+    uint32_t *gstat;  // [GSTAT_WORDS]
+    // generic kernel only: per-instance scratch in HBM
+    float *scratch;
+    int batch;
+    int max_iter;
+    int check_termination;  // <= 0: never check (the reference divides by it, admm.cpp:91)
+    int ref_mode;
+    int cold_start;  // 1: start from the zero workspace, do not read sd..sv
+    int save_state;  // 1: write sd..sv back at exit
+    float abs_pri_tol, abs_dua_tol, rho;
+    int nx, nu, N;  // generic kernel only
+};
+
+}  // namespace tmpc

@@ -1,0 +1,454 @@
+// extern "C" surface of libtinympc_hip.so (declared in include/tinympc_hip.h).
+// The process-global entry points keep the names, argument lists and return
+// conventions of the reference shim (reference: src/bindings.cpp:15-490) so that
+// src/TinyMPC.jl's ccalls bind unchanged; the tinympc_* handle API adds the batch.
+#include <algorithm>
+#include <cstdio>
+#include <exception>
+#include <memory>
+
+#include "../../include/tinympc_hip.h"
+#include "solver.h"
+
+using tmpc::set_error;
+
+namespace {
+
+std::unique_ptr<tinympc_solver> g_solver;  // bindings.cpp:15
+
+template <class F>
+int guarded(const char *what, F &&f) {
+    try {
+        return f();
+    } catch (const std::exception &e) {
+        set_error(std::string(what) + " failed: " + e.what());
+        return -1;
+    } catch (...) {
+        set_error(std::string(what) + " failed: unknown exception");
+        return -1;
+    }
+}
+
+int need_global(const char *what) {
+    if (!g_solver) {
+        set_error(std::string(what) + " failed: Solver not initialized");  // bindings.cpp:77-79
+        return -1;
+    }
+    return 0;
+}
+
+bool dims_ok(const char *name, int r, int c, int er, int ec) {
+    if (r == er && c == ec) return true;
+    char buf[160];
+    std::snprintf(buf, sizeof buf, "%s has %d x %d, expected %d x %d", name, r, c, er, ec);
+    set_error(buf);
+    return false;
+}
+
+int sync_status(tinympc_solver *s, hipStream_t stream) {
+    if (!tmpc::hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize")) return -1;
+    return s->s.solve_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+/* ------------------------------ handle API ------------------------------ */
+
+int tinympc_create(tinympc_solver **out, const double *A, const double *B, const double *Q,
+                   const double *R, double rho, int nx, int nu, int N, int batch, int device,
+                   int verbose) {
+    return guarded("tinympc_create", [&]() -> int {
+        if (!out || !A || !B || !Q || !R) {
+            set_error("tinympc_create: null argument");
+            return -1;
+        }
+        std::unique_ptr<tinympc_solver> s(new tinympc_solver());
+        if (s->s.init(A, B, Q, R, rho, nx, nu, N, batch, device, verbose)) return -1;
+        *out = s.release();
+        return 0;
+    });
+}
+
+void tinympc_destroy(tinympc_solver *s) { delete s; }
+
+int tinympc_update_settings(tinympc_solver *s, double abs_pri_tol, double abs_dua_tol, int max_iter,
+                            int check_termination, int en_state_bound, int en_input_bound) {
+    if (!s) return -1;
+    if (max_iter < 0) {
+        set_error("update_settings: max_iter < 0");
+        return -1;
+    }
+    tmpc::Settings &st = s->s.st;
+    const bool flags_changed = st.en_state_bound != en_state_bound || st.en_input_bound != en_input_bound;
+    st.abs_pri_tol = abs_pri_tol;
+    st.abs_dua_tol = abs_dua_tol;
+    st.max_iter = max_iter;
+    st.check_termination = check_termination;
+    st.en_state_bound = en_state_bound ? 1 : 0;
+    st.en_input_bound = en_input_bound ? 1 : 0;
+    if (flags_changed) s->s.packs_dirty = true;
+    return 0;
+}
+
+int tinympc_set_bound_constraints(tinympc_solver *s, const double *x_min, const double *x_max,
+                                  const double *u_min, const double *u_max) {
+    if (!s || !x_min || !x_max || !u_min || !u_max) return -1;
+    return guarded("set_bound_constraints", [&] { return s->s.set_bounds(x_min, x_max, u_min, u_max); });
+}
+
+int tinympc_set_cache_terms(tinympc_solver *s, const double *Kinf, const double *Pinf,
+                            const double *Quu_inv, const double *AmBKt) {
+    if (!s || !Kinf || !Pinf || !Quu_inv || !AmBKt) return -1;
+    tmpc::Solver &v = s->s;
+    v.cache.Kinf = tmpc::Mat(v.nu, v.nx, Kinf);
+    v.cache.Pinf = tmpc::Mat(v.nx, v.nx, Pinf);
+    v.cache.Quu_inv = tmpc::Mat(v.nu, v.nu, Quu_inv);
+    v.cache.AmBKt = tmpc::Mat(v.nx, v.nx, AmBKt);
+    v.packs_dirty = true;
+    return 0;
+}
+
+int tinympc_get_cache_terms(tinympc_solver *s, double *Kinf, double *Pinf, double *Quu_inv,
+                            double *AmBKt) {
+    if (!s) return -1;
+    const tmpc::Cache &c = s->s.cache;
+    if (Kinf) std::copy(c.Kinf.a.begin(), c.Kinf.a.end(), Kinf);
+    if (Pinf) std::copy(c.Pinf.a.begin(), c.Pinf.a.end(), Pinf);
+    if (Quu_inv) std::copy(c.Quu_inv.a.begin(), c.Quu_inv.a.end(), Quu_inv);
+    if (AmBKt) std::copy(c.AmBKt.a.begin(), c.AmBKt.a.end(), AmBKt);
+    return 0;
+}
+
+int tinympc_set_x0(tinympc_solver *s, const double *x0, int cols) {
+    if (!s || !x0) return -1;
+    return guarded("set_x0", [&] { return s->s.set_x0(x0, cols); });
+}
+int tinympc_set_x_ref(tinympc_solver *s, const double *x_ref, int cols) {
+    if (!s || !x_ref) return -1;
+    return guarded("set_x_ref", [&] { return s->s.set_ref(true, x_ref, cols); });
+}
+int tinympc_set_u_ref(tinympc_solver *s, const double *u_ref, int cols) {
+    if (!s || !u_ref) return -1;
+    return guarded("set_u_ref", [&] { return s->s.set_ref(false, u_ref, cols); });
+}
+int tinympc_reset(tinympc_solver *s) { return s ? s->s.reset() : -1; }
+int tinympc_set_warm_start(tinympc_solver *s, int warm_start) {
+    if (!s) return -1;
+    s->s.warm_start = warm_start != 0;
+    return 0;
+}
+
+int tinympc_solve(tinympc_solver *s) {
+    if (!s) return -1;
+    return guarded("solve", [&]() -> int {
+        if (s->s.solve_async(nullptr)) return -1;
+        return sync_status(s, nullptr);
+    });
+}
+int tinympc_solve_async(tinympc_solver *s, void *hip_stream) {
+    if (!s) return -1;
+    return guarded("solve_async", [&] { return s->s.solve_async((hipStream_t)hip_stream); });
+}
+int tinympc_solve_status(tinympc_solver *s) { return s ? s->s.solve_status() : -1; }
+
+int tinympc_get_states(tinympc_solver *s, double *buf) {
+    if (!s || !buf) return -1;
+    return guarded("get_states", [&] { return s->s.get_traj(true, buf); });
+}
+int tinympc_get_controls(tinympc_solver *s, double *buf) {
+    if (!s || !buf) return -1;
+    return guarded("get_controls", [&] { return s->s.get_traj(false, buf); });
+}
+int tinympc_get_status(tinympc_solver *s, int *iter, int *solved, double *residuals4) {
+    if (!s) return -1;
+    return guarded("get_status", [&] { return s->s.get_status(iter, solved, residuals4); });
+}
+int tinympc_get_workspace(tinympc_solver *s, double *d, double *y, double *g, double *v, double *z) {
+    if (!s) return -1;
+    return guarded("get_workspace", [&] { return s->s.get_workspace(d, y, g, v, z); });
+}
+int tinympc_set_workspace(tinympc_solver *s, const double *d, const double *y, const double *g,
+                          const double *v, const double *z) {
+    if (!s) return -1;
+    return guarded("set_workspace", [&] { return s->s.set_workspace(d, y, g, v, z); });
+}
+
+int tinympc_device_buffers(tinympc_solver *s, void **x0, void **x_ref, void **u_ref, void **states,
+                           void **controls, void **iter, void **solved, void **residuals,
+                           void **gstat) {
+    if (!s) return -1;
+    tmpc::Solver &v = s->s;
+    if (x0) *x0 = v.d_x0;
+    if (x_ref) *x_ref = v.d_xref;
+    if (u_ref) *u_ref = v.d_uref;
+    if (states) *states = v.d_xout;
+    if (controls) *controls = v.d_uout;
+    if (iter) *iter = v.d_iter;
+    if (solved) *solved = v.d_solved;
+    if (residuals) *residuals = v.d_res;
+    if (gstat) *gstat = v.d_gstat;
+    return 0;
+}
+
+int tinympc_set_ref_mode(tinympc_solver *s, int ref_mode) {
+    if (!s || ref_mode < 0 || ref_mode > 2) return -1;
+    return guarded("set_ref_mode", [&]() -> int {
+        tmpc::Solver &v = s->s;
+        // make the device buffers large enough for the mode, then hand them to the caller
+        v.xref_kind = v.uref_kind = ref_mode;
+        v.h_xref.assign(ref_mode == 2 ? (size_t)v.batch * v.ex() : (ref_mode == 1 ? v.ex() : 0), 0.f);
+        v.h_uref.assign(ref_mode == 2 ? (size_t)v.batch * v.eu() : (ref_mode == 1 ? v.eu() : 0), 0.f);
+        v.refs_dirty = true;
+        v.refs_device_owned = false;
+        if (v.upload_refs()) return -1;
+        v.h_xref.clear();
+        v.h_uref.clear();
+        v.refs_device_owned = true;
+        return 0;
+    });
+}
+
+const char *tinympc_kernel_name(tinympc_solver *s) { return s ? s->s.kernel_name.c_str() : ""; }
+
+/* compulsory fp32 device I/O per solve, state on chip. */
+double tinympc_algorithmic_bytes(tinympc_solver *s) {
+    if (!s) return 0;
+    const tmpc::Solver &v = s->s;
+    const double EX = v.ex(), EU = v.eu();
+    double per = 4.0 * v.nx + 4.0 * (EX + EU) + 24.0;             // x0 in, x/u out, iter/solved/4 res
+    if (v.ref_mode == tmpc::REF_PER_INSTANCE) per += 4.0 * (EX + EU);
+    if (v.warm_start) per += 2.0 * 4.0 * (3.0 * EU + 2.0 * EX);   // d,y,z,g,v in and out
+    return per * v.batch;
+}
+
+/* 2(N-1)(2nx^2+4nx nu+nu^2) + (N-1)(nu+2nx) + 15(Ex+Eu) + 2nx^2 + 3nx per iteration. */
+double tinympc_algorithmic_flops(tinympc_solver *s, int iters) {
+    if (!s) return 0;
+    const tmpc::Solver &v = s->s;
+    const double nx = v.nx, nu = v.nu, N = v.N, EX = v.ex(), EU = v.eu();
+    const double per_it = 2.0 * (N - 1) * (2 * nx * nx + 4 * nx * nu + nu * nu) + (N - 1) * (nu + 2 * nx) +
+                          15.0 * (EX + EU) + 2 * nx * nx + 3 * nx;
+    return per_it * iters * v.batch;
+}
+
+const char *tinympc_last_error(void) { return tmpc::last_error(); }
+
+int tinympc_host_precompute(const double *A, const double *B, const double *Q, const double *R,
+                            double rho, int nx, int nu, double *Kinf, double *Pinf,
+                            double *Quu_inv, double *AmBKt) {
+    return guarded("host_precompute", [&]() -> int {
+        if (!A || !B || !Q || !R || nx < 1 || nu < 1) return -1;
+        tmpc::Cache c;
+        if (tmpc::precompute_cache(tmpc::Mat(nx, nx, A), tmpc::Mat(nx, nu, B), tmpc::Mat(nx, nx, Q),
+                                   tmpc::Mat(nu, nu, R), rho, c)) {
+            set_error("Riccati precompute failed: R + B'PB is singular");
+            return -1;
+        }
+        if (Kinf) std::copy(c.Kinf.a.begin(), c.Kinf.a.end(), Kinf);
+        if (Pinf) std::copy(c.Pinf.a.begin(), c.Pinf.a.end(), Pinf);
+        if (Quu_inv) std::copy(c.Quu_inv.a.begin(), c.Quu_inv.a.end(), Quu_inv);
+        if (AmBKt) std::copy(c.AmBKt.a.begin(), c.AmBKt.a.end(), AmBKt);
+        return 0;
+    });
+}
+
+/* --------------------- process-global solver (drop-in) --------------------- */
+
+int setup_solver(double *A_data, int A_rows, int A_cols, double *B_data, int B_rows, int B_cols,
+                 double *fdyn_data, int fdyn_rows, int fdyn_cols, double *Q_data, int Q_rows,
+                 int Q_cols, double *R_data, int R_rows, int R_cols, double rho, int nx, int nu,
+                 int N, int verbose) {
+    return guarded("setup_solver", [&]() -> int {
+        if (!A_data || !B_data || !Q_data || !R_data) {
+            set_error("setup_solver: null matrix");
+            g_solver.reset();
+            return -1;
+        }
+        if (!dims_ok("A", A_rows, A_cols, nx, nx) || !dims_ok("B", B_rows, B_cols, nx, nu) ||
+            !dims_ok("Q", Q_rows, Q_cols, nx, nx) || !dims_ok("R", R_rows, R_cols, nu, nu)) {
+            g_solver.reset();
+            return -1;
+        }
+        if (fdyn_data)
+            for (long i = 0; i < (long)fdyn_rows * fdyn_cols; ++i)
+                if (fdyn_data[i] != 0.0) {
+                    set_error("setup_solver: non-zero fdyn (affine dynamics) is not supported: that term "
+                              "exists only in the un-vendored TinyMPC submodule");
+                    g_solver.reset();
+                    return -1;
+                }
+        tinympc_solver *s = nullptr;
+        if (tinympc_create(&s, A_data, B_data, Q_data, R_data, rho, nx, nu, N, 1, -1, verbose)) {
+            g_solver.reset();
+            return -1;
+        }
+        g_solver.reset(s);  // a second setup replaces the first (bindings.cpp:63)
+        return 0;
+    });
+}
+
+int set_batch_size(int batch) {
+    if (need_global("set_batch_size")) return -1;
+    return guarded("set_batch_size", [&] { return g_solver->s.alloc_batch(batch); });
+}
+int get_batch_size(void) { return g_solver ? g_solver->s.batch : 0; }
+
+int set_x0(double *x0_data, int x0_rows, int x0_cols, int verbose) {
+    (void)verbose;
+    if (need_global("set_x0")) return -1;
+    if (x0_rows != g_solver->s.nx) {
+        set_error("set_x0: x0 is not the correct length");
+        return -1;
+    }
+    return tinympc_set_x0(g_solver.get(), x0_data, x0_cols);
+}
+int set_x_ref(double *x_ref_data, int x_ref_rows, int x_ref_cols, int verbose) {
+    (void)verbose;
+    if (need_global("set_x_ref")) return -1;
+    if (x_ref_rows != g_solver->s.nx) {
+        set_error("set_x_ref: wrong number of rows");
+        return -1;
+    }
+    return tinympc_set_x_ref(g_solver.get(), x_ref_data, x_ref_cols);
+}
+int set_u_ref(double *u_ref_data, int u_ref_rows, int u_ref_cols, int verbose) {
+    (void)verbose;
+    if (need_global("set_u_ref")) return -1;
+    if (u_ref_rows != g_solver->s.nu) {
+        set_error("set_u_ref: wrong number of rows");
+        return -1;
+    }
+    return tinympc_set_u_ref(g_solver.get(), u_ref_data, u_ref_cols);
+}
+
+int solve_mpc(int verbose) {
+    if (need_global("solve_mpc")) return -1;
+    const int st = tinympc_solve(g_solver.get());
+    if (verbose) std::printf("Solve completed with status: %d\n", st);
+    return st;
+}
+
+int get_states(double *states_buffer, int *rows, int *cols) {
+    if (!g_solver || !states_buffer || !rows || !cols) return -1;
+    *rows = g_solver->s.nx;
+    *cols = g_solver->s.N * g_solver->s.batch;
+    return tinympc_get_states(g_solver.get(), states_buffer);
+}
+int get_controls(double *controls_buffer, int *rows, int *cols) {
+    if (!g_solver || !controls_buffer || !rows || !cols) return -1;
+    *rows = g_solver->s.nu;
+    *cols = (g_solver->s.N - 1) * g_solver->s.batch;
+    return tinympc_get_controls(g_solver.get(), controls_buffer);
+}
+
+void cleanup_solver(void) { g_solver.reset(); }
+
+int update_settings(double abs_pri_tol, double abs_dua_tol, int max_iter, int check_termination,
+                    int en_state_bound, int en_input_bound, int en_state_soc, int en_input_soc,
+                    int en_state_linear, int en_input_linear, int adaptive_rho,
+                    double adaptive_rho_min, double adaptive_rho_max,
+                    int adaptive_rho_enable_clipping, int verbose) {
+    (void)adaptive_rho_min;
+    (void)adaptive_rho_max;
+    (void)adaptive_rho_enable_clipping;
+    (void)verbose;
+    if (need_global("update_settings")) return -1;
+    if (en_state_soc || en_input_soc || en_state_linear || en_input_linear) {
+        set_error("update_settings: SOC / linear constraints are not supported (submodule-only arithmetic)");
+        return -1;
+    }
+    if (adaptive_rho) {
+        set_error("update_settings: adaptive_rho is not supported (out of scope, SURVEY.md §2 #7)");
+        return -1;
+    }
+    return tinympc_update_settings(g_solver.get(), abs_pri_tol, abs_dua_tol, max_iter, check_termination,
+                                   en_state_bound, en_input_bound);
+}
+
+int set_bound_constraints(double *x_min_data, int x_min_rows, int x_min_cols, double *x_max_data,
+                          int x_max_rows, int x_max_cols, double *u_min_data, int u_min_rows,
+                          int u_min_cols, double *u_max_data, int u_max_rows, int u_max_cols,
+                          int verbose) {
+    (void)verbose;
+    if (need_global("set_bound_constraints")) return -1;
+    const tmpc::Solver &v = g_solver->s;
+    if (!dims_ok("x_min", x_min_rows, x_min_cols, v.nx, v.N) ||
+        !dims_ok("x_max", x_max_rows, x_max_cols, v.nx, v.N) ||
+        !dims_ok("u_min", u_min_rows, u_min_cols, v.nu, v.N - 1) ||
+        !dims_ok("u_max", u_max_rows, u_max_cols, v.nu, v.N - 1))
+        return -1;
+    return tinympc_set_bound_constraints(g_solver.get(), x_min_data, x_max_data, u_min_data, u_max_data);
+}
+
+int set_cache_terms(double *Kinf_data, int Kinf_rows, int Kinf_cols, double *Pinf_data,
+                    int Pinf_rows, int Pinf_cols, double *Quu_inv_data, int Quu_inv_rows,
+                    int Quu_inv_cols, double *AmBKt_data, int AmBKt_rows, int AmBKt_cols,
+                    int verbose) {
+    (void)verbose;
+    if (need_global("set_cache_terms")) return -1;
+    const tmpc::Solver &v = g_solver->s;
+    if (!dims_ok("Kinf", Kinf_rows, Kinf_cols, v.nu, v.nx) ||
+        !dims_ok("Pinf", Pinf_rows, Pinf_cols, v.nx, v.nx) ||
+        !dims_ok("Quu_inv", Quu_inv_rows, Quu_inv_cols, v.nu, v.nu) ||
+        !dims_ok("AmBKt", AmBKt_rows, AmBKt_cols, v.nx, v.nx))
+        return -1;
+    return tinympc_set_cache_terms(g_solver.get(), Kinf_data, Pinf_data, Quu_inv_data, AmBKt_data);
+}
+
+int print_problem_data(int verbose) {
+    if (need_global("print_problem_data")) return -1;
+    const tmpc::Solver &v = g_solver->s;
+    std::printf("=== TinyMPC Problem Data ===\n");
+    std::printf("Problem: nx=%d, nu=%d, N=%d, batch=%d, kernel=%s\n", v.nx, v.nu, v.N, v.batch,
+                v.kernel_name.c_str());
+    std::printf("Cache: rho=%g\n", v.cache.rho);
+    std::printf("Settings: max_iter=%d, abs_pri_tol=%g, abs_dua_tol=%g, check_termination=%d\n",
+                v.st.max_iter, v.st.abs_pri_tol, v.st.abs_dua_tol, v.st.check_termination);
+    if (verbose) {
+        std::printf("Cache Kinf (%d x %d):\n", v.nu, v.nx);
+        for (int i = 0; i < v.nu; ++i) {
+            for (int j = 0; j < v.nx; ++j) std::printf(" %.10g", v.cache.Kinf(i, j));
+            std::printf("\n");
+        }
+    }
+    return 0;
+}
+
+int set_linear_constraints(double *Alin_x_data, int Alin_x_rows, int Alin_x_cols, double *blin_x_data,
+                           int blin_x_len, double *Alin_u_data, int Alin_u_rows, int Alin_u_cols,
+                           double *blin_u_data, int blin_u_len, int verbose) {
+    (void)Alin_x_data; (void)Alin_x_cols; (void)blin_x_data; (void)Alin_u_data; (void)Alin_u_cols;
+    (void)blin_u_data; (void)verbose;
+    if (need_global("set_linear_constraints")) return -1;
+    if ((Alin_x_rows > 0 && blin_x_len > 0) || (Alin_u_rows > 0 && blin_u_len > 0)) {
+        set_error("set_linear_constraints: not supported (arithmetic lives only in the absent TinyMPC submodule)");
+        return -1;
+    }
+    return 0;
+}
+
+int set_cone_constraints(int *Acu_data, int Acu_len, int *qcu_data, int qcu_len, double *cu_data,
+                         int cu_len, int *Acx_data, int Acx_len, int *qcx_data, int qcx_len,
+                         double *cx_data, int cx_len, int verbose) {
+    (void)Acu_data; (void)qcu_data; (void)cu_data; (void)Acx_data; (void)qcx_data; (void)cx_data;
+    (void)verbose;
+    if (need_global("set_cone_constraints")) return -1;
+    if ((Acu_len > 0 && qcu_len > 0 && cu_len > 0) || (Acx_len > 0 && qcx_len > 0 && cx_len > 0)) {
+        set_error("set_cone_constraints: not supported (arithmetic lives only in the absent TinyMPC submodule)");
+        return -1;
+    }
+    return 0;
+}
+
+int get_status(int *iter, int *solved, double *residuals4) {
+    if (need_global("get_status")) return -1;
+    return tinympc_get_status(g_solver.get(), iter, solved, residuals4);
+}
+int reset_workspace(void) {
+    if (need_global("reset_workspace")) return -1;
+    return tinympc_reset(g_solver.get());
+}
+
+}  // extern "C"

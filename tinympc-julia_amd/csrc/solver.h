@@ -1,0 +1,100 @@
+// Batched TinyMPC solver object behind the C-ABI (include/tinympc_hip.h).
+// Host side of the drop-in boundary that replaces the reference's global
+// `g_solver` + tiny_* calls (reference: src/bindings.cpp:15-490).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "admm_params.h"
+#include "host_setup.h"
+
+namespace tmpc {
+
+struct Solver;
+
+// One specialised quad-kernel instantiation (admm_quad.hip.h) and its pack builders.
+struct KernelEntry {
+    int nx, nu, N;
+    const char *name;
+    int coef_len, bounds_len;
+    void (*build_coef)(const Solver &, std::vector<float> &);
+    void (*build_bounds)(const Solver &, std::vector<float> &);
+    hipError_t (*launch)(const AdmmParams &, hipStream_t);
+};
+const KernelEntry *find_quad_kernel(int nx, int nu, int N);
+hipError_t launch_generic(const AdmmParams &, hipStream_t);
+void build_generic_coef(const Solver &, std::vector<float> &);
+void build_generic_bounds(const Solver &, std::vector<float> &);
+
+struct Settings {
+    double abs_pri_tol = 1e-3, abs_dua_tol = 1e-3;  // TinyMPC.jl:57-58
+    int max_iter = 100;                              // TinyMPC.jl:59
+    int check_termination = 1;                       // TinyMPC.jl:59,202
+    int en_state_bound = 0, en_input_bound = 0;      // TinyMPC.jl:94-95
+};
+
+struct Solver {
+    int nx = 0, nu = 0, N = 0, batch = 1, device = 0;
+    int verbose = 0;
+    Mat A, B, Q, R;
+    Cache cache;
+    Settings st;
+    // per-knot bounds, column-major fp64 (nx x N, nu x (N-1)); +-1e17 until set
+    std::vector<double> x_min, x_max, u_min, u_max;
+    // references as last set by the host API: kind 0 zero / 1 shared / 2 per instance
+    std::vector<float> h_xref, h_uref;
+    int xref_kind = 0, uref_kind = 0;
+    bool refs_dirty = true;
+    bool refs_device_owned = false;  // caller writes d_xref/d_uref itself (tinympc_set_ref_mode)
+    int ref_mode = REF_ZERO;
+    bool warm_start = true;
+    bool packs_dirty = true;
+    const KernelEntry *ke = nullptr;  // nullptr: generic kernel
+    std::string kernel_name;
+    // device buffers
+    float *d_coef = nullptr, *d_bounds = nullptr;
+    float *d_x0 = nullptr, *d_xref = nullptr, *d_uref = nullptr;
+    size_t xref_cap = 0, uref_cap = 0;  // floats allocated
+    float *d_xout = nullptr, *d_uout = nullptr, *d_res = nullptr;
+    int *d_iter = nullptr, *d_solved = nullptr;
+    float *d_sd = nullptr, *d_sy = nullptr, *d_sz = nullptr, *d_sg = nullptr, *d_sv = nullptr;
+    uint32_t *d_gstat = nullptr;
+    uint32_t *h_gstat = nullptr;  // pinned
+    float *d_scratch = nullptr;
+    size_t scratch_cap = 0;
+    bool solved_once = false;
+
+    int ex() const { return nx * N; }
+    int eu() const { return nu * (N - 1); }
+
+    ~Solver();
+    int init(const double *A_, const double *B_, const double *Q_, const double *R_, double rho,
+             int nx_, int nu_, int N_, int batch_, int device_, int verbose_);
+    int alloc_batch(int batch_);
+    void free_batch();
+    int upload_packs();
+    int upload_refs();
+    int set_x0(const double *x0, int cols);
+    int set_ref(bool is_x, const double *ref, int cols);
+    int set_bounds(const double *xmin, const double *xmax, const double *umin, const double *umax);
+    int reset();
+    int solve_async(hipStream_t stream);
+    int solve_status();
+    int get_traj(bool states, double *buf);
+    int get_status(int *iter, int *solved, double *res4);
+    int get_workspace(double *d, double *y, double *g, double *v, double *z);
+    int set_workspace(const double *d, const double *y, const double *g, const double *v,
+                      const double *z);
+};
+
+void set_error(const std::string &msg);
+const char *last_error();
+bool hip_ok(hipError_t e, const char *what);
+
+}  // namespace tmpc
+
+struct tinympc_solver {
+    tmpc::Solver s;
+};

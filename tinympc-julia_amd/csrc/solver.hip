@@ -1,0 +1,377 @@
+// Host side of the batched solver: device memory, pack uploads, launches.
+#include "solver.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+
+namespace tmpc {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) {
+    g_err = msg;
+    std::fprintf(stderr, "tinympc_hip: %s\n", msg.c_str());
+}
+const char *last_error() { return g_err.c_str(); }
+bool hip_ok(hipError_t e, const char *what) {
+    if (e == hipSuccess) return true;
+    set_error(std::string(what) + ": " + hipGetErrorString(e));
+    return false;
+}
+#define HIP_TRY(expr)                       \
+    do {                                    \
+        if (!hip_ok((expr), #expr)) return -1; \
+    } while (0)
+
+template <class T>
+static int dev_alloc(T *&p, size_t n) {
+    if (p) {
+        (void)hipFree(p);
+        p = nullptr;
+    }
+    if (n == 0) n = 1;
+    HIP_TRY(hipMalloc((void **)&p, n * sizeof(T)));
+    return 0;
+}
+template <class T>
+static void dev_free(T *&p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+Solver::~Solver() {
+    free_batch();
+    dev_free(d_coef);
+    dev_free(d_bounds);
+    dev_free(d_gstat);
+    if (h_gstat) (void)hipHostFree(h_gstat);
+    h_gstat = nullptr;
+}
+
+void Solver::free_batch() {
+    dev_free(d_x0);
+    dev_free(d_xref);
+    dev_free(d_uref);
+    dev_free(d_xout);
+    dev_free(d_uout);
+    dev_free(d_res);
+    dev_free(d_iter);
+    dev_free(d_solved);
+    dev_free(d_sd);
+    dev_free(d_sy);
+    dev_free(d_sz);
+    dev_free(d_sg);
+    dev_free(d_sv);
+    dev_free(d_scratch);
+    xref_cap = uref_cap = scratch_cap = 0;
+}
+
+int Solver::init(const double *A_, const double *B_, const double *Q_, const double *R_, double rho,
+                 int nx_, int nu_, int N_, int batch_, int device_, int verbose_) {
+    if (nx_ < 1 || nu_ < 1 || N_ < 2 || batch_ < 1) {
+        set_error("invalid dimensions (need nx >= 1, nu >= 1, N >= 2, batch >= 1)");
+        return -1;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        set_error("no HIP device available (this library has no CPU fallback)");
+        return -1;
+    }
+    if (device_ < 0) HIP_TRY(hipGetDevice(&device_));
+    device = device_;
+    HIP_TRY(hipSetDevice(device));
+    nx = nx_;
+    nu = nu_;
+    N = N_;
+    verbose = verbose_;
+    A = Mat(nx, nx, A_);
+    B = Mat(nx, nu, B_);
+    Q = Mat(nx, nx, Q_);
+    R = Mat(nu, nu, R_);
+    if (precompute_cache(A, B, Q, R, rho, cache) != 0) {
+        set_error("Riccati precompute failed: R + B'PB is singular");
+        return -1;
+    }
+    if (verbose)
+        std::printf("tinympc_hip: setup nx=%d nu=%d N=%d rho=%g batch=%d (Riccati %d sweeps)\n", nx, nu,
+                    N, rho, batch_, cache.riccati_iters);
+    x_min.assign((size_t)ex(), -1e17);
+    x_max.assign((size_t)ex(), 1e17);
+    u_min.assign((size_t)eu(), -1e17);
+    u_max.assign((size_t)eu(), 1e17);
+    ke = find_quad_kernel(nx, nu, N);
+    if (!ke && (nx > GEN_MAX_NX || nu > GEN_MAX_NU)) {
+        set_error("problem shape exceeds the generic kernel limits (nx <= 64, nu <= 32)");
+        return -1;
+    }
+    kernel_name = ke ? ke->name : "generic";
+    if (dev_alloc(d_gstat, (size_t)GSTAT_WORDS)) return -1;
+    HIP_TRY(hipHostMalloc((void **)&h_gstat, GSTAT_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+    std::memset(h_gstat, 0, GSTAT_WORDS * sizeof(uint32_t));
+    packs_dirty = true;
+    return alloc_batch(batch_);
+}
+
+int Solver::alloc_batch(int batch_) {
+    if (batch_ < 1) {
+        set_error("batch must be >= 1");
+        return -1;
+    }
+    HIP_TRY(hipSetDevice(device));
+    free_batch();
+    batch = batch_;
+    const size_t Bn = (size_t)batch, EX = (size_t)ex(), EU = (size_t)eu();
+    if (dev_alloc(d_x0, Bn * nx) || dev_alloc(d_xout, Bn * EX) || dev_alloc(d_uout, Bn * EU) ||
+        dev_alloc(d_res, Bn * 4) || dev_alloc(d_iter, Bn) || dev_alloc(d_solved, Bn) ||
+        dev_alloc(d_sd, Bn * EU) || dev_alloc(d_sy, Bn * EU) || dev_alloc(d_sz, Bn * EU) ||
+        dev_alloc(d_sg, Bn * EX) || dev_alloc(d_sv, Bn * EX))
+        return -1;
+    // shared-size reference buffers up front; per-instance ones on demand
+    if (dev_alloc(d_xref, EX) || dev_alloc(d_uref, EU)) return -1;
+    xref_cap = EX;
+    uref_cap = EU;
+    HIP_TRY(hipMemset(d_x0, 0, Bn * nx * sizeof(float)));
+    HIP_TRY(hipMemset(d_xout, 0, Bn * EX * sizeof(float)));
+    HIP_TRY(hipMemset(d_uout, 0, Bn * EU * sizeof(float)));
+    HIP_TRY(hipMemset(d_iter, 0, Bn * sizeof(int)));
+    HIP_TRY(hipMemset(d_solved, 0, Bn * sizeof(int)));
+    HIP_TRY(hipMemset(d_xref, 0, EX * sizeof(float)));
+    HIP_TRY(hipMemset(d_uref, 0, EU * sizeof(float)));
+    h_xref.clear();
+    h_uref.clear();
+    xref_kind = uref_kind = 0;
+    ref_mode = REF_ZERO;
+    refs_dirty = false;
+    refs_device_owned = false;
+    if (!ke) {
+        scratch_cap = Bn * (6 * EX + 6 * EU);
+        if (dev_alloc(d_scratch, scratch_cap)) return -1;
+    }
+    solved_once = false;
+    return reset();
+}
+
+int Solver::reset() {
+    HIP_TRY(hipSetDevice(device));
+    const size_t Bn = (size_t)batch, EX = (size_t)ex(), EU = (size_t)eu();
+    HIP_TRY(hipMemset(d_sd, 0, Bn * EU * sizeof(float)));
+    HIP_TRY(hipMemset(d_sy, 0, Bn * EU * sizeof(float)));
+    HIP_TRY(hipMemset(d_sz, 0, Bn * EU * sizeof(float)));
+    HIP_TRY(hipMemset(d_sg, 0, Bn * EX * sizeof(float)));
+    HIP_TRY(hipMemset(d_sv, 0, Bn * EX * sizeof(float)));
+    HIP_TRY(hipMemset(d_res, 0, Bn * 4 * sizeof(float)));
+    return 0;
+}
+
+int Solver::upload_packs() {
+    std::vector<float> coef, bnd;
+    if (ke) {
+        ke->build_coef(*this, coef);
+        ke->build_bounds(*this, bnd);
+    } else {
+        build_generic_coef(*this, coef);
+        build_generic_bounds(*this, bnd);
+    }
+    if (dev_alloc(d_coef, coef.size()) || dev_alloc(d_bounds, bnd.size())) return -1;
+    HIP_TRY(hipMemcpy(d_coef, coef.data(), coef.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_bounds, bnd.data(), bnd.size() * sizeof(float), hipMemcpyHostToDevice));
+    packs_dirty = false;
+    return 0;
+}
+
+int Solver::set_x0(const double *x0, int cols) {
+    if (cols != 1 && cols != batch) {
+        set_error("set_x0: expected nx x 1 or nx x batch");
+        return -1;
+    }
+    HIP_TRY(hipSetDevice(device));
+    std::vector<float> h((size_t)batch * nx);
+    for (int b = 0; b < batch; ++b)
+        for (int i = 0; i < nx; ++i) h[(size_t)b * nx + i] = (float)x0[(cols == 1 ? 0 : (size_t)b * nx) + i];
+    HIP_TRY(hipMemcpy(d_x0, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int Solver::set_ref(bool is_x, const double *ref, int cols) {
+    const int kn = is_x ? N : N - 1;       // knots
+    const int rows = is_x ? nx : nu;
+    int kind;
+    if (cols == kn)
+        kind = 1;
+    else if ((long)cols == (long)kn * batch)
+        kind = 2;
+    else {
+        set_error(is_x ? "set_x_ref: expected nx x N or nx x (N*batch)"
+                       : "set_u_ref: expected nu x (N-1) or nu x ((N-1)*batch)");
+        return -1;
+    }
+    std::vector<float> &h = is_x ? h_xref : h_uref;
+    const size_t n = (size_t)rows * cols;
+    h.resize(n);
+    bool all_zero = true;
+    for (size_t i = 0; i < n; ++i) {
+        h[i] = (float)ref[i];
+        all_zero = all_zero && (ref[i] == 0.0);
+    }
+    if (all_zero) {
+        kind = 0;  // identical arithmetic (-(0*Q) - rho(..) == 0 - rho(..)), cheaper kernel
+        h.clear();
+    }
+    (is_x ? xref_kind : uref_kind) = kind;
+    refs_dirty = true;
+    refs_device_owned = false;
+    return 0;
+}
+
+// Materialise h_xref/h_uref on the device in one common mode for the kernel.
+int Solver::upload_refs() {
+    if (refs_device_owned || !refs_dirty) return 0;
+    HIP_TRY(hipSetDevice(device));
+    const int mode = xref_kind > uref_kind ? xref_kind : uref_kind;
+    const size_t EX = (size_t)ex(), EU = (size_t)eu(), Bn = (size_t)batch;
+    auto put = [&](float *&dptr, size_t &cap, const std::vector<float> &h, int kind, size_t E) -> int {
+        const size_t need = mode == REF_PER_INSTANCE ? Bn * E : E;
+        if (cap < need) {
+            if (dev_alloc(dptr, need)) return -1;
+            cap = need;
+        }
+        if (mode == REF_ZERO) return 0;
+        std::vector<float> tmp;
+        const float *src;
+        if (kind == mode) {
+            src = h.data();
+        } else {
+            tmp.assign(need, 0.f);
+            if (kind == 1)  // shared -> replicate per instance
+                for (size_t b = 0; b < Bn; ++b) std::memcpy(tmp.data() + b * E, h.data(), E * sizeof(float));
+            src = tmp.data();
+        }
+        HIP_TRY(hipMemcpy(dptr, src, need * sizeof(float), hipMemcpyHostToDevice));
+        return 0;
+    };
+    if (put(d_xref, xref_cap, h_xref, xref_kind, EX)) return -1;
+    if (put(d_uref, uref_cap, h_uref, uref_kind, EU)) return -1;
+    ref_mode = mode;
+    refs_dirty = false;
+    return 0;
+}
+
+int Solver::set_bounds(const double *xmin, const double *xmax, const double *umin, const double *umax) {
+    x_min.assign(xmin, xmin + ex());
+    x_max.assign(xmax, xmax + ex());
+    u_min.assign(umin, umin + eu());
+    u_max.assign(umax, umax + eu());
+    st.en_state_bound = 1;  // bindings.cpp:400-404
+    st.en_input_bound = 1;
+    packs_dirty = true;
+    return 0;
+}
+
+int Solver::solve_async(hipStream_t stream) {
+    HIP_TRY(hipSetDevice(device));
+    if (packs_dirty && upload_packs()) return -1;
+    if (upload_refs()) return -1;
+    AdmmParams P;
+    std::memset(&P, 0, sizeof(P));
+    P.coef = d_coef;
+    P.bounds = d_bounds;
+    P.x0 = d_x0;
+    P.xref = d_xref;
+    P.uref = d_uref;
+    P.xout = d_xout;
+    P.uout = d_uout;
+    P.iter = d_iter;
+    P.solved = d_solved;
+    P.res = d_res;
+    P.sd = d_sd;
+    P.sy = d_sy;
+    P.sz = d_sz;
+    P.sg = d_sg;
+    P.sv = d_sv;
+    P.gstat = d_gstat;
+    P.scratch = d_scratch;
+    P.batch = batch;
+    P.max_iter = st.max_iter;
+    P.check_termination = st.check_termination;
+    P.ref_mode = ref_mode;
+    P.cold_start = warm_start ? 0 : 1;
+    P.save_state = warm_start ? 1 : 0;
+    P.abs_pri_tol = (float)st.abs_pri_tol;
+    P.abs_dua_tol = (float)st.abs_dua_tol;
+    P.rho = (float)cache.rho;
+    P.nx = nx;
+    P.nu = nu;
+    P.N = N;
+    HIP_TRY(hipMemsetAsync(d_gstat, 0, GSTAT_WORDS * sizeof(uint32_t), stream));
+    HIP_TRY(ke ? ke->launch(P, stream) : launch_generic(P, stream));
+    HIP_TRY(hipMemcpyAsync(h_gstat, d_gstat, GSTAT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    solved_once = true;
+    return 0;
+}
+
+int Solver::solve_status() {
+    if (!solved_once) {
+        set_error("solve_status before any solve");
+        return -1;
+    }
+    return h_gstat[4] == 0 ? 0 : 1;  // admm.cpp:192 / :206 folded over the batch
+}
+
+int Solver::get_traj(bool states, double *buf) {
+    HIP_TRY(hipSetDevice(device));
+    const size_t n = (size_t)batch * (states ? ex() : eu());
+    std::vector<float> h(n);
+    HIP_TRY(hipMemcpy(h.data(), states ? d_xout : d_uout, n * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) buf[i] = (double)h[i];
+    return 0;
+}
+
+int Solver::get_status(int *iter, int *solved, double *res4) {
+    HIP_TRY(hipSetDevice(device));
+    const size_t Bn = (size_t)batch;
+    if (iter) HIP_TRY(hipMemcpy(iter, d_iter, Bn * sizeof(int), hipMemcpyDeviceToHost));
+    if (solved) HIP_TRY(hipMemcpy(solved, d_solved, Bn * sizeof(int), hipMemcpyDeviceToHost));
+    if (res4) {
+        std::vector<float> h(Bn * 4);
+        HIP_TRY(hipMemcpy(h.data(), d_res, Bn * 4 * sizeof(float), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < Bn * 4; ++i) res4[i] = (double)h[i];
+    }
+    return 0;
+}
+
+static int d2h_double(const float *d, double *out, size_t n) {
+    if (!out) return 0;
+    std::vector<float> h(n);
+    HIP_TRY(hipMemcpy(h.data(), d, n * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) out[i] = (double)h[i];
+    return 0;
+}
+static int h2d_float(float *d, const double *in, size_t n) {
+    if (!in) return 0;
+    std::vector<float> h(n);
+    for (size_t i = 0; i < n; ++i) h[i] = (float)in[i];
+    HIP_TRY(hipMemcpy(d, h.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int Solver::get_workspace(double *d, double *y, double *g, double *v, double *z) {
+    HIP_TRY(hipSetDevice(device));
+    const size_t Bn = (size_t)batch, EX = (size_t)ex(), EU = (size_t)eu();
+    if (d2h_double(d_sd, d, Bn * EU) || d2h_double(d_sy, y, Bn * EU) || d2h_double(d_sz, z, Bn * EU) ||
+        d2h_double(d_sg, g, Bn * EX) || d2h_double(d_sv, v, Bn * EX))
+        return -1;
+    return 0;
+}
+
+int Solver::set_workspace(const double *d, const double *y, const double *g, const double *v,
+                          const double *z) {
+    HIP_TRY(hipSetDevice(device));
+    const size_t Bn = (size_t)batch, EX = (size_t)ex(), EU = (size_t)eu();
+    if (h2d_float(d_sd, d, Bn * EU) || h2d_float(d_sy, y, Bn * EU) || h2d_float(d_sz, z, Bn * EU) ||
+        h2d_float(d_sg, g, Bn * EX) || h2d_float(d_sv, v, Bn * EX))
+        return -1;
+    return 0;
+}
+
+}  // namespace tmpc

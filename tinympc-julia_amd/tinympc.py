@@ -1,0 +1,488 @@
+"""Python mirror of the reference's Julia module over the C-ABI (ctypes in place of ccall).
+
+Same names, argument meaning and error behaviour as reference src/TinyMPC.jl:
+  TinyMPCSolver (:34-48), setup (:55-112), set_x0 / set_x_ref / set_u_ref (:115-141),
+  solve (:143-148, returns the status without throwing), get_solution (:150-177),
+  update_settings (:181-211), set_bound_constraints (:214-227), set_cache_terms (:278-292)
+with a batch dimension added:
+  setup(..., batch=B); set_x0 takes (nx,) or (nx, B); set_x_ref (nx, N) or (nx, N, B);
+  get_solution returns states (nx, N, B) / controls (nu, N-1, B) (squeezed to 2-D for B == 1,
+  i.e. exactly the reference's shapes).
+
+Like the reference (one process-global `g_solver`, bindings.cpp:15) the module-level functions
+drive ONE global solver inside libtinympc_hip.so; `BatchSolver` wraps the handle API for callers
+that need several solvers or device-resident I/O.
+
+The library is the HIP build only.  If it is missing, or no GPU is usable, calls raise — there is
+no CPU fallback.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "lib", "libtinympc_hip.so")
+
+c_dp = ctypes.POINTER(ctypes.c_double)
+c_ip = ctypes.POINTER(ctypes.c_int)
+c_int = ctypes.c_int
+c_dbl = ctypes.c_double
+c_vp = ctypes.c_void_p
+
+
+class TinyMPCError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol include/tinympc_hip.h declares
+SIGNATURES = {
+    "setup_solver": (c_int, [c_dp, c_int, c_int, c_dp, c_int, c_int, c_dp, c_int, c_int, c_dp, c_int,
+                             c_int, c_dp, c_int, c_int, c_dbl, c_int, c_int, c_int, c_int]),
+    "set_x0": (c_int, [c_dp, c_int, c_int, c_int]),
+    "set_x_ref": (c_int, [c_dp, c_int, c_int, c_int]),
+    "set_u_ref": (c_int, [c_dp, c_int, c_int, c_int]),
+    "solve_mpc": (c_int, [c_int]),
+    "get_states": (c_int, [c_dp, c_ip, c_ip]),
+    "get_controls": (c_int, [c_dp, c_ip, c_ip]),
+    "cleanup_solver": (None, []),
+    "update_settings": (c_int, [c_dbl, c_dbl, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                c_int, c_dbl, c_dbl, c_int, c_int]),
+    "set_bound_constraints": (c_int, [c_dp, c_int, c_int, c_dp, c_int, c_int, c_dp, c_int, c_int,
+                                      c_dp, c_int, c_int, c_int]),
+    "set_cache_terms": (c_int, [c_dp, c_int, c_int, c_dp, c_int, c_int, c_dp, c_int, c_int, c_dp,
+                                c_int, c_int, c_int]),
+    "print_problem_data": (c_int, [c_int]),
+    "set_linear_constraints": (c_int, [c_dp, c_int, c_int, c_dp, c_int, c_dp, c_int, c_int, c_dp,
+                                       c_int, c_int]),
+    "set_cone_constraints": (c_int, [c_ip, c_int, c_ip, c_int, c_dp, c_int, c_ip, c_int, c_ip, c_int,
+                                     c_dp, c_int, c_int]),
+    "set_batch_size": (c_int, [c_int]),
+    "get_batch_size": (c_int, []),
+    "get_status": (c_int, [c_ip, c_ip, c_dp]),
+    "reset_workspace": (c_int, []),
+    "tinympc_create": (c_int, [ctypes.POINTER(c_vp), c_dp, c_dp, c_dp, c_dp, c_dbl, c_int, c_int,
+                               c_int, c_int, c_int, c_int]),
+    "tinympc_destroy": (None, [c_vp]),
+    "tinympc_update_settings": (c_int, [c_vp, c_dbl, c_dbl, c_int, c_int, c_int, c_int]),
+    "tinympc_set_bound_constraints": (c_int, [c_vp, c_dp, c_dp, c_dp, c_dp]),
+    "tinympc_set_cache_terms": (c_int, [c_vp, c_dp, c_dp, c_dp, c_dp]),
+    "tinympc_get_cache_terms": (c_int, [c_vp, c_dp, c_dp, c_dp, c_dp]),
+    "tinympc_set_x0": (c_int, [c_vp, c_dp, c_int]),
+    "tinympc_set_x_ref": (c_int, [c_vp, c_dp, c_int]),
+    "tinympc_set_u_ref": (c_int, [c_vp, c_dp, c_int]),
+    "tinympc_reset": (c_int, [c_vp]),
+    "tinympc_set_warm_start": (c_int, [c_vp, c_int]),
+    "tinympc_solve": (c_int, [c_vp]),
+    "tinympc_get_states": (c_int, [c_vp, c_dp]),
+    "tinympc_get_controls": (c_int, [c_vp, c_dp]),
+    "tinympc_get_status": (c_int, [c_vp, c_ip, c_ip, c_dp]),
+    "tinympc_get_workspace": (c_int, [c_vp, c_dp, c_dp, c_dp, c_dp, c_dp]),
+    "tinympc_set_workspace": (c_int, [c_vp, c_dp, c_dp, c_dp, c_dp, c_dp]),
+    "tinympc_device_buffers": (c_int, [c_vp] + [ctypes.POINTER(c_vp)] * 9),
+    "tinympc_set_ref_mode": (c_int, [c_vp, c_int]),
+    "tinympc_solve_async": (c_int, [c_vp, c_vp]),
+    "tinympc_solve_status": (c_int, [c_vp]),
+    "tinympc_kernel_name": (ctypes.c_char_p, [c_vp]),
+    "tinympc_algorithmic_bytes": (c_dbl, [c_vp]),
+    "tinympc_algorithmic_flops": (c_dbl, [c_vp, c_int]),
+    "tinympc_last_error": (ctypes.c_char_p, []),
+    "tinympc_host_precompute": (c_int, [c_dp, c_dp, c_dp, c_dp, c_dbl, c_int, c_int, c_dp, c_dp, c_dp, c_dp]),
+}
+
+
+def load_library(path=None):
+    """dlopen libtinympc_hip.so and bind every declared symbol (the `_ensure_loaded` of TinyMPC.jl:14)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or _LIB_PATH
+    if not os.path.isfile(path):
+        raise TinyMPCError(f"TinyMPC library not found: {path} (build it with __graft_entry__.build())")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _err():
+    try:
+        return (load_library().tinympc_last_error() or b"").decode()
+    except Exception:
+        return ""
+
+
+def _mat(a, name=None):
+    m = np.asfortranarray(np.asarray(a, dtype=np.float64))
+    if m.ndim == 1:
+        m = np.asfortranarray(m.reshape(-1, 1))
+    return m
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_dp)
+
+
+class TinyMPCSolver:
+    """Mirror of the Julia struct (TinyMPC.jl:34-48): dims, rho, is_setup and copies of A, B, Q, R."""
+
+    def __init__(self):
+        self.nx = 0
+        self.nu = 0
+        self.N = 0
+        self.batch = 1
+        self.rho = 0.0
+        self.is_setup = False
+        self.A = np.zeros((0, 0))
+        self.B = np.zeros((0, 0))
+        self.Q = np.zeros((0, 0))
+        self.R = np.zeros((0, 0))
+
+
+def setup(solver, A, B, f, Q, R, rho, nx, nu, N, *, batch=1, verbose=False, abs_pri_tol=1e-3,
+          abs_dua_tol=1e-3, max_iter=100, check_termination=True, adaptive_rho=False,
+          adaptive_rho_min=0.1, adaptive_rho_max=10.0, adaptive_rho_clipping=True):
+    """TinyMPC.jl:55-112.  Raises on failure like the Julia `error(...)`; returns the status."""
+    lib = load_library()
+    A, B, Q, R = _mat(A), _mat(B), _mat(Q), _mat(R)
+    f = _mat(np.zeros(nx) if f is None else f)
+    solver.nx, solver.nu, solver.N, solver.rho, solver.batch = nx, nu, N, float(rho), int(batch)
+    solver.A, solver.B, solver.Q, solver.R = A.copy(), B.copy(), Q.copy(), R.copy()
+    status = lib.setup_solver(_dp(A), A.shape[0], A.shape[1], _dp(B), B.shape[0], B.shape[1],
+                              _dp(f), f.shape[0], f.shape[1], _dp(Q), Q.shape[0], Q.shape[1],
+                              _dp(R), R.shape[0], R.shape[1], float(rho), nx, nu, N, 1 if verbose else 0)
+    if status != 0:
+        solver.is_setup = False
+        raise TinyMPCError(f"Setup failed with status: {status} ({_err()})")
+    if batch != 1 and lib.set_batch_size(int(batch)) != 0:
+        raise TinyMPCError(f"Failed to set batch size ({_err()})")
+    solver.is_setup = True
+    # TinyMPC.jl:89-104 — settings pushed with every en_* false
+    update_settings(solver, abs_pri_tol=abs_pri_tol, abs_dua_tol=abs_dua_tol, max_iter=max_iter,
+                    check_termination=check_termination, en_state_bound=False, en_input_bound=False,
+                    en_state_soc=False, en_input_soc=False, en_state_linear=False,
+                    en_input_linear=False, adaptive_rho=adaptive_rho,
+                    adaptive_rho_min=adaptive_rho_min, adaptive_rho_max=adaptive_rho_max,
+                    adaptive_rho_enable_clipping=adaptive_rho_clipping, verbose=verbose)
+    return status
+
+
+def _need_setup(solver):
+    if not solver.is_setup:
+        raise TinyMPCError("Solver not setup")
+
+
+def set_batch_size(solver, batch):
+    _need_setup(solver)
+    if load_library().set_batch_size(int(batch)) != 0:
+        raise TinyMPCError(f"Failed to set batch size ({_err()})")
+    solver.batch = int(batch)
+    return 0
+
+
+def set_x0(solver, x0, *, verbose=False):
+    """TinyMPC.jl:115-123.  x0: (nx,) broadcast to the batch, or (nx, batch)."""
+    _need_setup(solver)
+    m = _mat(x0)
+    status = load_library().set_x0(_dp(m), m.shape[0], m.shape[1], 1 if verbose else 0)
+    if status != 0:
+        raise TinyMPCError(f"Failed to set initial state ({_err()})")
+    return status
+
+
+def _ref3(a):
+    a = np.asarray(a, dtype=np.float64)
+    if a.ndim == 3:  # (rows, knots, batch) -> rows x (knots*batch), column-major
+        a = np.asfortranarray(a).reshape(a.shape[0], -1, order="F")
+    return _mat(a)
+
+
+def set_x_ref(solver, x_ref, *, verbose=False):
+    """TinyMPC.jl:125-132.  (nx, N) shared or (nx, N, batch)."""
+    _need_setup(solver)
+    m = _ref3(x_ref)
+    status = load_library().set_x_ref(_dp(m), m.shape[0], m.shape[1], 1 if verbose else 0)
+    if status != 0:
+        raise TinyMPCError(f"Failed to set state reference ({_err()})")
+    return status
+
+
+def set_u_ref(solver, u_ref, *, verbose=False):
+    """TinyMPC.jl:134-141.  (nu, N-1) shared or (nu, N-1, batch)."""
+    _need_setup(solver)
+    m = _ref3(u_ref)
+    status = load_library().set_u_ref(_dp(m), m.shape[0], m.shape[1], 1 if verbose else 0)
+    if status != 0:
+        raise TinyMPCError(f"Failed to set input reference ({_err()})")
+    return status
+
+
+def solve(solver, *, verbose=False):
+    """TinyMPC.jl:143-148 — returns the status (0 converged / 1 max_iter / -1 error), never raises on it."""
+    _need_setup(solver)
+    return int(load_library().solve_mpc(1 if verbose else 0))
+
+
+def get_solution(solver):
+    """TinyMPC.jl:150-177.  Returns dict(states=(nx,N[,B]), controls=(nu,N-1[,B]))."""
+    _need_setup(solver)
+    lib = load_library()
+    nx, nu, N, B = solver.nx, solver.nu, solver.N, solver.batch
+    sb = np.zeros(nx * N * B)
+    cb = np.zeros(nu * (N - 1) * B)
+    sr, sc, cr, cc = c_int(), c_int(), c_int(), c_int()
+    s1 = lib.get_states(_dp(sb), ctypes.byref(sr), ctypes.byref(sc))
+    s2 = lib.get_controls(_dp(cb), ctypes.byref(cr), ctypes.byref(cc))
+    if s1 != 0 or s2 != 0:
+        raise TinyMPCError(f"Failed to get solution ({_err()})")
+    states = sb[: sr.value * sc.value].reshape((sr.value, sc.value), order="F")
+    controls = cb[: cr.value * cc.value].reshape((cr.value, cc.value), order="F")
+    if B > 1:
+        states = states.reshape((nx, N, B), order="F")
+        controls = controls.reshape((nu, N - 1, B), order="F")
+    return dict(states=states, controls=controls)
+
+
+def get_status(solver):
+    """Batched solution->iter / solved / residuals (extension; types.hpp:32-37,128-131)."""
+    _need_setup(solver)
+    B = solver.batch
+    it = np.zeros(B, dtype=np.int32)
+    so = np.zeros(B, dtype=np.int32)
+    res = np.zeros((B, 4))
+    if load_library().get_status(it.ctypes.data_as(c_ip), so.ctypes.data_as(c_ip), _dp(res)) != 0:
+        raise TinyMPCError(f"Failed to get status ({_err()})")
+    return dict(iter=it, solved=so, residuals=res)
+
+
+def reset_workspace(solver):
+    _need_setup(solver)
+    if load_library().reset_workspace() != 0:
+        raise TinyMPCError(f"Failed to reset workspace ({_err()})")
+    return 0
+
+
+def update_settings(solver, *, abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100,
+                    check_termination=True, en_state_bound=False, en_input_bound=False,
+                    en_state_soc=False, en_input_soc=False, en_state_linear=False,
+                    en_input_linear=False, adaptive_rho=False, adaptive_rho_min=0.1,
+                    adaptive_rho_max=10.0, adaptive_rho_enable_clipping=True, verbose=False):
+    """TinyMPC.jl:181-211 — every field is sent with its keyword default, like the reference
+    (so calling it later resets en_*_bound to false and the tolerances to 1e-3).
+    `check_termination` may also be an int interval (extension); True/False map to 1/0."""
+    ct = int(check_termination) if not isinstance(check_termination, bool) else (1 if check_termination else 0)
+    status = load_library().update_settings(
+        float(abs_pri_tol), float(abs_dua_tol), int(max_iter), ct, int(bool(en_state_bound)),
+        int(bool(en_input_bound)), int(bool(en_state_soc)), int(bool(en_input_soc)),
+        int(bool(en_state_linear)), int(bool(en_input_linear)), int(bool(adaptive_rho)),
+        float(adaptive_rho_min), float(adaptive_rho_max), int(bool(adaptive_rho_enable_clipping)),
+        1 if verbose else 0)
+    if status != 0:
+        raise TinyMPCError(f"Failed to update settings ({_err()})")
+    return status
+
+
+def set_bound_constraints(solver, x_min, x_max, u_min, u_max, *, verbose=False):
+    """TinyMPC.jl:214-227; both bound flags are auto-enabled in the library (bindings.cpp:400-404)."""
+    ms = [_mat(m) for m in (x_min, x_max, u_min, u_max)]
+    args = []
+    for m in ms:
+        args += [_dp(m), m.shape[0], m.shape[1]]
+    status = load_library().set_bound_constraints(*args, 1 if verbose else 0)
+    if status != 0:
+        raise TinyMPCError(f"Failed to set bound constraints ({_err()})")
+    return status
+
+
+def set_linear_constraints(solver, Alin_x, blin_x, Alin_u, blin_u, *, verbose=False):
+    """TinyMPC.jl:229-243.  Only empty blocks are accepted (parity unpinned)."""
+    Ax, Au = _mat(np.asarray(Alin_x, dtype=np.float64).reshape(len(blin_x), -1)), _mat(
+        np.asarray(Alin_u, dtype=np.float64).reshape(len(blin_u), -1))
+    bx, bu = np.asarray(blin_x, dtype=np.float64), np.asarray(blin_u, dtype=np.float64)
+    status = load_library().set_linear_constraints(_dp(Ax), Ax.shape[0], Ax.shape[1], _dp(bx), len(bx),
+                                                   _dp(Au), Au.shape[0], Au.shape[1], _dp(bu), len(bu),
+                                                   1 if verbose else 0)
+    if status != 0:
+        raise TinyMPCError(f"Failed to set linear constraints ({_err()})")
+    return status
+
+
+def set_cone_constraints(solver, Acu, qcu, cu, Acx, qcx, cx, *, verbose=False):
+    """TinyMPC.jl:245-259.  Only empty cone lists are accepted (parity unpinned)."""
+    ia = [np.asarray(a, dtype=np.int32) for a in (Acu, qcu, Acx, qcx)]
+    da = [np.asarray(a, dtype=np.float64) for a in (cu, cx)]
+    status = load_library().set_cone_constraints(
+        ia[0].ctypes.data_as(c_ip), len(ia[0]), ia[1].ctypes.data_as(c_ip), len(ia[1]), _dp(da[0]),
+        len(da[0]), ia[2].ctypes.data_as(c_ip), len(ia[2]), ia[3].ctypes.data_as(c_ip), len(ia[3]),
+        _dp(da[1]), len(da[1]), 1 if verbose else 0)
+    if status != 0:
+        raise TinyMPCError(f"Failed to set cone constraints ({_err()})")
+    return status
+
+
+def set_cache_terms(solver, Kinf, Pinf, Quu_inv, AmBKt, *, verbose=False):
+    """TinyMPC.jl:278-292"""
+    _need_setup(solver)
+    ms = [_mat(m) for m in (Kinf, Pinf, Quu_inv, AmBKt)]
+    args = []
+    for m in ms:
+        args += [_dp(m), m.shape[0], m.shape[1]]
+    status = load_library().set_cache_terms(*args, 1 if verbose else 0)
+    if status != 0:
+        raise TinyMPCError(f"Failed to set cache terms ({_err()})")
+    return status
+
+
+def print_problem_data(solver, *, verbose=False):
+    _need_setup(solver)
+    return load_library().print_problem_data(1 if verbose else 0)
+
+
+def cleanup():
+    """TinyMPC.jl:428-429"""
+    try:
+        load_library().cleanup_solver()
+    except Exception:
+        pass
+
+
+def host_precompute(A, B, Q, R, rho):
+    """fp64 Riccati cache on the host (no GPU needed): dict(Kinf, Pinf, Quu_inv, AmBKt)."""
+    A, B, Q, R = _mat(A), _mat(B), _mat(Q), _mat(R)
+    nx, nu = A.shape[0], B.shape[1]
+    K, P = np.zeros((nu, nx), order="F"), np.zeros((nx, nx), order="F")
+    Qi, Am = np.zeros((nu, nu), order="F"), np.zeros((nx, nx), order="F")
+    if load_library().tinympc_host_precompute(_dp(A), _dp(B), _dp(Q), _dp(R), float(rho), nx, nu, _dp(K),
+                                              _dp(P), _dp(Qi), _dp(Am)) != 0:
+        raise TinyMPCError(f"host_precompute failed ({_err()})")
+    return dict(Kinf=K, Pinf=P, Quu_inv=Qi, AmBKt=Am)
+
+
+class BatchSolver:
+    """Handle-API wrapper (tinympc_* in include/tinympc_hip.h): several solvers per process,
+    device-resident I/O, stream-ordered solves.  Used by bench.py and the sharded driver."""
+
+    def __init__(self, A, B, Q, R, rho, N, batch, device=-1, verbose=False):
+        self.lib = load_library()
+        A, B, Q, R = _mat(A), _mat(B), _mat(Q), _mat(R)
+        self.nx, self.nu, self.N, self.batch = A.shape[0], B.shape[1], int(N), int(batch)
+        h = c_vp()
+        st = self.lib.tinympc_create(ctypes.byref(h), _dp(A), _dp(B), _dp(Q), _dp(R), float(rho), self.nx,
+                                     self.nu, self.N, self.batch, int(device), 1 if verbose else 0)
+        if st != 0:
+            raise TinyMPCError(f"tinympc_create failed ({_err()})")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tinympc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, st, what):
+        if st != 0:
+            raise TinyMPCError(f"{what} failed ({_err()})")
+
+    def update_settings(self, abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1,
+                        en_state_bound=0, en_input_bound=0):
+        self._chk(self.lib.tinympc_update_settings(self.h, float(abs_pri_tol), float(abs_dua_tol),
+                                                   int(max_iter), int(check_termination),
+                                                   int(en_state_bound), int(en_input_bound)),
+                  "update_settings")
+
+    def set_bound_constraints(self, x_min, x_max, u_min, u_max):
+        ms = [_mat(m) for m in (x_min, x_max, u_min, u_max)]
+        self._chk(self.lib.tinympc_set_bound_constraints(self.h, *[_dp(m) for m in ms]), "set_bound_constraints")
+
+    def set_cache_terms(self, Kinf, Pinf, Quu_inv, AmBKt):
+        ms = [_mat(m) for m in (Kinf, Pinf, Quu_inv, AmBKt)]
+        self._chk(self.lib.tinympc_set_cache_terms(self.h, *[_dp(m) for m in ms]), "set_cache_terms")
+
+    def get_cache_terms(self):
+        nx, nu = self.nx, self.nu
+        K, P = np.zeros((nu, nx), order="F"), np.zeros((nx, nx), order="F")
+        Qi, Am = np.zeros((nu, nu), order="F"), np.zeros((nx, nx), order="F")
+        self._chk(self.lib.tinympc_get_cache_terms(self.h, _dp(K), _dp(P), _dp(Qi), _dp(Am)), "get_cache_terms")
+        return dict(Kinf=K, Pinf=P, Quu_inv=Qi, AmBKt=Am)
+
+    def set_x0(self, x0):
+        m = _mat(x0)
+        self._chk(self.lib.tinympc_set_x0(self.h, _dp(m), m.shape[1]), "set_x0")
+
+    def set_x_ref(self, x_ref):
+        m = _ref3(x_ref)
+        self._chk(self.lib.tinympc_set_x_ref(self.h, _dp(m), m.shape[1]), "set_x_ref")
+
+    def set_u_ref(self, u_ref):
+        m = _ref3(u_ref)
+        self._chk(self.lib.tinympc_set_u_ref(self.h, _dp(m), m.shape[1]), "set_u_ref")
+
+    def reset(self):
+        self._chk(self.lib.tinympc_reset(self.h), "reset")
+
+    def set_warm_start(self, on):
+        self._chk(self.lib.tinympc_set_warm_start(self.h, 1 if on else 0), "set_warm_start")
+
+    def solve(self):
+        st = int(self.lib.tinympc_solve(self.h))
+        if st < 0:
+            raise TinyMPCError(f"solve failed ({_err()})")
+        return st
+
+    def solve_async(self, stream=None):
+        self._chk(self.lib.tinympc_solve_async(self.h, c_vp(stream or 0)), "solve_async")
+
+    def solve_status(self):
+        return int(self.lib.tinympc_solve_status(self.h))
+
+    def get_solution(self):
+        nx, nu, N, B = self.nx, self.nu, self.N, self.batch
+        sb, cb = np.zeros(nx * N * B), np.zeros(nu * (N - 1) * B)
+        self._chk(self.lib.tinympc_get_states(self.h, _dp(sb)), "get_states")
+        self._chk(self.lib.tinympc_get_controls(self.h, _dp(cb)), "get_controls")
+        return dict(states=sb.reshape((nx, N, B), order="F"), controls=cb.reshape((nu, N - 1, B), order="F"))
+
+    def get_status(self):
+        B = self.batch
+        it, so, res = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32), np.zeros((B, 4))
+        self._chk(self.lib.tinympc_get_status(self.h, it.ctypes.data_as(c_ip), so.ctypes.data_as(c_ip), _dp(res)),
+                  "get_status")
+        return dict(iter=it, solved=so, residuals=res)
+
+    def get_workspace(self):
+        nx, nu, N, B = self.nx, self.nu, self.N, self.batch
+        d, y, z = (np.zeros(nu * (N - 1) * B) for _ in range(3))
+        g, v = (np.zeros(nx * N * B) for _ in range(2))
+        self._chk(self.lib.tinympc_get_workspace(self.h, _dp(d), _dp(y), _dp(g), _dp(v), _dp(z)), "get_workspace")
+        ru = lambda a: a.reshape((nu, N - 1, B), order="F")
+        rx = lambda a: a.reshape((nx, N, B), order="F")
+        return dict(d=ru(d), y=ru(y), z=ru(z), g=rx(g), v=rx(v))
+
+    def device_buffers(self):
+        ptrs = [c_vp() for _ in range(9)]
+        self._chk(self.lib.tinympc_device_buffers(self.h, *[ctypes.byref(p) for p in ptrs]), "device_buffers")
+        names = ("x0", "x_ref", "u_ref", "states", "controls", "iter", "solved", "residuals", "gstat")
+        return {n: p.value for n, p in zip(names, ptrs)}
+
+    def set_ref_mode(self, mode):
+        self._chk(self.lib.tinympc_set_ref_mode(self.h, int(mode)), "set_ref_mode")
+
+    @property
+    def kernel_name(self):
+        return self.lib.tinympc_kernel_name(self.h).decode()
+
+    def algorithmic_bytes(self):
+        return float(self.lib.tinympc_algorithmic_bytes(self.h))
+
+    def algorithmic_flops(self, iters):
+        return float(self.lib.tinympc_algorithmic_flops(self.h, int(iters)))
