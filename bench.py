@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Benchmark of the batched TinyMPC ADMM hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one batched solve of the workload on every rank: BASELINE.json configs[1] —
+cartpole nx=4 nu=1 N=20, u in [-0.5, 0.5], batch 65 536 per GPU, cold start, exactly 100 ADMM
+iterations per instance (tolerances 0).  Inputs are resident in HBM before the timed region.
+One process per GPU; the batch shards with no data-path collective; each step ends with the
+path's only exchange: an all-reduce(MAX) over RCCL of the 5-word status block (4 residual
+maxima + unsolved count) that decides the global solve status.  scaling = weak (per-GPU batch
+fixed).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cartpole", choices=["cartpole", "quadrotor", "rocket"])
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--precision", type=int, default=0, help="0: fp64 recurrences (default), 1: all fp32")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def make_workload(t, name, batch, rank):
+    P = t.problems
+    if name == "cartpole":
+        prob = P.cartpole(20, u_bound=0.5)
+        x0 = P.cartpole_x0(batch, seed=0 + 1000 * rank)
+        refs = None
+        label = "cartpole nx=4 nu=1 N=20 box-only, batch=65536/GPU, fixed 100 ADMM iters, cold start"
+    elif name == "quadrotor":
+        prob = P.quadrotor(30, u_bound=0.5)
+        x0 = P.quadrotor_x0(batch, seed=1 + 1000 * rank)
+        refs = None
+        label = "quadrotor nx=12 nu=4 N=30 box, batch=65536/GPU, fixed 100 ADMM iters, cold start"
+    else:
+        prob = P.rocket(50)
+        x0 = P.rocket_x0(batch, seed=2 + 1000 * rank)
+        refs = P.rocket_refs(50)
+        label = "rocket nx=6 nu=3 N=50 box-only sub-problem (no fdyn/SOC), batch=32768/GPU, fixed 100 iters"
+    return prob, x0, refs, label
+
+
+def cpu_baseline(prob, x0, refs, iters, seconds):
+    """The reference's own compiled snapshot (oracle/_ref) when its prebuilt .so is present, else our
+    C restatement, threaded over the host cores, on a bounded sample of the same workload."""
+    from oracle import cpu_oracle
+    kind = "ref" if cpu_oracle.have_ref() else "orc64"
+    if kind == "orc64" and not os.path.isfile(cpu_oracle.PORT_LIB):
+        cpu_oracle.build(port=True, ref=False)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
+    xr, ur = refs if refs is not None else (None, None)
+    n = min(x0.shape[1], 2048 * cores)
+    done, spent = 0, 0.0
+    while spent < seconds and done < 64 * x0.shape[1]:
+        r = cpu_oracle.solve_batch(kind, prob, x0[:, :n], xref=xr, uref=ur, abs_pri_tol=0.0, abs_dua_tol=0.0,
+                                   max_iter=iters, nthreads=cores, want_outputs=False)
+        done += n
+        spent += r["seconds"]
+    return {"value": done / spent, "unit": "solves/s", "cores": cores,
+            "kind": "reference" if kind == "ref" else "port",
+            "sample": f"{done} cold-start solves of the same workload ({iters} fixed iters) in {spent:.1f} s on "
+                      f"{cores} threads" + (" (compiled reference snapshot, oracle/_ref)" if kind == "ref"
+                                            else " (fp64 C restatement, oracle/)")}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # RCCL on ROCm
+
+    import tinympc_julia_amd as t
+    from tinympc_julia_amd import sharding
+
+    batch = args.batch or (32768 if args.config == "rocket" else 65536)
+    prob, x0, refs, label = make_workload(t, args.config, batch, rank)
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=batch, device=local_rank)
+    bs.update_settings(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=args.iters, check_termination=1)
+    bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    bs.set_precision(args.precision)
+    bs.set_warm_start(False)          # cold start, no state I/O: compulsory traffic only
+    bs.set_x0(x0)                     # H2D once; inputs stay resident in HBM
+    if refs is not None:
+        bs.set_x_ref(refs[0])
+        bs.set_u_ref(refs[1])
+    bs.set_profiling(True)
+    stream = torch.cuda.current_stream(dev)
+    gstat = sharding.device_tensor(bs.device_buffers()["gstat"], (8,), torch.int32, dev)
+
+    def step():
+        bs.solve_async(stream.cuda_stream)
+        if world > 1:
+            # the path's only exchange: global max residuals / unsolved count (16 + 4 bytes)
+            sharding.allreduce_status(gstat)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for i in range(args.steps):
+        ev[i][0].record(stream)
+        step()
+        ev[i][1].record(stream)
+    fence()
+    elapsed = time.perf_counter() - t0
+    # per-launch kernel duration: HIP events recorded on the launch stream around the kernel
+    step_ms = [a.elapsed_time(b) for a, b in ev]
+    kernel_ms.append(bs.kernel_elapsed_ms())  # last launch, events immediately around the kernel
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    status = bs.solve_status()
+    st = bs.get_status()
+    assert int(st["iter"].min()) == args.iters and int(st["iter"].max()) == args.iters, "work skipped"
+
+    if rank == 0:
+        total = world * batch * args.steps
+        value = total / elapsed
+        avg_step_ms = float(np.mean(step_ms))
+        k_ms = kernel_ms[-1] if kernel_ms[-1] > 0 else avg_step_ms
+        alg_bytes = bs.algorithmic_bytes()          # per launch (one rank's batch)
+        alg_flops = bs.algorithmic_flops(args.iters)
+        ach_gbs = alg_bytes / (k_ms * 1e-3) / 1e9
+        ach_tf = alg_flops / (k_ms * 1e-3) / 1e12
+        out = {
+            "metric": "qp_solves_per_sec", "value": value, "unit": "solves/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == 1 else "f32 (f64 recurrences)", "data": "synthetic",
+            "config": {"workload": label, "family": args.config, "batch_per_gpu": batch,
+                       "admm_iters_per_solve": args.iters, "kernel": bs.kernel_name,
+                       "sharding": f"batch-sharded x{world}, status all-reduce only"},
+            "admm_iters_per_sec": value * args.iters,
+            "solve_status": status,
+            "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "compute-bound path (SURVEY 8d): ~430 FLOP/B; see valu"},
+            "valu": {"achieved_tflops": ach_tf, "peak_tflops": FP32_PEAK_TFLOPS,
+                     "frac": ach_tf / FP32_PEAK_TFLOPS, "algorithmic_flops_per_launch": alg_flops},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(prob, x0, refs, args.iters, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    bs.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -148,6 +148,14 @@ int tinympc_set_ref_mode(tinympc_solver *s, int ref_mode);
 int tinympc_solve_async(tinympc_solver *s, void *hip_stream);
 /* After the stream has been synchronised: 0 all converged / 1 otherwise (reads gstat). */
 int tinympc_solve_status(tinympc_solver *s);
+/* Kernel timing: when enabled, every solve records HIP events immediately around the ADMM kernel
+ * launch on the launch stream; tinympc_kernel_elapsed_ms returns the last kernel's duration
+ * (call after the stream has been synchronised; < 0 if unavailable). */
+int tinympc_set_profiling(tinympc_solver *s, int enable);
+double tinympc_kernel_elapsed_ms(tinympc_solver *s);
+/* Arithmetic of the two serial recurrences (rollout, Riccati gradient): 0 = fp64 accumulation
+ * with fp64 coefficients (default; ADMM state and elementwise steps stay fp32), 1 = all fp32. */
+int tinympc_set_precision(tinympc_solver *s, int precision);
 /* Name of the kernel path that the last solve used: "quad<nx,nu,N>" or "generic". */
 const char *tinympc_kernel_name(tinympc_solver *s);
 /* Algorithmic HBM bytes and FLOPs of one solve of the whole batch (SURVEY.md 8d formulas);

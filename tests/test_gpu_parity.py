@@ -241,7 +241,7 @@ def test_refs_shared_and_per_instance(hip_lib, oracle_built):
     bs.close()
 
 
-@pytest.mark.parametrize("shape", ["cartpole_N15", "random_3x2_N7", "rocket_N50"])
+@pytest.mark.parametrize("shape", ["cartpole_N15", "random_3x2_N7", "rocket_N40"])
 def test_generic_kernel_vs_oracle(hip_lib, oracle_built, shape):
     """Shapes without a specialised instantiation run on the generic HIP kernel (never on the CPU)."""
     rng = np.random.default_rng(11)
@@ -250,10 +250,10 @@ def test_generic_kernel_vs_oracle(hip_lib, oracle_built, shape):
     if shape == "cartpole_N15":
         prob = t.problems.cartpole(15, u_bound=0.5)
         x0 = t.problems.cartpole_x0(B, seed=4)
-    elif shape == "rocket_N50":
-        prob = t.problems.rocket(50)
+    elif shape == "rocket_N40":
+        prob = t.problems.rocket(40)
         x0 = t.problems.rocket_x0(B, seed=2)
-        xref, uref = t.problems.rocket_refs(50)
+        xref, uref = t.problems.rocket_refs(40)
     else:
         A = np.eye(3) + 0.1 * rng.standard_normal((3, 3))
         Bm = rng.standard_normal((3, 2))
@@ -341,14 +341,15 @@ def test_edge_cases(hip_lib, oracle_built):
     assert np.all(st["iter"] == 5) and np.all(st["solved"] == 0) and np.all(st["residuals"] == 0)
     # check_termination = 3: residuals are evaluated on iterations 3, 6, ... only
     ref = oracle_built.solve_batch("orc64", prob, t.problems.cartpole_x0(2, seed=1), abs_pri_tol=1e-3,
-                                   abs_dua_tol=1e-3, max_iter=50, check_termination=3)
-    bs.update_settings(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=50, check_termination=3,
+                                   abs_dua_tol=1e-3, max_iter=100, check_termination=3)
+    bs.update_settings(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=3,
                        en_state_bound=1, en_input_bound=1)
     bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
     bs.reset()
     bs.solve()
     st = bs.get_status()
-    assert np.array_equal(st["iter"], ref["iter"]) and np.all(st["iter"] % 3 == 0)
+    assert np.array_equal(st["iter"], ref["iter"]) and np.array_equal(st["solved"], ref["solved"])
+    assert np.all((st["iter"] % 3 == 0) | (st["solved"] == 0))
     # max_iter = 0: no iteration runs, status 1 (admm.cpp:125,206)
     bs.update_settings(max_iter=0)
     assert bs.solve() == 1

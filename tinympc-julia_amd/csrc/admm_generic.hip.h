@@ -12,9 +12,10 @@
 
 namespace tmpc {
 
-// coefficient pack (column-major fp32): A, B, Kinf, Pinf, Quu_inv, AmBKt, Qd, Rd
+// coefficient pack (column-major, elements of RT): A, B, Kinf, Pinf, Quu_inv, AmBKt;
+// the fp32 diagonals Qd, Rd ride at the end of the bounds pack
 struct GenericPack {
-    int oA, oB, oK, oP, oQi, oAt, oQd, oRd, len;
+    int oA, oB, oK, oP, oQi, oAt, len;
     __host__ __device__ GenericPack(int nx, int nu) {
         oA = 0;
         oB = oA + nx * nx;
@@ -22,15 +23,17 @@ struct GenericPack {
         oP = oK + nu * nx;
         oQi = oP + nx * nx;
         oAt = oQi + nu * nu;
-        oQd = oAt + nx * nx;
-        oRd = oQd + nx;
-        len = oRd + nu;
+        len = oAt + nx * nx;
     }
 };
-// bounds pack: xmin[N*nx] xmax[N*nx] umin[(N-1)*nu] umax[(N-1)*nu]
+// bounds pack: xmin[N*nx] xmax[N*nx] umin[(N-1)*nu] umax[(N-1)*nu] Qd[nx] Rd[nu]
 // scratch arrays, in units of E_x / E_u blocks of [element][batch]
-//   x q p v vnew g  (6 x E_x)   then   u r d z znew y  (6 x E_u)
+//   x q v vnew g  (5 x E_x)   then   u r d z znew y  (6 x E_u); p is a running vector
 
+__device__ __forceinline__ float gfma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ double gfma(double a, double b, double c) { return fma(a, b, c); }
+
+template <class RT>
 __global__ __launch_bounds__(256) void admm_generic_kernel(const AdmmParams P) {
     const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= P.batch) return;
@@ -38,13 +41,13 @@ __global__ __launch_bounds__(256) void admm_generic_kernel(const AdmmParams P) {
     const long B = P.batch;
     const int EX = nx * N, EU = nu * (N - 1);
     const GenericPack pk(nx, nu);
-    const float *cA = P.coef + pk.oA, *cB = P.coef + pk.oB, *cK = P.coef + pk.oK,
-                *cP = P.coef + pk.oP, *cQi = P.coef + pk.oQi, *cAt = P.coef + pk.oAt,
-                *cQd = P.coef + pk.oQd, *cRd = P.coef + pk.oRd;
+    const RT *coef = reinterpret_cast<const RT *>(P.coef);
+    const RT *cA = coef + pk.oA, *cB = coef + pk.oB, *cK = coef + pk.oK, *cP = coef + pk.oP,
+             *cQi = coef + pk.oQi, *cAt = coef + pk.oAt;
     const float *xmin = P.bounds, *xmax = P.bounds + EX, *umin = P.bounds + 2 * EX,
-                *umax = P.bounds + 2 * EX + EU;
-    float *sx = P.scratch + b, *sq = sx + (long)EX * B, *sp = sq + (long)EX * B,
-          *sv = sp + (long)EX * B, *svn = sv + (long)EX * B, *sg = svn + (long)EX * B;
+                *umax = P.bounds + 2 * EX + EU, *cQd = P.bounds + 2 * EX + 2 * EU,
+                *cRd = P.bounds + 2 * EX + 2 * EU + nx;
+    float *sx = P.scratch + b, *sq = sx + (long)EX * B, *sv = sq + (long)EX * B, *svn = sv + (long)EX * B, *sg = svn + (long)EX * B;
     float *su = sg + (long)EX * B, *sr = su + (long)EU * B, *sd = sr + (long)EU * B,
           *sz = sd + (long)EU * B, *szn = sz + (long)EU * B, *sy = szn + (long)EU * B;
 #define AT(arr, e) arr[(long)(e)*B]
@@ -56,7 +59,6 @@ __global__ __launch_bounds__(256) void admm_generic_kernel(const AdmmParams P) {
         AT(sv, e) = warm ? P.sv[b * EX + e] : 0.f;
         AT(svn, e) = 0.f;
         AT(sq, e) = 0.f;
-        AT(sp, e) = 0.f;
     }
     for (int e = 0; e < EU; ++e) {
         AT(su, e) = 0.f;
@@ -84,23 +86,25 @@ __global__ __launch_bounds__(256) void admm_generic_kernel(const AdmmParams P) {
         return 0.f;
     };
     int it = 0, conv = 0;
-    float t[GEN_MAX_NU], xv[GEN_MAX_NX], uv[GEN_MAX_NU];
+    RT t[GEN_MAX_NU], xv[GEN_MAX_NX], xn[GEN_MAX_NX], uv[GEN_MAX_NU], rv[GEN_MAX_NU];
     for (int i = 0; i < P.max_iter; ++i) {
         // forward_pass — admm.cpp:25-35
+        for (int j = 0; j < nx; ++j) xv[j] = (RT)AT(sx, j);
         for (int k = 0; k < N - 1; ++k) {
-            for (int j = 0; j < nx; ++j) xv[j] = AT(sx, k * nx + j);
             for (int a = 0; a < nu; ++a) {
-                float acc = 0.f;
-                for (int j = 0; j < nx; ++j) acc = fmaf(cK[a + j * nu], xv[j], acc);
-                uv[a] = -acc - AT(sd, k * nu + a);
-                AT(su, k * nu + a) = uv[a];
+                RT acc = 0;
+                for (int j = 0; j < nx; ++j) acc = gfma(cK[a + j * nu], xv[j], acc);
+                uv[a] = -acc - (RT)AT(sd, k * nu + a);
+                AT(su, k * nu + a) = (float)uv[a];
             }
             for (int r = 0; r < nx; ++r) {
-                float ax = 0.f, bu = 0.f;
-                for (int j = 0; j < nx; ++j) ax = fmaf(cA[r + j * nx], xv[j], ax);
-                for (int a = 0; a < nu; ++a) bu = fmaf(cB[r + a * nx], uv[a], bu);
-                AT(sx, (k + 1) * nx + r) = ax + bu;
+                RT acc = 0;
+                for (int a = 0; a < nu; ++a) acc = gfma(cB[r + a * nx], uv[a], acc);
+                for (int j = 0; j < nx; ++j) acc = gfma(cA[r + j * nx], xv[j], acc);
+                xn[r] = acc;
+                AT(sx, (k + 1) * nx + r) = (float)acc;
             }
+            for (int r = 0; r < nx; ++r) xv[r] = xn[r];
         }
         // update_slack, update_dual, update_linear_cost, residuals — admm.cpp:43-96
         float pri_x = 0.f, dua_x = 0.f, pri_u = 0.f, dua_u = 0.f;
@@ -130,9 +134,9 @@ __global__ __launch_bounds__(256) void admm_generic_kernel(const AdmmParams P) {
         }
         for (int r = 0; r < nx; ++r) {
             const int e = (N - 1) * nx + r;
-            float acc = 0.f;
-            for (int j = 0; j < nx; ++j) acc = fmaf(xref(N - 1, j), cP[j + r * nx], acc);
-            AT(sp, e) = -acc - rho * (AT(svn, e) - AT(sg, e));
+            RT acc = 0;
+            for (int j = 0; j < nx; ++j) acc = gfma(cP[j + r * nx], (RT)xref(N - 1, j), acc);
+            xn[r] = -acc - (RT)(rho * (AT(svn, e) - AT(sg, e)));  // p_{N-1}
         }
         it += 1;
         // termination_condition — admm.cpp:89-107
@@ -150,24 +154,26 @@ __global__ __launch_bounds__(256) void admm_generic_kernel(const AdmmParams P) {
         for (int e = 0; e < EX; ++e) AT(sv, e) = AT(svn, e);
         for (int e = 0; e < EU; ++e) AT(sz, e) = AT(szn, e);
         // backward_pass_grad — admm.cpp:13-20
+        for (int j = 0; j < nx; ++j) xv[j] = xn[j];  // running p, kept in RT
         for (int k = N - 2; k >= 0; --k) {
-            for (int j = 0; j < nx; ++j) xv[j] = AT(sp, (k + 1) * nx + j);
             for (int a = 0; a < nu; ++a) {
-                float acc = 0.f;
-                for (int j = 0; j < nx; ++j) acc = fmaf(cB[j + a * nx], xv[j], acc);
-                t[a] = acc + AT(sr, k * nu + a);
+                rv[a] = (RT)AT(sr, k * nu + a);
+                RT acc = rv[a];
+                for (int j = 0; j < nx; ++j) acc = gfma(cB[j + a * nx], xv[j], acc);
+                t[a] = acc;
             }
             for (int a = 0; a < nu; ++a) {
-                float acc = 0.f;
-                for (int c = 0; c < nu; ++c) acc = fmaf(cQi[a + c * nu], t[c], acc);
-                AT(sd, k * nu + a) = acc;
+                RT acc = 0;
+                for (int c = 0; c < nu; ++c) acc = gfma(cQi[a + c * nu], t[c], acc);
+                AT(sd, k * nu + a) = (float)acc;
             }
             for (int r = 0; r < nx; ++r) {
-                float ap = 0.f, kr = 0.f;
-                for (int j = 0; j < nx; ++j) ap = fmaf(cAt[r + j * nx], xv[j], ap);
-                for (int a = 0; a < nu; ++a) kr = fmaf(cK[a + r * nu], AT(sr, k * nu + a), kr);
-                AT(sp, k * nx + r) = (AT(sq, k * nx + r) + ap) - kr;
+                RT ap = (RT)AT(sq, k * nx + r), kr = 0;
+                for (int j = 0; j < nx; ++j) ap = gfma(cAt[r + j * nx], xv[j], ap);
+                for (int a = 0; a < nu; ++a) kr = gfma(cK[a + r * nu], rv[a], kr);
+                xn[r] = ap - kr;
             }
+            for (int r = 0; r < nx; ++r) xv[r] = xn[r];
         }
     }
     for (int e = 0; e < EX; ++e) P.xout[b * EX + e] = AT(svn, e);

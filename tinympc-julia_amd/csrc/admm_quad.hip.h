@@ -17,14 +17,20 @@
 //     75 % for nx = 6.  See DESIGN.md.)
 //   * the small mat-vecs (nx x nx, nu x nx, ...) are row-per-lane FMAs whose vector
 //     operand is fetched from the owning lane of the quad with a DPP quad_perm
-//     broadcast — no LDS, no ds_bpermute, no MFMA (4x4 .. 12x12 is not a contraction
-//     worth a matrix core).
-//   * every trajectory the ADMM iteration carries (g, v, vnew, y, z, znew, d) lives in
-//     VGPRs for the whole solve; the horizon loops are fully unrolled so the arrays are
-//     statically indexed.  x, u, q, r, p of the reference are never materialised: they
-//     are produced and consumed knot by knot inside the two fused sweeps.
-//   * family constants: coefficient rows are loaded once per lane; per-knot bounds (and
-//     shared references) are staged once per workgroup in LDS.
+//     broadcast — no LDS traffic, no ds_bpermute, no MFMA (4x4 .. 12x12 is not a
+//     contraction worth a matrix core).
+//   * precision: the two serial recurrences (rollout x_{k+1} = A x_k + B u_k and the
+//     Riccati gradient p_k, d_k) run in RT = double on the fp64 VALU with fp64
+//     coefficients; everything the ADMM iteration stores (g, v, vnew, y, z, znew, d) and
+//     all elementwise steps are fp32.  All-fp32 (RT = float) is selectable; it is faster
+//     but its worst instance misses the 1e-5 parity target (DESIGN.md "Precision").
+//   * every trajectory the ADMM iteration carries lives on chip for the whole solve:
+//     in VGPRs (horizon loops fully unrolled, statically indexed), with the two
+//     "previous slack" arrays optionally parked in LDS for long horizons.  x, u, q, r, p
+//     of the reference are never materialised: they are produced and consumed knot by
+//     knot inside the two fused sweeps.
+//   * family constants: coefficient rows sit in VGPRs (small shapes) or LDS (nx = 12);
+//     per-knot bounds and shared references are staged once per workgroup in LDS.
 //   * HBM traffic is the compulsory I/O only: x0 (+refs, +warm state) in, x/u/status
 //     (+warm state) out.
 #pragma once
@@ -43,27 +49,37 @@ struct QuadShape {
     static constexpr int NXP = 4 * RX, NUP = 4 * RU;
     static constexpr int NXL = (NX + RX - 1) / RX;  // lanes of a quad owning real x rows
     static constexpr int NUL = (NU + RU - 1) / RU;  // lanes of a quad owning real u rows
-    // Coefficient pack per lane role q (floats); rows beyond nx/nu and columns beyond
-    // nx/nu are zero.  Filled by host (solver.cpp: build_quad_coef).
-    static constexpr int O_A = 0;                 // A      rows [RX][NXP]
-    static constexpr int O_AT = O_A + RX * NXP;   // AmBKt  rows [RX][NXP]
-    static constexpr int O_K = O_AT + RX * NXP;   // Kinf   rows [RU][NXP]
-    static constexpr int O_B = O_K + RU * NXP;    // B      rows [RX][NUP]
-    static constexpr int O_BT = O_B + RX * NUP;   // B^T    rows [RU][NXP]
-    static constexpr int O_KT = O_BT + RU * NXP;  // Kinf^T rows [RX][NUP]
+    // Coefficient pack per lane role q (elements of RT); rows beyond nx/nu and columns
+    // beyond nx/nu are zero.  Filled by the host (kernels.hip: build_quad_coef).
+    static constexpr int O_A = 0;                 // A       rows [RX][NXP]
+    static constexpr int O_AT = O_A + RX * NXP;   // AmBKt   rows [RX][NXP]
+    static constexpr int O_K = O_AT + RX * NXP;   // Kinf    rows [RU][NXP]
+    static constexpr int O_B = O_K + RU * NXP;    // B       rows [RX][NUP]
+    static constexpr int O_BT = O_B + RX * NUP;   // B^T     rows [RU][NXP]
+    static constexpr int O_KT = O_BT + RU * NXP;  // Kinf^T  rows [RX][NUP]
     static constexpr int O_QI = O_KT + RX * NUP;  // Quu_inv rows [RU][NUP]
-    static constexpr int O_PT = O_QI + RU * NUP;  // Pinf^T rows [RX][NXP]
-    static constexpr int O_QD = O_PT + RX * NXP;  // diag(Q)+rho [RX]
-    static constexpr int O_RD = O_QD + RX;        // diag(R)+rho [RU]
-    static constexpr int CP = O_RD + RU;
+    static constexpr int O_PT = O_QI + RU * NUP;  // Pinf^T  rows [RX][NXP]
+    static constexpr int CP = O_PT + RX * NXP;
+    // fp32 side pack per role: diag(Q)+rho [RX], diag(R)+rho [RU]
+    static constexpr int DW = RX + RU;
     // Bounds pack: [N][4 roles][xmin[RX] xmax[RX] umin[RU] umax[RU]]
     static constexpr int BW = 2 * RX + 2 * RU;
-    static constexpr int BOUNDS_LEN = N * 4 * BW;
+    static constexpr int BOUNDS_LEN = N * 4 * BW + 4 * DW;  // + the diag pack at the end
     // Shared-reference pack: [N][4 roles][xref[RX] uref[RU]]
     static constexpr int RW = RX + RU;
     static constexpr int REFS_LEN = N * 4 * RW;
     static constexpr int INST_PER_BLOCK = 64;
     static constexpr int THREADS = 256;
+    // ---- storage policy ----
+    // coefficients in LDS when their register footprint would exceed ~1/4 of the VGPR file
+    template <class RT>
+    static constexpr bool coef_in_lds() {
+        return CP * (int)(sizeof(RT) / 4) > 72;
+    }
+    // previous-slack arrays v, z in LDS when the register-resident state would not fit
+    static constexpr int STATE_REGS = 3 * RX * N + 4 * RU * (N - 1);
+    static constexpr bool OLD_IN_LDS = STATE_REGS > 300;
+    static constexpr int OLD_LEN = OLD_IN_LDS ? (RX * N + RU * (N - 1)) * THREADS : 1;
 };
 
 // ---- compile-time loop, so DPP controls are integer constant expressions ----
@@ -77,12 +93,21 @@ __device__ __forceinline__ void sfor(F &&f) {
 
 // DPP quad_perm: lane l reads lane (l & ~3) | perm[l & 3] of its own quad.
 template <int CTRL>
-__device__ __forceinline__ float dpp_quad(float v) {
-    return __builtin_bit_cast(
-        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+__device__ __forceinline__ int dpp_quad_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
 }
-template <int S>
-__device__ __forceinline__ float qbcast(float v) {
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float v) {
+    return __builtin_bit_cast(float, dpp_quad_i<CTRL>(__builtin_bit_cast(int, v)));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_quad(double v) {
+    const int lo = dpp_quad_i<CTRL>(__double2loint(v));
+    const int hi = dpp_quad_i<CTRL>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+template <int S, class T>
+__device__ __forceinline__ T qbcast(T v) {
     return dpp_quad<S * 0x55>(v);  // quad_perm:[S,S,S,S]
 }
 __device__ __forceinline__ float quad_max(float m) {
@@ -90,37 +115,49 @@ __device__ __forceinline__ float quad_max(float m) {
     m = fmaxf(m, dpp_quad<0x4E>(m));  // quad_perm:[2,3,0,1]
     return m;
 }
+__device__ __forceinline__ float tfma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ double tfma(double a, double b, double c) { return fma(a, b, c); }
 
 // acc[m] += sum_{s < SL} sum_{k < SK} C[m*CW + s*SK + k] * (src[k] of quad lane s)
-template <int ROWS, int SL, int SK, int CW>
-__device__ __forceinline__ void quad_matvec(float (&acc)[ROWS], const float *C,
-                                            const float (&src)[SK]) {
+template <int ROWS, int SL, int SK, int CW, class RT, class CP>
+__device__ __forceinline__ void quad_matvec(RT (&acc)[ROWS], const CP C, const RT (&src)[SK]) {
     sfor<0, SL>([&](auto s) {
         constexpr int S = decltype(s)::value;
 #pragma unroll
         for (int k = 0; k < SK; ++k) {
-            const float xv = qbcast<S>(src[k]);
+            const RT xv = qbcast<S>(src[k]);
 #pragma unroll
-            for (int m = 0; m < ROWS; ++m) acc[m] = fmaf(C[m * CW + S * SK + k], xv, acc[m]);
+            for (int m = 0; m < ROWS; ++m) acc[m] = tfma((RT)C[m * CW + S * SK + k], xv, acc[m]);
         }
     });
 }
 
-template <class S, int REFS>
+template <class S, int REFS, class RT>
 __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
     constexpr int NX = S::NX, NU = S::NU, N = S::N;
     constexpr int RX = S::RX, RU = S::RU, NXP = S::NXP, NUP = S::NUP;
     constexpr int NXL = S::NXL, NUL = S::NUL;
     constexpr int EX = NX * N, EU = NU * (N - 1);
+    constexpr bool COEF_LDS = S::template coef_in_lds<RT>();
+    constexpr bool OLD_LDS = S::OLD_IN_LDS;
+    constexpr int T = S::THREADS;
 
     __shared__ float s_bnd[S::BOUNDS_LEN];
     __shared__ float s_ref[REFS == REF_SHARED ? S::REFS_LEN : 1];
+    __shared__ RT s_coef[COEF_LDS ? 4 * S::CP : 1];
+    __shared__ float s_old[S::OLD_LEN];
+    static_assert(sizeof(float) * (S::BOUNDS_LEN + S::REFS_LEN + S::OLD_LEN) + sizeof(RT) * 4 * S::CP <=
+                      160 * 1024,
+                  "workgroup LDS budget exceeded");
 
     const int tid = threadIdx.x;
-    for (int i = tid; i < S::BOUNDS_LEN; i += S::THREADS) s_bnd[i] = P.bounds[i];
+    const RT *gcoef = reinterpret_cast<const RT *>(P.coef);
+    for (int i = tid; i < S::BOUNDS_LEN; i += T) s_bnd[i] = P.bounds[i];
+    if constexpr (COEF_LDS)
+        for (int i = tid; i < 4 * S::CP; i += T) s_coef[i] = gcoef[i];
     if constexpr (REFS == REF_SHARED) {
-        // pack [N][4][xref[RX] uref[RU]] from row-major-per-knot xref [N][nx], uref [N-1][nu]
-        for (int i = tid; i < S::REFS_LEN; i += S::THREADS) {
+        // pack [N][4][xref[RX] uref[RU]] from knot-major xref [N][nx], uref [N-1][nu]
+        for (int i = tid; i < S::REFS_LEN; i += T) {
             const int k = i / (4 * S::RW), rem = i % (4 * S::RW);
             const int qq = rem / S::RW, j = rem % S::RW;
             float val = 0.f;
@@ -141,34 +178,51 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
     const bool active = b < P.batch;
     const float *lb = s_bnd + q * S::BW;
     const float *lr = s_ref + q * S::RW;
+    const float *ld = s_bnd + N * 4 * S::BW + q * S::DW;  // diag(Q)+rho, diag(R)+rho
 
-    // ---- per-lane coefficient rows ----
-    const float *cp = P.coef + q * S::CP;
-    float cA[RX * NXP], cAT[RX * NXP], cK[RU * NXP], cB[RX * NUP], cBT[RU * NXP], cKT[RX * NUP],
-        cQI[RU * NUP], cQD[RX], cRD[RU];
+    // ---- per-lane coefficient rows: registers, or LDS for the big shapes ----
+    RT rcoef[COEF_LDS ? 1 : S::CP];
+    const RT *cbase;
+    if constexpr (COEF_LDS) {
+        cbase = s_coef + q * S::CP;
+    } else {
+        const RT *cp = gcoef + q * S::CP;
 #pragma unroll
-    for (int i = 0; i < RX * NXP; ++i) cA[i] = cp[S::O_A + i];
+        for (int i = 0; i < S::CP; ++i) rcoef[i] = cp[i];
+        cbase = rcoef;
+    }
+    const RT *cA = cbase + S::O_A, *cAT = cbase + S::O_AT, *cK = cbase + S::O_K, *cB = cbase + S::O_B,
+             *cBT = cbase + S::O_BT, *cKT = cbase + S::O_KT, *cQI = cbase + S::O_QI,
+             *cPT = cbase + S::O_PT;
+    float cQD[RX], cRD[RU];
 #pragma unroll
-    for (int i = 0; i < RX * NXP; ++i) cAT[i] = cp[S::O_AT + i];
+    for (int m = 0; m < RX; ++m) cQD[m] = ld[m];
 #pragma unroll
-    for (int i = 0; i < RU * NXP; ++i) cK[i] = cp[S::O_K + i];
-#pragma unroll
-    for (int i = 0; i < RX * NUP; ++i) cB[i] = cp[S::O_B + i];
-#pragma unroll
-    for (int i = 0; i < RU * NXP; ++i) cBT[i] = cp[S::O_BT + i];
-#pragma unroll
-    for (int i = 0; i < RX * NUP; ++i) cKT[i] = cp[S::O_KT + i];
-#pragma unroll
-    for (int i = 0; i < RU * NUP; ++i) cQI[i] = cp[S::O_QI + i];
-#pragma unroll
-    for (int i = 0; i < RX; ++i) cQD[i] = cp[S::O_QD + i];
-#pragma unroll
-    for (int i = 0; i < RU; ++i) cRD[i] = cp[S::O_RD + i];
+    for (int m = 0; m < RU; ++m) cRD[m] = ld[RX + m];
     const float rho = P.rho;
 
-    // ---- per-instance state, all in registers ----
-    float g[N][RX], v[N][RX], w[N][RX];
-    float y[N - 1][RU], z[N - 1][RU], zw[N - 1][RU], d[N - 1][RU];
+    // ---- per-instance state ----
+    float g[N][RX], w[N][RX];
+    float y[N - 1][RU], zw[N - 1][RU], d[N - 1][RU];
+    float vreg[OLD_LDS ? 1 : N][RX], zreg[OLD_LDS ? 1 : N - 1][RU];
+    float *lv = s_old + tid;                    // v: [k][m][T]
+    float *lz = s_old + RX * N * T + tid;       // z: [k][m][T]
+    auto v_get = [&](int k, int m) -> float {
+        if constexpr (OLD_LDS) return lv[(k * RX + m) * T];
+        else return vreg[k][m];
+    };
+    auto v_set = [&](int k, int m, float val) {
+        if constexpr (OLD_LDS) lv[(k * RX + m) * T] = val;
+        else vreg[k][m] = val;
+    };
+    auto z_get = [&](int k, int m) -> float {
+        if constexpr (OLD_LDS) return lz[(k * RU + m) * T];
+        else return zreg[k][m];
+    };
+    auto z_set = [&](int k, int m, float val) {
+        if constexpr (OLD_LDS) lz[(k * RU + m) * T] = val;
+        else zreg[k][m] = val;
+    };
     float x0[RX];
     float xr[REFS == REF_PER_INSTANCE ? N : 1][RX];
     float ur[REFS == REF_PER_INSTANCE ? N - 1 : 1][RU];
@@ -179,31 +233,71 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
         x0[m] = (active && row < NX) ? P.x0[b * NX + row] : 0.f;
     }
     const bool warm = active && !P.cold_start;
+    // cold start = the zero workspace tiny_setup leaves (tiny_api.cpp:73-88)
 #pragma unroll
     for (int k = 0; k < N; ++k)
 #pragma unroll
         for (int m = 0; m < RX; ++m) {
-            const int row = q * RX + m;
-            const bool ld = warm && row < NX;
-            g[k][m] = ld ? P.sg[b * EX + k * NX + row] : 0.f;
-            v[k][m] = ld ? P.sv[b * EX + k * NX + row] : 0.f;
+            g[k][m] = 0.f;
             w[k][m] = 0.f;
-            if constexpr (REFS == REF_PER_INSTANCE)
-                xr[k][m] = (active && row < NX) ? P.xref[b * EX + k * NX + row] : 0.f;
+            v_set(k, m, 0.f);
+            if constexpr (REFS == REF_PER_INSTANCE) xr[k][m] = 0.f;
         }
 #pragma unroll
     for (int k = 0; k < N - 1; ++k)
 #pragma unroll
         for (int m = 0; m < RU; ++m) {
-            const int row = q * RU + m;
-            const bool ld = warm && row < NU;
-            y[k][m] = ld ? P.sy[b * EU + k * NU + row] : 0.f;
-            z[k][m] = ld ? P.sz[b * EU + k * NU + row] : 0.f;
-            d[k][m] = ld ? P.sd[b * EU + k * NU + row] : 0.f;
+            y[k][m] = 0.f;
+            d[k][m] = 0.f;
             zw[k][m] = 0.f;
-            if constexpr (REFS == REF_PER_INSTANCE)
-                ur[k][m] = (active && row < NU) ? P.uref[b * EU + k * NU + row] : 0.f;
+            z_set(k, m, 0.f);
+            if constexpr (REFS == REF_PER_INSTANCE) ur[k][m] = 0.f;
         }
+    if (warm) {
+#pragma unroll
+        for (int m = 0; m < RX; ++m) {
+            const int row = q * RX + m;
+            if (row < NX) {
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    g[k][m] = P.sg[b * EX + k * NX + row];
+                    v_set(k, m, P.sv[b * EX + k * NX + row]);
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < RU; ++m) {
+            const int row = q * RU + m;
+            if (row < NU) {
+#pragma unroll
+                for (int k = 0; k < N - 1; ++k) {
+                    y[k][m] = P.sy[b * EU + k * NU + row];
+                    z_set(k, m, P.sz[b * EU + k * NU + row]);
+                    d[k][m] = P.sd[b * EU + k * NU + row];
+                }
+            }
+        }
+    }
+    if constexpr (REFS == REF_PER_INSTANCE) {
+        if (active) {
+#pragma unroll
+            for (int m = 0; m < RX; ++m) {
+                const int row = q * RX + m;
+                if (row < NX) {
+#pragma unroll
+                    for (int k = 0; k < N; ++k) xr[k][m] = P.xref[b * EX + k * NX + row];
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < RU; ++m) {
+                const int row = q * RU + m;
+                if (row < NU) {
+#pragma unroll
+                    for (int k = 0; k < N - 1; ++k) ur[k][m] = P.uref[b * EU + k * NU + row];
+                }
+            }
+        }
+    }
 
     auto ref_x = [&](auto kk, int m) -> float {
         constexpr int K = decltype(kk)::value;
@@ -237,45 +331,50 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
             // ================= fused forward sweep =================
             // forward_pass (admm.cpp:25-35) + update_slack (:43-59) + update_dual (:65-69)
             // + the residual maxima of termination_condition (:93-96), knot by knot.
-            float x[RX];
+            RT x[RX];
 #pragma unroll
-            for (int m = 0; m < RX; ++m) x[m] = x0[m];
+            for (int m = 0; m < RX; ++m) x[m] = (RT)x0[m];
             float pri_x = 0.f, dua_x = 0.f, pri_u = 0.f, dua_u = 0.f;
 #pragma unroll
             for (int k = 0; k < N; ++k) {
+                // LDS-resident constants are re-read at every knot instead of being hoisted
+                // into (and spilled from) registers for the whole solve.
+                if constexpr (COEF_LDS) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
                 for (int m = 0; m < RX; ++m) {
-                    float vn = x[m] + g[k][m];                                  // vnew = x + g
+                    const float xf = (float)x[m];
+                    float vn = xf + g[k][m];                                    // vnew = x + g
                     vn = fminf(lb[k * 4 * S::BW + RX + m],                      // x_max.cwiseMin(
                                fmaxf(lb[k * 4 * S::BW + m], vn));               //   x_min.cwiseMax(vnew))
-                    g[k][m] = (g[k][m] + x[m]) - vn;                            // g = g + x - vnew
-                    pri_x = fmaxf(pri_x, fabsf(x[m] - vn));
-                    dua_x = fmaxf(dua_x, fabsf(v[k][m] - vn));
+                    g[k][m] = (g[k][m] + xf) - vn;                              // g = g + x - vnew
+                    pri_x = fmaxf(pri_x, fabsf(xf - vn));
+                    dua_x = fmaxf(dua_x, fabsf(v_get(k, m) - vn));
                     w[k][m] = vn;
                 }
                 if (k < N - 1) {
-                    float u[RU];
+                    RT u[RU];
 #pragma unroll
-                    for (int m = 0; m < RU; ++m) u[m] = 0.f;
+                    for (int m = 0; m < RU; ++m) u[m] = (RT)0;
                     quad_matvec<RU, NXL, RX, NXP>(u, cK, x);                    // Kinf x
 #pragma unroll
                     for (int m = 0; m < RU; ++m) {
-                        u[m] = -u[m] - d[k][m];                                 // u = -Kinf x - d
-                        float zn = u[m] + y[k][m];                              // znew = u + y
+                        u[m] = -u[m] - (RT)d[k][m];                             // u = -Kinf x - d
+                        const float uf = (float)u[m];
+                        float zn = uf + y[k][m];                                // znew = u + y
                         zn = fminf(lb[k * 4 * S::BW + 2 * RX + RU + m],
                                    fmaxf(lb[k * 4 * S::BW + 2 * RX + m], zn));
-                        y[k][m] = (y[k][m] + u[m]) - zn;                        // y = y + u - znew
-                        pri_u = fmaxf(pri_u, fabsf(u[m] - zn));
-                        dua_u = fmaxf(dua_u, fabsf(z[k][m] - zn));
+                        y[k][m] = (y[k][m] + uf) - zn;                          // y = y + u - znew
+                        pri_u = fmaxf(pri_u, fabsf(uf - zn));
+                        dua_u = fmaxf(dua_u, fabsf(z_get(k, m) - zn));
                         zw[k][m] = zn;
                     }
-                    float xn[RX], bu[RX];
+                    RT xn[RX];
 #pragma unroll
-                    for (int m = 0; m < RX; ++m) xn[m] = bu[m] = 0.f;
-                    quad_matvec<RX, NXL, RX, NXP>(xn, cA, x);                   // A x
-                    quad_matvec<RX, NUL, RU, NUP>(bu, cB, u);                   // B u
+                    for (int m = 0; m < RX; ++m) xn[m] = (RT)0;
+                    quad_matvec<RX, NUL, RU, NUP>(xn, cB, u);                   // B u
+                    quad_matvec<RX, NXL, RX, NXP>(xn, cA, x);                   //   + A x
 #pragma unroll
-                    for (int m = 0; m < RX; ++m) x[m] = xn[m] + bu[m];
+                    for (int m = 0; m < RX; ++m) x[m] = xn[m];
                 }
             }
             it += 1;  // admm.cpp:143
@@ -301,69 +400,62 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
                 // ================= fused backward sweep =================
                 // v = vnew, z = znew (admm.cpp:196-197); update_linear_cost (:75-83) and
                 // backward_pass_grad (:13-20) knot by knot, q/r/p never stored.
-                float p[RX];
+                RT p[RX];
                 {
-                    float acc[RX];
+                    RT acc[RX];
 #pragma unroll
-                    for (int m = 0; m < RX; ++m) acc[m] = 0.f;
+                    for (int m = 0; m < RX; ++m) acc[m] = (RT)0;
                     if constexpr (REFS != REF_ZERO) {
-                        float xrl[RX];
+                        RT xrl[RX];
 #pragma unroll
-                        for (int m = 0; m < RX; ++m)
-                            xrl[m] = ref_x(std::integral_constant<int, N - 1>{}, m);
-                        // -(Xref_{N-1}^T Pinf)^T  (admm.cpp:81)
-                        float cPT[RX * NXP];
-#pragma unroll
-                        for (int i2 = 0; i2 < RX * NXP; ++i2) cPT[i2] = cp[S::O_PT + i2];
-                        quad_matvec<RX, NXL, RX, NXP>(acc, cPT, xrl);
+                        for (int m = 0; m < RX; ++m) xrl[m] = (RT)ref_x(std::integral_constant<int, N - 1>{}, m);
+                        quad_matvec<RX, NXL, RX, NXP>(acc, cPT, xrl);           // (Xref_{N-1}^T Pinf)^T
                     }
 #pragma unroll
                     for (int m = 0; m < RX; ++m) {
-                        p[m] = -acc[m] - rho * (w[N - 1][m] - g[N - 1][m]);    // admm.cpp:81-82
-                        v[N - 1][m] = w[N - 1][m];
+                        p[m] = -acc[m] - (RT)(rho * (w[N - 1][m] - g[N - 1][m]));  // admm.cpp:81-82
+                        v_set(N - 1, m, w[N - 1][m]);
                     }
                 }
                 sfor<0, N - 1>([&](auto kk) {
                     constexpr int k = N - 2 - decltype(kk)::value;
                     constexpr std::integral_constant<int, k> kc{};
-                    float r[RU], qk[RX];
+                    if constexpr (COEF_LDS) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+                    RT r[RU], qk[RX];
 #pragma unroll
                     for (int m = 0; m < RU; ++m) {
                         float rr = 0.f;
-                        if constexpr (REFS != REF_ZERO) {
-                            rr = -(ref_u(kc, m) * cRD[m]);                               // -(Uref .* R)
-                        }
-                        r[m] = rr - rho * (zw[k][m] - y[k][m]);                 // admm.cpp:77-78
-                        z[k][m] = zw[k][m];
+                        if constexpr (REFS != REF_ZERO) rr = -(ref_u(kc, m) * cRD[m]);  // -(Uref .* R)
+                        r[m] = (RT)(rr - rho * (zw[k][m] - y[k][m]));           // admm.cpp:77-78
+                        z_set(k, m, zw[k][m]);
                     }
 #pragma unroll
                     for (int m = 0; m < RX; ++m) {
                         float qq = 0.f;
-                        if constexpr (REFS != REF_ZERO) {
-                            qq = -(ref_x(kc, m) * cQD[m]);                               // -(Xref .* Q)
-                        }
-                        qk[m] = qq - rho * (w[k][m] - g[k][m]);                 // admm.cpp:79-80
-                        v[k][m] = w[k][m];
+                        if constexpr (REFS != REF_ZERO) qq = -(ref_x(kc, m) * cQD[m]);  // -(Xref .* Q)
+                        qk[m] = (RT)(qq - rho * (w[k][m] - g[k][m]));           // admm.cpp:79-80
+                        v_set(k, m, w[k][m]);
                     }
-                    float t[RU];
+                    RT t[RU];
 #pragma unroll
-                    for (int m = 0; m < RU; ++m) t[m] = 0.f;
-                    quad_matvec<RU, NXL, RX, NXP>(t, cBT, p);                   // B^T p_{k+1}
+                    for (int m = 0; m < RU; ++m) t[m] = r[m];
+                    quad_matvec<RU, NXL, RX, NXP>(t, cBT, p);                   // B^T p_{k+1} + r_k
+                    RT dn[RU];
 #pragma unroll
-                    for (int m = 0; m < RU; ++m) t[m] += r[m];                  //   + r_k
-                    float dn[RU];
-#pragma unroll
-                    for (int m = 0; m < RU; ++m) dn[m] = 0.f;
+                    for (int m = 0; m < RU; ++m) dn[m] = (RT)0;
                     quad_matvec<RU, NUL, RU, NUP>(dn, cQI, t);                  // d_k = Quu_inv (...)
 #pragma unroll
-                    for (int m = 0; m < RU; ++m) d[k][m] = dn[m];
-                    float ap[RX], kr[RX];
+                    for (int m = 0; m < RU; ++m) d[k][m] = (float)dn[m];
+                    RT ap[RX], kr[RX];
 #pragma unroll
-                    for (int m = 0; m < RX; ++m) ap[m] = kr[m] = 0.f;
-                    quad_matvec<RX, NXL, RX, NXP>(ap, cAT, p);                  // AmBKt p_{k+1}
+                    for (int m = 0; m < RX; ++m) {
+                        ap[m] = qk[m];
+                        kr[m] = (RT)0;
+                    }
+                    quad_matvec<RX, NXL, RX, NXP>(ap, cAT, p);                  // q_k + AmBKt p_{k+1}
                     quad_matvec<RX, NUL, RU, NUP>(kr, cKT, r);                  // Kinf^T r_k
 #pragma unroll
-                    for (int m = 0; m < RX; ++m) p[m] = (qk[m] + ap[m]) - kr[m];  // admm.cpp:18
+                    for (int m = 0; m < RX; ++m) p[m] = ap[m] - kr[m];          // admm.cpp:18
                 });
             }
         }
@@ -375,19 +467,21 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
     if (active) {
         // solution = projected slack of the last executed iteration (admm.cpp:187-188,204-205)
 #pragma unroll
-        for (int k = 0; k < N; ++k)
+        for (int m = 0; m < RX; ++m) {
+            const int row = q * RX + m;
+            if (row < NX) {
 #pragma unroll
-            for (int m = 0; m < RX; ++m) {
-                const int row = q * RX + m;
-                if (row < NX) P.xout[b * EX + k * NX + row] = w[k][m];
+                for (int k = 0; k < N; ++k) P.xout[b * EX + k * NX + row] = w[k][m];
             }
+        }
 #pragma unroll
-        for (int k = 0; k < N - 1; ++k)
+        for (int m = 0; m < RU; ++m) {
+            const int row = q * RU + m;
+            if (row < NU) {
 #pragma unroll
-            for (int m = 0; m < RU; ++m) {
-                const int row = q * RU + m;
-                if (row < NU) P.uout[b * EU + k * NU + row] = zw[k][m];
+                for (int k = 0; k < N - 1; ++k) P.uout[b * EU + k * NU + row] = zw[k][m];
             }
+        }
         if (q == 0) {
             P.iter[b] = it;
             P.solved[b] = conv;
@@ -398,26 +492,28 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
         }
         if (P.save_state) {
 #pragma unroll
-            for (int k = 0; k < N; ++k)
+            for (int m = 0; m < RX; ++m) {
+                const int row = q * RX + m;
+                if (row < NX) {
 #pragma unroll
-                for (int m = 0; m < RX; ++m) {
-                    const int row = q * RX + m;
-                    if (row < NX) {
+                    for (int k = 0; k < N; ++k) {
                         P.sg[b * EX + k * NX + row] = g[k][m];
-                        P.sv[b * EX + k * NX + row] = v[k][m];
+                        P.sv[b * EX + k * NX + row] = v_get(k, m);
                     }
                 }
+            }
 #pragma unroll
-            for (int k = 0; k < N - 1; ++k)
+            for (int m = 0; m < RU; ++m) {
+                const int row = q * RU + m;
+                if (row < NU) {
 #pragma unroll
-                for (int m = 0; m < RU; ++m) {
-                    const int row = q * RU + m;
-                    if (row < NU) {
+                    for (int k = 0; k < N - 1; ++k) {
                         P.sy[b * EU + k * NU + row] = y[k][m];
-                        P.sz[b * EU + k * NU + row] = z[k][m];
+                        P.sz[b * EU + k * NU + row] = z_get(k, m);
                         P.sd[b * EU + k * NU + row] = d[k][m];
                     }
                 }
+            }
         }
     }
     // global status block: wavefront max of the residuals, count of unsolved instances

@@ -210,6 +210,19 @@ int tinympc_set_ref_mode(tinympc_solver *s, int ref_mode) {
     });
 }
 
+int tinympc_set_profiling(tinympc_solver *s, int enable) {
+    if (!s) return -1;
+    s->s.profiling = enable != 0;
+    return 0;
+}
+double tinympc_kernel_elapsed_ms(tinympc_solver *s) { return s ? s->s.kernel_elapsed_ms() : -1.0; }
+int tinympc_set_precision(tinympc_solver *s, int precision) {
+    if (!s || precision < 0 || precision > 1) return -1;
+    if (s->s.precision != precision) s->s.packs_dirty = true;
+    s->s.precision = precision;
+    return 0;
+}
+
 const char *tinympc_kernel_name(tinympc_solver *s) { return s ? s->s.kernel_name.c_str() : ""; }
 
 /* compulsory fp32 device I/O per solve, state on chip. */

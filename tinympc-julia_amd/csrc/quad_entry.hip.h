@@ -1,0 +1,125 @@
+// Host-side pack builders + launcher for one QuadShape; each shape is instantiated in its
+// own translation unit (inst_*.hip) so the unrolled kernels compile in parallel.
+#pragma once
+#include <cstring>
+#include <limits>
+
+#include "admm_quad.hip.h"
+#include "solver.h"
+
+namespace tmpc {
+
+template <class RT>
+inline void put_coef(std::vector<unsigned char> &out, size_t idx, double val) {
+    const RT v = (RT)val;
+    std::memcpy(out.data() + idx * sizeof(RT), &v, sizeof(RT));
+}
+
+// layout: QuadShape in admm_quad.hip.h
+template <class S, class RT>
+void fill_quad_coef(const Solver &sv, std::vector<unsigned char> &out) {
+    constexpr int NX = S::NX, NU = S::NU, RX = S::RX, RU = S::RU, NXP = S::NXP, NUP = S::NUP;
+    out.assign((size_t)4 * S::CP * sizeof(RT), 0);
+    const Cache &c = sv.cache;
+    for (int q = 0; q < 4; ++q) {
+        const size_t o = (size_t)q * S::CP;
+        for (int m = 0; m < RX; ++m) {
+            const int row = q * RX + m;
+            if (row >= NX) continue;
+            for (int j = 0; j < NX; ++j) {
+                put_coef<RT>(out, o + S::O_A + m * NXP + j, sv.A(row, j));
+                put_coef<RT>(out, o + S::O_AT + m * NXP + j, c.AmBKt(row, j));
+                put_coef<RT>(out, o + S::O_PT + m * NXP + j, c.Pinf(j, row));  // (Pinf^T)[row][j]
+            }
+            for (int a = 0; a < NU; ++a) {
+                put_coef<RT>(out, o + S::O_B + m * NUP + a, sv.B(row, a));
+                put_coef<RT>(out, o + S::O_KT + m * NUP + a, c.Kinf(a, row));  // (Kinf^T)[row][a]
+            }
+        }
+        for (int m = 0; m < RU; ++m) {
+            const int row = q * RU + m;
+            if (row >= NU) continue;
+            for (int j = 0; j < NX; ++j) {
+                put_coef<RT>(out, o + S::O_K + m * NXP + j, c.Kinf(row, j));
+                put_coef<RT>(out, o + S::O_BT + m * NXP + j, sv.B(j, row));  // (B^T)[row][j]
+            }
+            for (int a = 0; a < NU; ++a) put_coef<RT>(out, o + S::O_QI + m * NUP + a, c.Quu_inv(row, a));
+        }
+    }
+}
+
+template <class S>
+void build_quad_coef(const Solver &sv, std::vector<unsigned char> &out) {
+    if (sv.precision == 0)
+        fill_quad_coef<S, double>(sv, out);
+    else
+        fill_quad_coef<S, float>(sv, out);
+}
+
+template <class S>
+void build_quad_bounds(const Solver &sv, std::vector<float> &out) {
+    constexpr float kInf = std::numeric_limits<float>::infinity();
+    constexpr int NX = S::NX, NU = S::NU, N = S::N, RX = S::RX, RU = S::RU, BW = S::BW;
+    out.assign((size_t)S::BOUNDS_LEN, 0.f);
+    for (int k = 0; k < N; ++k)
+        for (int q = 0; q < 4; ++q) {
+            float *p = out.data() + ((size_t)k * 4 + q) * BW;
+            for (int m = 0; m < RX; ++m) {
+                const int row = q * RX + m;
+                const bool on = sv.st.en_state_bound && row < NX;
+                p[m] = on ? (float)sv.x_min[row + (size_t)k * NX] : -kInf;
+                p[RX + m] = on ? (float)sv.x_max[row + (size_t)k * NX] : kInf;
+            }
+            for (int m = 0; m < RU; ++m) {
+                const int row = q * RU + m;
+                const bool on = sv.st.en_input_bound && row < NU && k < N - 1;
+                p[2 * RX + m] = on ? (float)sv.u_min[row + (size_t)k * NU] : -kInf;
+                p[2 * RX + RU + m] = on ? (float)sv.u_max[row + (size_t)k * NU] : kInf;
+            }
+        }
+    // diag(Q)+rho, diag(R)+rho per role (tiny_api.cpp:90-91)
+    float *dg = out.data() + (size_t)N * 4 * BW;
+    for (int q = 0; q < 4; ++q) {
+        for (int m = 0; m < RX; ++m) {
+            const int row = q * RX + m;
+            dg[q * S::DW + m] = row < NX ? (float)sv.cache.Qd[row] : 0.f;
+        }
+        for (int m = 0; m < RU; ++m) {
+            const int row = q * RU + m;
+            dg[q * S::DW + RX + m] = row < NU ? (float)sv.cache.Rd[row] : 0.f;
+        }
+    }
+}
+
+template <class S, class RT>
+hipError_t launch_quad_rt(const AdmmParams &P, hipStream_t stream) {
+    const int grid = (P.batch + S::INST_PER_BLOCK - 1) / S::INST_PER_BLOCK;
+    switch (P.ref_mode) {
+        case REF_ZERO:
+            hipLaunchKernelGGL((admm_quad_kernel<S, REF_ZERO, RT>), dim3(grid), dim3(S::THREADS), 0, stream, P);
+            break;
+        case REF_SHARED:
+            hipLaunchKernelGGL((admm_quad_kernel<S, REF_SHARED, RT>), dim3(grid), dim3(S::THREADS), 0, stream, P);
+            break;
+        default:
+            hipLaunchKernelGGL((admm_quad_kernel<S, REF_PER_INSTANCE, RT>), dim3(grid), dim3(S::THREADS), 0,
+                               stream, P);
+            break;
+    }
+    return hipGetLastError();
+}
+
+template <class S>
+hipError_t launch_quad(const AdmmParams &P, int precision, hipStream_t stream) {
+    return precision == 0 ? launch_quad_rt<S, double>(P, stream) : launch_quad_rt<S, float>(P, stream);
+}
+
+#define TMPC_DEFINE_QUAD_ENTRY(NX, NU, NN)                                                     \
+    const KernelEntry *quad_entry_##NX##_##NU##_##NN() {                                       \
+        using S = QuadShape<NX, NU, NN>;                                                       \
+        static const KernelEntry e = {NX, NU, NN, "quad<" #NX "," #NU "," #NN ">",            \
+                                      &build_quad_coef<S>, &build_quad_bounds<S>, &launch_quad<S>}; \
+        return &e;                                                                             \
+    }
+
+}  // namespace tmpc

@@ -18,14 +18,13 @@ struct Solver;
 struct KernelEntry {
     int nx, nu, N;
     const char *name;
-    int coef_len, bounds_len;
-    void (*build_coef)(const Solver &, std::vector<float> &);
+    void (*build_coef)(const Solver &, std::vector<unsigned char> &);  // typed by Solver::precision
     void (*build_bounds)(const Solver &, std::vector<float> &);
-    hipError_t (*launch)(const AdmmParams &, hipStream_t);
+    hipError_t (*launch)(const AdmmParams &, int precision, hipStream_t);
 };
 const KernelEntry *find_quad_kernel(int nx, int nu, int N);
-hipError_t launch_generic(const AdmmParams &, hipStream_t);
-void build_generic_coef(const Solver &, std::vector<float> &);
+hipError_t launch_generic(const AdmmParams &, int precision, hipStream_t);
+void build_generic_coef(const Solver &, std::vector<unsigned char> &);
 void build_generic_bounds(const Solver &, std::vector<float> &);
 
 struct Settings {
@@ -54,7 +53,8 @@ struct Solver {
     const KernelEntry *ke = nullptr;  // nullptr: generic kernel
     std::string kernel_name;
     // device buffers
-    float *d_coef = nullptr, *d_bounds = nullptr;
+    unsigned char *d_coef = nullptr;
+    float *d_bounds = nullptr;
     float *d_x0 = nullptr, *d_xref = nullptr, *d_uref = nullptr;
     size_t xref_cap = 0, uref_cap = 0;  // floats allocated
     float *d_xout = nullptr, *d_uout = nullptr, *d_res = nullptr;
@@ -65,6 +65,9 @@ struct Solver {
     float *d_scratch = nullptr;
     size_t scratch_cap = 0;
     bool solved_once = false;
+    bool profiling = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int precision = 0;  // 0: fp64 recurrences (default), 1: all fp32
 
     int ex() const { return nx * N; }
     int eu() const { return nu * (N - 1); }
@@ -82,6 +85,7 @@ struct Solver {
     int reset();
     int solve_async(hipStream_t stream);
     int solve_status();
+    double kernel_elapsed_ms();
     int get_traj(bool states, double *buf);
     int get_status(int *iter, int *solved, double *res4);
     int get_workspace(double *d, double *y, double *g, double *v, double *z);

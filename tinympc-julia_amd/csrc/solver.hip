@@ -47,6 +47,8 @@ Solver::~Solver() {
     dev_free(d_gstat);
     if (h_gstat) (void)hipHostFree(h_gstat);
     h_gstat = nullptr;
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
 }
 
 void Solver::free_batch() {
@@ -145,7 +147,7 @@ int Solver::alloc_batch(int batch_) {
     refs_dirty = false;
     refs_device_owned = false;
     if (!ke) {
-        scratch_cap = Bn * (6 * EX + 6 * EU);
+        scratch_cap = Bn * (5 * EX + 6 * EU);
         if (dev_alloc(d_scratch, scratch_cap)) return -1;
     }
     solved_once = false;
@@ -165,7 +167,8 @@ int Solver::reset() {
 }
 
 int Solver::upload_packs() {
-    std::vector<float> coef, bnd;
+    std::vector<unsigned char> coef;
+    std::vector<float> bnd;
     if (ke) {
         ke->build_coef(*this, coef);
         ke->build_bounds(*this, bnd);
@@ -174,7 +177,7 @@ int Solver::upload_packs() {
         build_generic_bounds(*this, bnd);
     }
     if (dev_alloc(d_coef, coef.size()) || dev_alloc(d_bounds, bnd.size())) return -1;
-    HIP_TRY(hipMemcpy(d_coef, coef.data(), coef.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_coef, coef.data(), coef.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_bounds, bnd.data(), bnd.size() * sizeof(float), hipMemcpyHostToDevice));
     packs_dirty = false;
     return 0;
@@ -274,7 +277,7 @@ int Solver::solve_async(hipStream_t stream) {
     if (upload_refs()) return -1;
     AdmmParams P;
     std::memset(&P, 0, sizeof(P));
-    P.coef = d_coef;
+    P.coef = reinterpret_cast<const float *>(d_coef);
     P.bounds = d_bounds;
     P.x0 = d_x0;
     P.xref = d_xref;
@@ -304,7 +307,13 @@ int Solver::solve_async(hipStream_t stream) {
     P.nu = nu;
     P.N = N;
     HIP_TRY(hipMemsetAsync(d_gstat, 0, GSTAT_WORDS * sizeof(uint32_t), stream));
-    HIP_TRY(ke ? ke->launch(P, stream) : launch_generic(P, stream));
+    if (profiling) {
+        if (!ev0) HIP_TRY(hipEventCreate(&ev0));
+        if (!ev1) HIP_TRY(hipEventCreate(&ev1));
+        HIP_TRY(hipEventRecord(ev0, stream));
+    }
+    HIP_TRY(ke ? ke->launch(P, precision, stream) : launch_generic(P, precision, stream));
+    if (profiling) HIP_TRY(hipEventRecord(ev1, stream));
     HIP_TRY(hipMemcpyAsync(h_gstat, d_gstat, GSTAT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     solved_once = true;
     return 0;
@@ -316,6 +325,13 @@ int Solver::solve_status() {
         return -1;
     }
     return h_gstat[4] == 0 ? 0 : 1;  // admm.cpp:192 / :206 folded over the batch
+}
+
+double Solver::kernel_elapsed_ms() {
+    if (!profiling || !ev0 || !ev1) return -1.0;
+    float ms = -1.f;
+    if (hipEventElapsedTime(&ms, ev0, ev1) != hipSuccess) return -1.0;
+    return (double)ms;
 }
 
 int Solver::get_traj(bool states, double *buf) {

@@ -85,6 +85,9 @@ SIGNATURES = {
     "tinympc_set_ref_mode": (c_int, [c_vp, c_int]),
     "tinympc_solve_async": (c_int, [c_vp, c_vp]),
     "tinympc_solve_status": (c_int, [c_vp]),
+    "tinympc_set_profiling": (c_int, [c_vp, c_int]),
+    "tinympc_kernel_elapsed_ms": (c_dbl, [c_vp]),
+    "tinympc_set_precision": (c_int, [c_vp, c_int]),
     "tinympc_kernel_name": (ctypes.c_char_p, [c_vp]),
     "tinympc_algorithmic_bytes": (c_dbl, [c_vp]),
     "tinympc_algorithmic_flops": (c_dbl, [c_vp, c_int]),
@@ -476,6 +479,16 @@ class BatchSolver:
 
     def set_ref_mode(self, mode):
         self._chk(self.lib.tinympc_set_ref_mode(self.h, int(mode)), "set_ref_mode")
+
+    def set_profiling(self, on):
+        self._chk(self.lib.tinympc_set_profiling(self.h, 1 if on else 0), "set_profiling")
+
+    def kernel_elapsed_ms(self):
+        return float(self.lib.tinympc_kernel_elapsed_ms(self.h))
+
+    def set_precision(self, precision):
+        """0: fp64 recurrences (default), 1: all fp32"""
+        self._chk(self.lib.tinympc_set_precision(self.h, int(precision)), "set_precision")
 
     @property
     def kernel_name(self):
