@@ -1,0 +1,223 @@
+module TinyMPC
+
+# Julia host side of the MI355X batched TinyMPC engine.
+#
+# Keeps the surface of the reference module (reference: src/TinyMPC.jl:3-6,34-292):
+#   TinyMPCSolver / setup / set_x0 / set_x_ref / set_u_ref / set_bound_constraints /
+#   update_settings / set_cache_terms / solve / get_solution
+# and reaches the solver the same way — `ccall((:sym, libpath), Int32, ...)` by symbol name into a
+# C-ABI shared library — but the library is libtinympc_hip.so (include/tinympc_hip.h) instead of
+# libtinympc_jl built from src/bindings.cpp.  A batch dimension is added:
+#   setup(...; batch=B)
+#   set_x0(solver, x0)        x0 :: Vector (broadcast) or Matrix (nx, B)
+#   set_x_ref(solver, xref)   Matrix (nx, N) shared, or Array{Float64,3} (nx, N, B)
+#   get_solution(solver)      states (nx, N) for B == 1 (the reference's shape), else (nx, N, B)
+#   get_status(solver)        per-instance iter / solved / residuals
+#
+# NOTE: the Julia toolchain is absent from the image this repository is built and tested in, so this
+# file has not been executed there; the C-ABI it binds is exercised call-for-call by the Python
+# mirror (tinympc-julia_amd/tinympc.py) in tests/.  INTEGRATION.md shows the two-line change that
+# makes the reference's own src/TinyMPC.jl use this library without adopting this module.
+
+export TinyMPCSolver, setup, solve, get_solution, get_status, set_x0, set_x_ref, set_u_ref,
+       set_bound_constraints, set_linear_constraints, set_cone_constraints, update_settings,
+       set_cache_terms, set_batch_size, reset_workspace, print_problem_data
+
+using LinearAlgebra, Libdl, Printf
+
+const _lib = Ref{String}(joinpath(dirname(@__DIR__), "lib", "libtinympc_hip." * Libdl.dlext))
+_lib_path() = _lib[]
+set_library_path!(p::AbstractString) = (_lib[] = String(p))
+_ensure_loaded() = isfile(_lib_path()) || error("TinyMPC library not found: $(_lib_path())")
+_last_error() = unsafe_string(ccall((:tinympc_last_error, _lib_path()), Cstring, ()))
+
+mutable struct TinyMPCSolver
+    nx::Int
+    nu::Int
+    N::Int
+    batch::Int
+    rho::Float64
+    is_setup::Bool
+    A::Matrix{Float64}
+    B::Matrix{Float64}
+    Q::Matrix{Float64}
+    R::Matrix{Float64}
+    TinyMPCSolver() = new(0, 0, 0, 1, 0.0, false, zeros(0, 0), zeros(0, 0), zeros(0, 0), zeros(0, 0))
+end
+
+# ---- small helpers ---------------------------------------------------------------------------
+# every matrix crosses the boundary as (pointer, rows, cols), column-major Float64 — Julia's own layout
+_mat(a::AbstractMatrix{Float64}) = Matrix(a)
+_mat(a::AbstractVector{Float64}) = reshape(collect(a), length(a), 1)
+_mat(a::AbstractArray{Float64,3}) = reshape(Array(a), size(a, 1), size(a, 2) * size(a, 3))  # (rows, knots*batch)
+_flag(b::Bool) = Int32(b ? 1 : 0)
+_need(solver) = solver.is_setup || error("Solver not setup")
+_ok(status, what) = status == 0 ? status : error("$what ($(_last_error()))")
+
+"""
+    setup(solver, A, B, f, Q, R, rho, nx, nu, N; batch=1, kwargs...)
+
+Same call as the reference (src/TinyMPC.jl:55-112) plus `batch`.  The infinite-horizon Riccati
+precompute runs on the host in Float64 inside the library; `f` must be all zero.  Settings are then
+pushed with every `en_*` flag false, exactly like the reference (src/TinyMPC.jl:89-104).
+"""
+function setup(solver::TinyMPCSolver, A::Matrix{Float64}, B::Matrix{Float64}, f::Vector{Float64},
+               Q::Matrix{Float64}, R::Matrix{Float64}, rho::Float64, nx::Int, nu::Int, N::Int;
+               batch::Int=1, verbose::Bool=false, abs_pri_tol::Float64=1e-3, abs_dua_tol::Float64=1e-3,
+               max_iter::Int=100, check_termination::Bool=true, adaptive_rho::Bool=false,
+               adaptive_rho_min::Float64=0.1, adaptive_rho_max::Float64=10.0,
+               adaptive_rho_clipping::Bool=true)
+    _ensure_loaded()
+    solver.nx, solver.nu, solver.N, solver.rho, solver.batch = nx, nu, N, rho, batch
+    solver.A, solver.B, solver.Q, solver.R = copy(A), copy(B), copy(Q), copy(R)
+    fm = _mat(f)
+    status = ccall((:setup_solver, _lib_path()), Int32,
+                   (Ptr{Float64}, Int32, Int32, Ptr{Float64}, Int32, Int32, Ptr{Float64}, Int32, Int32,
+                    Ptr{Float64}, Int32, Int32, Ptr{Float64}, Int32, Int32, Float64, Int32, Int32, Int32, Int32),
+                   A, size(A, 1), size(A, 2), B, size(B, 1), size(B, 2), fm, size(fm, 1), size(fm, 2),
+                   Q, size(Q, 1), size(Q, 2), R, size(R, 1), size(R, 2), rho, nx, nu, N, _flag(verbose))
+    status == 0 || error("Setup failed with status: $status ($(_last_error()))")
+    batch == 1 || _ok(ccall((:set_batch_size, _lib_path()), Int32, (Int32,), batch), "Failed to set batch size")
+    solver.is_setup = true
+    update_settings(solver; abs_pri_tol=abs_pri_tol, abs_dua_tol=abs_dua_tol, max_iter=max_iter,
+                    check_termination=check_termination, adaptive_rho=adaptive_rho,
+                    adaptive_rho_min=adaptive_rho_min, adaptive_rho_max=adaptive_rho_max,
+                    adaptive_rho_enable_clipping=adaptive_rho_clipping, verbose=verbose)
+    verbose && @printf("TinyMPC solver setup successful (nx=%d, nu=%d, N=%d, batch=%d)\n", nx, nu, N, batch)
+    return status
+end
+
+function set_batch_size(solver::TinyMPCSolver, batch::Int)
+    _need(solver)
+    _ok(ccall((:set_batch_size, _lib_path()), Int32, (Int32,), batch), "Failed to set batch size")
+    solver.batch = batch
+    return 0
+end
+
+# x0: Vector (length nx, broadcast to the batch) or Matrix (nx, batch)
+function set_x0(solver::TinyMPCSolver, x0::AbstractVecOrMat{Float64}; verbose::Bool=false)
+    _need(solver)
+    m = _mat(x0)
+    _ok(ccall((:set_x0, _lib_path()), Int32, (Ptr{Float64}, Int32, Int32, Int32),
+              m, size(m, 1), size(m, 2), _flag(verbose)), "Failed to set initial state")
+end
+
+# x_ref: Matrix (nx, N) shared by the batch, or Array{Float64,3} (nx, N, batch)
+function set_x_ref(solver::TinyMPCSolver, x_ref::AbstractArray{Float64}; verbose::Bool=false)
+    _need(solver)
+    m = _mat(x_ref)
+    _ok(ccall((:set_x_ref, _lib_path()), Int32, (Ptr{Float64}, Int32, Int32, Int32),
+              m, size(m, 1), size(m, 2), _flag(verbose)), "Failed to set state reference")
+end
+
+# u_ref: Matrix (nu, N-1) shared by the batch, or Array{Float64,3} (nu, N-1, batch)
+function set_u_ref(solver::TinyMPCSolver, u_ref::AbstractArray{Float64}; verbose::Bool=false)
+    _need(solver)
+    m = _mat(u_ref)
+    _ok(ccall((:set_u_ref, _lib_path()), Int32, (Ptr{Float64}, Int32, Int32, Int32),
+              m, size(m, 1), size(m, 2), _flag(verbose)), "Failed to set input reference")
+end
+
+# Returns 0 (every instance converged), 1 (some instance hit max_iter) or -1; never throws on it,
+# like the reference (src/TinyMPC.jl:143-148).
+function solve(solver::TinyMPCSolver; verbose::Bool=false)
+    _need(solver)
+    return ccall((:solve_mpc, _lib_path()), Int32, (Int32,), _flag(verbose))
+end
+
+function get_solution(solver::TinyMPCSolver)
+    _need(solver)
+    nx, nu, N, B = solver.nx, solver.nu, solver.N, solver.batch
+    xs, us = zeros(nx * N * B), zeros(nu * (N - 1) * B)
+    xr, xc, ur, uc = Ref{Int32}(), Ref{Int32}(), Ref{Int32}(), Ref{Int32}()
+    s1 = ccall((:get_states, _lib_path()), Int32, (Ptr{Float64}, Ref{Int32}, Ref{Int32}), xs, xr, xc)
+    s2 = ccall((:get_controls, _lib_path()), Int32, (Ptr{Float64}, Ref{Int32}, Ref{Int32}), us, ur, uc)
+    (s1 != 0 || s2 != 0) && error("Failed to get solution ($(_last_error()))")
+    B == 1 && return (states=reshape(xs, nx, N), controls=reshape(us, nu, N - 1))   # the reference's shapes
+    return (states=reshape(xs, nx, N, B), controls=reshape(us, nu, N - 1, B))
+end
+
+# Per-instance iteration count, solved flag and residuals (pri_state, dua_state, pri_input, dua_input)
+function get_status(solver::TinyMPCSolver)
+    _need(solver)
+    B = solver.batch
+    iter, solved, res = zeros(Int32, B), zeros(Int32, B), zeros(4, B)
+    _ok(ccall((:get_status, _lib_path()), Int32, (Ptr{Int32}, Ptr{Int32}, Ptr{Float64}), iter, solved, res),
+        "Failed to get status")
+    return (iter=iter, solved=solved, residuals=res)
+end
+
+function reset_workspace(solver::TinyMPCSolver)
+    _need(solver)
+    _ok(ccall((:reset_workspace, _lib_path()), Int32, ()), "Failed to reset workspace")
+end
+
+# Like the reference (src/TinyMPC.jl:181-211) every field is sent with its keyword default, so a later
+# call resets en_*_bound to false and the tolerances to 1e-3.
+function update_settings(solver::TinyMPCSolver;
+                         abs_pri_tol::Float64=1e-3, abs_dua_tol::Float64=1e-3, max_iter::Int=100,
+                         check_termination::Bool=true, en_state_bound::Bool=false, en_input_bound::Bool=false,
+                         en_state_soc::Bool=false, en_input_soc::Bool=false, en_state_linear::Bool=false,
+                         en_input_linear::Bool=false, adaptive_rho::Bool=false, adaptive_rho_min::Float64=0.1,
+                         adaptive_rho_max::Float64=10.0, adaptive_rho_enable_clipping::Bool=true,
+                         verbose::Bool=false)
+    _ok(ccall((:update_settings, _lib_path()), Int32,
+              (Float64, Float64, Int32, Int32, Int32, Int32, Int32, Int32, Int32, Int32,
+               Int32, Float64, Float64, Int32, Int32),
+              abs_pri_tol, abs_dua_tol, max_iter, _flag(check_termination), _flag(en_state_bound),
+              _flag(en_input_bound), _flag(en_state_soc), _flag(en_input_soc), _flag(en_state_linear),
+              _flag(en_input_linear), _flag(adaptive_rho), adaptive_rho_min, adaptive_rho_max,
+              _flag(adaptive_rho_enable_clipping), _flag(verbose)), "Failed to update settings")
+end
+
+# per-knot bounds (nx, N) / (nu, N-1), shared by the batch; the library enables both bound flags
+function set_bound_constraints(solver::TinyMPCSolver, x_min::Matrix{Float64}, x_max::Matrix{Float64},
+                               u_min::Matrix{Float64}, u_max::Matrix{Float64}; verbose::Bool=false)
+    _ok(ccall((:set_bound_constraints, _lib_path()), Int32,
+              (Ptr{Float64}, Int32, Int32, Ptr{Float64}, Int32, Int32,
+               Ptr{Float64}, Int32, Int32, Ptr{Float64}, Int32, Int32, Int32),
+              x_min, size(x_min, 1), size(x_min, 2), x_max, size(x_max, 1), size(x_max, 2),
+              u_min, size(u_min, 1), size(u_min, 2), u_max, size(u_max, 1), size(u_max, 2), _flag(verbose)),
+        "Failed to set bound constraints")
+end
+
+# Only empty blocks are accepted: linear / cone projections live in the un-vendored TinyMPC submodule.
+function set_linear_constraints(solver::TinyMPCSolver, Alin_x::Matrix{Float64}, blin_x::Vector{Float64},
+                                Alin_u::Matrix{Float64}, blin_u::Vector{Float64}; verbose::Bool=false)
+    _ok(ccall((:set_linear_constraints, _lib_path()), Int32,
+              (Ptr{Float64}, Int32, Int32, Ptr{Float64}, Int32, Ptr{Float64}, Int32, Int32, Ptr{Float64}, Int32, Int32),
+              Alin_x, size(Alin_x, 1), size(Alin_x, 2), blin_x, length(blin_x),
+              Alin_u, size(Alin_u, 1), size(Alin_u, 2), blin_u, length(blin_u), _flag(verbose)),
+        "Failed to set linear constraints")
+end
+
+function set_cone_constraints(solver::TinyMPCSolver, Acu::Vector{Int32}, qcu::Vector{Int32}, cu::Vector{Float64},
+                              Acx::Vector{Int32}, qcx::Vector{Int32}, cx::Vector{Float64}; verbose::Bool=false)
+    _ok(ccall((:set_cone_constraints, _lib_path()), Int32,
+              (Ptr{Int32}, Int32, Ptr{Int32}, Int32, Ptr{Float64}, Int32,
+               Ptr{Int32}, Int32, Ptr{Int32}, Int32, Ptr{Float64}, Int32, Int32),
+              Acu, length(Acu), qcu, length(qcu), cu, length(cu),
+              Acx, length(Acx), qcx, length(qcx), cx, length(cx), _flag(verbose)),
+        "Failed to set cone constraints")
+end
+
+function set_cache_terms(solver::TinyMPCSolver, Kinf::Matrix{Float64}, Pinf::Matrix{Float64},
+                         Quu_inv::Matrix{Float64}, AmBKt::Matrix{Float64}; verbose::Bool=false)
+    _need(solver)
+    _ok(ccall((:set_cache_terms, _lib_path()), Int32,
+              (Ptr{Float64}, Int32, Int32, Ptr{Float64}, Int32, Int32,
+               Ptr{Float64}, Int32, Int32, Ptr{Float64}, Int32, Int32, Int32),
+              Kinf, size(Kinf, 1), size(Kinf, 2), Pinf, size(Pinf, 1), size(Pinf, 2),
+              Quu_inv, size(Quu_inv, 1), size(Quu_inv, 2), AmBKt, size(AmBKt, 1), size(AmBKt, 2), _flag(verbose)),
+        "Failed to set cache terms")
+end
+
+function print_problem_data(solver::TinyMPCSolver; verbose::Bool=false)
+    _need(solver)
+    ccall((:print_problem_data, _lib_path()), Int32, (Int32,), _flag(verbose))
+end
+
+cleanup() = try; ccall((:cleanup_solver, _lib_path()), Cvoid, ()); catch; end
+atexit(cleanup)
+
+end # module
