@@ -49,6 +49,9 @@ struct QuadShape {
     static constexpr int NXP = 4 * RX, NUP = 4 * RU;
     static constexpr int NXL = (NX + RX - 1) / RX;  // lanes of a quad owning real x rows
     static constexpr int NUL = (NU + RU - 1) / RU;  // lanes of a quad owning real u rows
+    // nu == 1: every lane of the quad carries the single input row (u, y, z, d replicated), so the
+    // input-side products need no cross-lane traffic at all; the packs hold row 0 for every role.
+    static constexpr bool UREP = (NU == 1);
     // Coefficient pack per lane role q (elements of RT); rows beyond nx/nu and columns
     // beyond nx/nu are zero.  Filled by the host (kernels.hip: build_quad_coef).
     static constexpr int O_A = 0;                 // A       rows [RX][NXP]
@@ -132,7 +135,7 @@ __device__ __forceinline__ void quad_matvec(RT (&acc)[ROWS], const CP C, const R
     });
 }
 
-template <class S, int REFS, class RT>
+template <class S, int REFS, class RT, bool XB>
 __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
     constexpr int NX = S::NX, NU = S::NU, N = S::N;
     constexpr int RX = S::RX, RU = S::RU, NXP = S::NXP, NUP = S::NUP;
@@ -141,6 +144,9 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
     constexpr bool COEF_LDS = S::template coef_in_lds<RT>();
     constexpr bool OLD_LDS = S::OLD_IN_LDS;
     constexpr int T = S::THREADS;
+    constexpr bool UREP = S::UREP;
+    // two copies of the forward sweep (with / without the residual maxima) only where the code stays small
+    constexpr bool DUAL_FWD = (RX + RU) * N <= 64;
 
     __shared__ float s_bnd[S::BOUNDS_LEN];
     __shared__ float s_ref[REFS == REF_SHARED ? S::REFS_LEN : 1];
@@ -165,7 +171,7 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
                 const int row = qq * RX + j;
                 if (row < NX) val = P.xref[k * NX + row];
             } else {
-                const int row = qq * RU + (j - RX);
+                const int row = UREP ? (j - RX) : qq * RU + (j - RX);
                 if (row < NU && k < N - 1) val = P.uref[k * NU + row];
             }
             s_ref[i] = val;
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
         }
 #pragma unroll
         for (int m = 0; m < RU; ++m) {
-            const int row = q * RU + m;
+            const int row = UREP ? m : q * RU + m;
             if (row < NU) {
 #pragma unroll
                 for (int k = 0; k < N - 1; ++k) {
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
             }
 #pragma unroll
             for (int m = 0; m < RU; ++m) {
-                const int row = q * RU + m;
+                const int row = UREP ? m : q * RU + m;
                 if (row < NU) {
 #pragma unroll
                     for (int k = 0; k < N - 1; ++k) ur[k][m] = P.uref[b * EU + k * NU + row];
@@ -326,60 +332,78 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
     const int ct = P.check_termination;
     int ct_count = ct;
 
-    for (int i = 0; i < P.max_iter; ++i) {
-        if (active && !conv) {
-            // ================= fused forward sweep =================
-            // forward_pass (admm.cpp:25-35) + update_slack (:43-59) + update_dual (:65-69)
-            // + the residual maxima of termination_condition (:93-96), knot by knot.
-            RT x[RX];
+    // Residual maxima are only needed on iterations whose termination check can matter: every
+    // check when the tolerances are positive, otherwise (a residual >= 0 is never < tol <= 0, so no
+    // instance can converge) only the last check, whose values the reference would report.
+    const bool can_converge = P.abs_pri_tol > 0.f && P.abs_dua_tol > 0.f;
+    const int last_check_it = ct > 0 ? (P.max_iter / ct) * ct : 0;
+    float pri_x = 0.f, dua_x = 0.f, pri_u = 0.f, dua_u = 0.f;
+
+    // ================= fused forward sweep =================
+    // forward_pass (admm.cpp:25-35) + update_slack (:43-59) + update_dual (:65-69)
+    // + (RES) the residual maxima of termination_condition (:93-96), knot by knot.
+    auto forward_sweep = [&](auto res_tag) {
+        constexpr bool RES = decltype(res_tag)::value;
+        RT x[RX];
 #pragma unroll
-            for (int m = 0; m < RX; ++m) x[m] = (RT)x0[m];
-            float pri_x = 0.f, dua_x = 0.f, pri_u = 0.f, dua_u = 0.f;
+        for (int m = 0; m < RX; ++m) x[m] = (RT)x0[m];
+        if constexpr (RES) pri_x = dua_x = pri_u = dua_u = 0.f;
 #pragma unroll
-            for (int k = 0; k < N; ++k) {
-                // LDS-resident constants are re-read at every knot instead of being hoisted
-                // into (and spilled from) registers for the whole solve.
-                if constexpr (COEF_LDS) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+        for (int k = 0; k < N; ++k) {
+            // LDS-resident constants are re-read at every knot instead of being hoisted
+            // into (and spilled from) registers for the whole solve.
+            if constexpr (COEF_LDS) asm volatile("" ::: "memory");
 #pragma unroll
-                for (int m = 0; m < RX; ++m) {
-                    const float xf = (float)x[m];
-                    float vn = xf + g[k][m];                                    // vnew = x + g
+            for (int m = 0; m < RX; ++m) {
+                const float xf = (float)x[m];
+                float vn = xf + g[k][m];                                        // vnew = x + g
+                if constexpr (XB)
                     vn = fminf(lb[k * 4 * S::BW + RX + m],                      // x_max.cwiseMin(
                                fmaxf(lb[k * 4 * S::BW + m], vn));               //   x_min.cwiseMax(vnew))
-                    g[k][m] = (g[k][m] + xf) - vn;                              // g = g + x - vnew
+                g[k][m] = (g[k][m] + xf) - vn;                                  // g = g + x - vnew
+                if constexpr (RES) {
                     pri_x = fmaxf(pri_x, fabsf(xf - vn));
                     dua_x = fmaxf(dua_x, fabsf(v_get(k, m) - vn));
-                    w[k][m] = vn;
                 }
-                if (k < N - 1) {
-                    RT u[RU];
+                w[k][m] = vn;
+            }
+            if (k < N - 1) {
+                RT u[RU];
 #pragma unroll
-                    for (int m = 0; m < RU; ++m) u[m] = (RT)0;
-                    quad_matvec<RU, NXL, RX, NXP>(u, cK, x);                    // Kinf x
+                for (int m = 0; m < RU; ++m) u[m] = (RT)0;
+                quad_matvec<RU, NXL, RX, NXP>(u, cK, x);                        // Kinf x
 #pragma unroll
-                    for (int m = 0; m < RU; ++m) {
-                        u[m] = -u[m] - (RT)d[k][m];                             // u = -Kinf x - d
-                        const float uf = (float)u[m];
-                        float zn = uf + y[k][m];                                // znew = u + y
-                        zn = fminf(lb[k * 4 * S::BW + 2 * RX + RU + m],
-                                   fmaxf(lb[k * 4 * S::BW + 2 * RX + m], zn));
-                        y[k][m] = (y[k][m] + uf) - zn;                          // y = y + u - znew
+                for (int m = 0; m < RU; ++m) {
+                    u[m] = -u[m] - (RT)d[k][m];                                 // u = -Kinf x - d
+                    const float uf = (float)u[m];
+                    float zn = uf + y[k][m];                                    // znew = u + y
+                    zn = fminf(lb[k * 4 * S::BW + 2 * RX + RU + m],
+                               fmaxf(lb[k * 4 * S::BW + 2 * RX + m], zn));
+                    y[k][m] = (y[k][m] + uf) - zn;                              // y = y + u - znew
+                    if constexpr (RES) {
                         pri_u = fmaxf(pri_u, fabsf(uf - zn));
                         dua_u = fmaxf(dua_u, fabsf(z_get(k, m) - zn));
-                        zw[k][m] = zn;
                     }
-                    RT xn[RX];
+                    zw[k][m] = zn;
+                }
+                RT xn[RX];
+                if constexpr (UREP) {
+#pragma unroll
+                    for (int m = 0; m < RX; ++m) xn[m] = (RT)cB[m * NUP] * u[0];  // B u, u on every lane
+                } else {
 #pragma unroll
                     for (int m = 0; m < RX; ++m) xn[m] = (RT)0;
                     quad_matvec<RX, NUL, RU, NUP>(xn, cB, u);                   // B u
-                    quad_matvec<RX, NXL, RX, NXP>(xn, cA, x);                   //   + A x
-#pragma unroll
-                    for (int m = 0; m < RX; ++m) x[m] = xn[m];
                 }
+                quad_matvec<RX, NXL, RX, NXP>(xn, cA, x);                       //   + A x
+#pragma unroll
+                for (int m = 0; m < RX; ++m) x[m] = xn[m];
             }
-            it += 1;  // admm.cpp:143
+        }
+    };
 
-            // ================= termination_condition (admm.cpp:89-107) =================
+    for (int i = 0; i < P.max_iter; ++i) {
+        if (active && !conv) {
             bool check = false;
             if (ct > 0) {
                 if (--ct_count == 0) {
@@ -387,7 +411,19 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
                     ct_count = ct;
                 }
             }
-            if (check) {
+            const bool need_res = check && (can_converge || it + 1 == last_check_it);
+            if constexpr (DUAL_FWD) {
+                if (need_res)
+                    forward_sweep(std::true_type{});
+                else
+                    forward_sweep(std::false_type{});
+            } else {
+                forward_sweep(std::true_type{});
+            }
+            it += 1;  // admm.cpp:143
+
+            // ================= termination_condition (admm.cpp:89-107) =================
+            if (need_res) {
                 res0 = quad_max(pri_x);
                 res1 = quad_max(dua_x) * rho;
                 res2 = quad_max(pri_u);
@@ -441,19 +477,27 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
                     for (int m = 0; m < RU; ++m) t[m] = r[m];
                     quad_matvec<RU, NXL, RX, NXP>(t, cBT, p);                   // B^T p_{k+1} + r_k
                     RT dn[RU];
+                    if constexpr (UREP) {
+                        dn[0] = (RT)cQI[0] * t[0];                              // d_k = Quu_inv (...)
+                    } else {
 #pragma unroll
-                    for (int m = 0; m < RU; ++m) dn[m] = (RT)0;
-                    quad_matvec<RU, NUL, RU, NUP>(dn, cQI, t);                  // d_k = Quu_inv (...)
+                        for (int m = 0; m < RU; ++m) dn[m] = (RT)0;
+                        quad_matvec<RU, NUL, RU, NUP>(dn, cQI, t);
+                    }
 #pragma unroll
                     for (int m = 0; m < RU; ++m) d[k][m] = (float)dn[m];
                     RT ap[RX], kr[RX];
 #pragma unroll
-                    for (int m = 0; m < RX; ++m) {
-                        ap[m] = qk[m];
-                        kr[m] = (RT)0;
-                    }
+                    for (int m = 0; m < RX; ++m) ap[m] = qk[m];
                     quad_matvec<RX, NXL, RX, NXP>(ap, cAT, p);                  // q_k + AmBKt p_{k+1}
-                    quad_matvec<RX, NUL, RU, NUP>(kr, cKT, r);                  // Kinf^T r_k
+                    if constexpr (UREP) {
+#pragma unroll
+                        for (int m = 0; m < RX; ++m) kr[m] = (RT)cKT[m * NUP] * r[0];  // Kinf^T r_k
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < RX; ++m) kr[m] = (RT)0;
+                        quad_matvec<RX, NUL, RU, NUP>(kr, cKT, r);
+                    }
 #pragma unroll
                     for (int m = 0; m < RX; ++m) p[m] = ap[m] - kr[m];          // admm.cpp:18
                 });

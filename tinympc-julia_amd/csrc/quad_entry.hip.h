@@ -37,7 +37,7 @@ void fill_quad_coef(const Solver &sv, std::vector<unsigned char> &out) {
             }
         }
         for (int m = 0; m < RU; ++m) {
-            const int row = q * RU + m;
+            const int row = S::UREP ? m : q * RU + m;  // UREP: every role carries input row 0
             if (row >= NU) continue;
             for (int j = 0; j < NX; ++j) {
                 put_coef<RT>(out, o + S::O_K + m * NXP + j, c.Kinf(row, j));
@@ -71,7 +71,7 @@ void build_quad_bounds(const Solver &sv, std::vector<float> &out) {
                 p[RX + m] = on ? (float)sv.x_max[row + (size_t)k * NX] : kInf;
             }
             for (int m = 0; m < RU; ++m) {
-                const int row = q * RU + m;
+                const int row = S::UREP ? m : q * RU + m;
                 const bool on = sv.st.en_input_bound && row < NU && k < N - 1;
                 p[2 * RX + m] = on ? (float)sv.u_min[row + (size_t)k * NU] : -kInf;
                 p[2 * RX + RU + m] = on ? (float)sv.u_max[row + (size_t)k * NU] : kInf;
@@ -85,33 +85,41 @@ void build_quad_bounds(const Solver &sv, std::vector<float> &out) {
             dg[q * S::DW + m] = row < NX ? (float)sv.cache.Qd[row] : 0.f;
         }
         for (int m = 0; m < RU; ++m) {
-            const int row = q * RU + m;
+            const int row = S::UREP ? m : q * RU + m;
             dg[q * S::DW + RX + m] = row < NU ? (float)sv.cache.Rd[row] : 0.f;
         }
     }
 }
 
-template <class S, class RT>
+template <class S, class RT, bool XB>
 hipError_t launch_quad_rt(const AdmmParams &P, hipStream_t stream) {
     const int grid = (P.batch + S::INST_PER_BLOCK - 1) / S::INST_PER_BLOCK;
     switch (P.ref_mode) {
         case REF_ZERO:
-            hipLaunchKernelGGL((admm_quad_kernel<S, REF_ZERO, RT>), dim3(grid), dim3(S::THREADS), 0, stream, P);
+            hipLaunchKernelGGL((admm_quad_kernel<S, REF_ZERO, RT, XB>), dim3(grid), dim3(S::THREADS), 0, stream, P);
             break;
         case REF_SHARED:
-            hipLaunchKernelGGL((admm_quad_kernel<S, REF_SHARED, RT>), dim3(grid), dim3(S::THREADS), 0, stream, P);
+            hipLaunchKernelGGL((admm_quad_kernel<S, REF_SHARED, RT, XB>), dim3(grid), dim3(S::THREADS), 0, stream,
+                               P);
             break;
         default:
-            hipLaunchKernelGGL((admm_quad_kernel<S, REF_PER_INSTANCE, RT>), dim3(grid), dim3(S::THREADS), 0,
+            hipLaunchKernelGGL((admm_quad_kernel<S, REF_PER_INSTANCE, RT, XB>), dim3(grid), dim3(S::THREADS), 0,
                                stream, P);
             break;
     }
     return hipGetLastError();
 }
 
+// state_bounds_active: false when every state bound is disabled or at/beyond +-1e17 (what
+// set_bound_constraints callers pass for "unbounded", e.g. rocket_landing_constraints.jl:36-37);
+// the projection is then the identity for any iterate below 1e17 and is compiled out.
 template <class S>
-hipError_t launch_quad(const AdmmParams &P, int precision, hipStream_t stream) {
-    return precision == 0 ? launch_quad_rt<S, double>(P, stream) : launch_quad_rt<S, float>(P, stream);
+hipError_t launch_quad(const AdmmParams &P, int precision, bool state_bounds_active, hipStream_t stream) {
+    if (precision == 0)
+        return state_bounds_active ? launch_quad_rt<S, double, true>(P, stream)
+                                   : launch_quad_rt<S, double, false>(P, stream);
+    return state_bounds_active ? launch_quad_rt<S, float, true>(P, stream)
+                               : launch_quad_rt<S, float, false>(P, stream);
 }
 
 #define TMPC_DEFINE_QUAD_ENTRY(NX, NU, NN)                                                     \

@@ -20,7 +20,7 @@ struct KernelEntry {
     const char *name;
     void (*build_coef)(const Solver &, std::vector<unsigned char> &);  // typed by Solver::precision
     void (*build_bounds)(const Solver &, std::vector<float> &);
-    hipError_t (*launch)(const AdmmParams &, int precision, hipStream_t);
+    hipError_t (*launch)(const AdmmParams &, int precision, bool state_bounds_active, hipStream_t);
 };
 const KernelEntry *find_quad_kernel(int nx, int nu, int N);
 hipError_t launch_generic(const AdmmParams &, int precision, hipStream_t);
@@ -50,6 +50,7 @@ struct Solver {
     int ref_mode = REF_ZERO;
     bool warm_start = true;
     bool packs_dirty = true;
+    bool state_bounds_active = false;  // any finite (|b| < 1e17) enabled state bound
     const KernelEntry *ke = nullptr;  // nullptr: generic kernel
     std::string kernel_name;
     // device buffers

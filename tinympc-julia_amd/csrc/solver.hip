@@ -167,6 +167,13 @@ int Solver::reset() {
 }
 
 int Solver::upload_packs() {
+    state_bounds_active = false;
+    if (st.en_state_bound)
+        for (size_t i = 0; i < x_min.size(); ++i)
+            if (x_min[i] > -1e17 || x_max[i] < 1e17) {
+                state_bounds_active = true;
+                break;
+            }
     std::vector<unsigned char> coef;
     std::vector<float> bnd;
     if (ke) {
@@ -312,7 +319,7 @@ int Solver::solve_async(hipStream_t stream) {
         if (!ev1) HIP_TRY(hipEventCreate(&ev1));
         HIP_TRY(hipEventRecord(ev0, stream));
     }
-    HIP_TRY(ke ? ke->launch(P, precision, stream) : launch_generic(P, precision, stream));
+    HIP_TRY(ke ? ke->launch(P, precision, state_bounds_active, stream) : launch_generic(P, precision, stream));
     if (profiling) HIP_TRY(hipEventRecord(ev1, stream));
     HIP_TRY(hipMemcpyAsync(h_gstat, d_gstat, GSTAT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     solved_once = true;
