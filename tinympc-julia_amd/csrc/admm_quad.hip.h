@@ -42,14 +42,16 @@
 
 namespace tmpc {
 
-template <int NX_, int NU_, int N_>
+// G = lanes per problem instance (a "group"): 4 = one DPP quad, 2 = half a quad, 1 = one lane.
+template <int NX_, int NU_, int N_, int G_ = 4>
 struct QuadShape {
-    static constexpr int NX = NX_, NU = NU_, N = N_;
-    static constexpr int RX = (NX + 3) / 4, RU = (NU + 3) / 4;
-    static constexpr int NXP = 4 * RX, NUP = 4 * RU;
-    static constexpr int NXL = (NX + RX - 1) / RX;  // lanes of a quad owning real x rows
-    static constexpr int NUL = (NU + RU - 1) / RU;  // lanes of a quad owning real u rows
-    // nu == 1: every lane of the quad carries the single input row (u, y, z, d replicated), so the
+    static_assert(G_ == 1 || G_ == 2 || G_ == 4, "group size must be 1, 2 or 4 lanes");
+    static constexpr int NX = NX_, NU = NU_, N = N_, G = G_;
+    static constexpr int RX = (NX + G - 1) / G, RU = (NU + G - 1) / G;
+    static constexpr int NXP = G * RX, NUP = G * RU;
+    static constexpr int NXL = (NX + RX - 1) / RX;  // lanes of a group owning real x rows
+    static constexpr int NUL = (NU + RU - 1) / RU;  // lanes of a group owning real u rows
+    // nu == 1: every lane of the group carries the single input row (u, y, z, d replicated), so the
     // input-side products need no cross-lane traffic at all; the packs hold row 0 for every role.
     static constexpr bool UREP = (NU == 1);
     // Coefficient pack per lane role q (elements of RT); rows beyond nx/nu and columns
@@ -65,24 +67,34 @@ struct QuadShape {
     static constexpr int CP = O_PT + RX * NXP;
     // fp32 side pack per role: diag(Q)+rho [RX], diag(R)+rho [RU]
     static constexpr int DW = RX + RU;
-    // Bounds pack: [N][4 roles][xmin[RX] xmax[RX] umin[RU] umax[RU]]
+    // Bounds pack: [N][G roles][xmin[RX] xmax[RX] umin[RU] umax[RU]]
     static constexpr int BW = 2 * RX + 2 * RU;
-    static constexpr int BOUNDS_LEN = N * 4 * BW + 4 * DW;  // + the diag pack at the end
-    // Shared-reference pack: [N][4 roles][xref[RX] uref[RU]]
+    static constexpr int BOUNDS_LEN = N * G * BW + G * DW;  // + the diag pack at the end
+    // Shared-reference pack: [N][G roles][xref[RX] uref[RU]]
     static constexpr int RW = RX + RU;
-    static constexpr int REFS_LEN = N * 4 * RW;
-    static constexpr int INST_PER_BLOCK = 64;
+    static constexpr int REFS_LEN = N * G * RW;
     static constexpr int THREADS = 256;
+    static constexpr int INST_PER_BLOCK = THREADS / G;
     // ---- storage policy ----
-    // coefficients in LDS when their register footprint would exceed ~1/4 of the VGPR file
+    // coefficients: VGPRs when small, LDS when their register footprint would exceed ~1/4 of the
+    // VGPR file; with one lane per instance (G = 1) they are wave-uniform and are read straight from
+    // memory with scalar loads instead.
+    template <class RT>
+    static constexpr int coef_regs() {
+        return CP * (int)(sizeof(RT) / 4);
+    }
     template <class RT>
     static constexpr bool coef_in_lds() {
-        return CP * (int)(sizeof(RT) / 4) > 72;
+        return G > 1 && coef_regs<RT>() > 72;
     }
-    // previous-slack arrays v, z in LDS when the register-resident state would not fit
+    // previous-slack arrays v, z in LDS when the register-resident state (+ coefficient rows) would
+    // not leave room for two wavefronts per SIMD / would not fit at all
     static constexpr int STATE_REGS = 3 * RX * N + 4 * RU * (N - 1);
-    static constexpr bool OLD_IN_LDS = STATE_REGS > 300;
-    static constexpr int OLD_LEN = OLD_IN_LDS ? (RX * N + RU * (N - 1)) * THREADS : 1;
+    template <class RT>
+    static constexpr bool old_in_lds() {
+        return STATE_REGS + ((G > 1 && !coef_in_lds<RT>()) ? coef_regs<RT>() : 0) > 230;
+    }
+    static constexpr int OLD_FLOATS = (RX * N + RU * (N - 1)) * THREADS;
 };
 
 // ---- compile-time loop, so DPP controls are integer constant expressions ----
@@ -109,40 +121,79 @@ __device__ __forceinline__ double dpp_quad(double v) {
     const int hi = dpp_quad_i<CTRL>(__double2hiint(v));
     return __hiloint2double(hi, lo);
 }
-template <int S, class T>
-__device__ __forceinline__ T qbcast(T v) {
-    return dpp_quad<S * 0x55>(v);  // quad_perm:[S,S,S,S]
+// value held by lane S of the caller's group of G lanes
+template <int G, int S, class T>
+__device__ __forceinline__ T gbcast(T v) {
+    if constexpr (G == 4)
+        return dpp_quad<S * 0x55>(v);  // quad_perm:[S,S,S,S]
+    else if constexpr (G == 2)
+        return dpp_quad<S | (S << 2) | ((2 + S) << 4) | ((2 + S) << 6)>(v);  // quad_perm:[S,S,2+S,2+S]
+    else
+        return v;
 }
-__device__ __forceinline__ float quad_max(float m) {
-    m = fmaxf(m, dpp_quad<0xB1>(m));  // quad_perm:[1,0,3,2]
-    m = fmaxf(m, dpp_quad<0x4E>(m));  // quad_perm:[2,3,0,1]
+template <int G>
+__device__ __forceinline__ float group_max(float m) {
+    if constexpr (G >= 2) m = fmaxf(m, dpp_quad<0xB1>(m));  // quad_perm:[1,0,3,2]
+    if constexpr (G == 4) m = fmaxf(m, dpp_quad<0x4E>(m));  // quad_perm:[2,3,0,1]
     return m;
 }
+// LDS image of the coefficient pack: 16-byte chunks of one role, the 4 roles of a chunk adjacent
+// (64 contiguous bytes), so the 4 distinct addresses a wavefront reads per instruction fall in
+// different banks.  (Role-major, as the pack is in HBM, puts all 4 roles on the same banks whenever
+// the per-role size is a multiple of 256 B — a 4-way conflict on every coefficient read.)
+template <class RT, int G>
+struct CoefLds {
+    static constexpr int VEC = 16 / (int)sizeof(RT);
+    const RT *base;  // s_coef + q * VEC
+    __device__ __forceinline__ static int slot(int i, int q) { return ((i / VEC) * G + q) * VEC + i % VEC; }
+    __device__ __forceinline__ RT operator[](int i) const { return base[(i / VEC) * G * VEC + i % VEC]; }
+    __device__ __forceinline__ CoefLds operator+(int off) const {
+        // offsets used are multiples of VEC (every pack section is a multiple of G rows), so chunking commutes
+        return CoefLds{base + (off / VEC) * G * VEC};
+    }
+};
 __device__ __forceinline__ float tfma(float a, float b, float c) { return fmaf(a, b, c); }
 __device__ __forceinline__ double tfma(double a, double b, double c) { return fma(a, b, c); }
 
 // acc[m] += sum_{s < SL} sum_{k < SK} C[m*CW + s*SK + k] * (src[k] of quad lane s)
-template <int ROWS, int SL, int SK, int CW, class RT, class CP>
+// Dot products longer than 6 terms are accumulated in two independent chains (source lanes 0,1 and
+// 2,3) that are added at the end: the dependent-FMA chain is what a lone wavefront waits on.
+template <int G, int ROWS, int SL, int SK, int CW, class RT, class CP>
 __device__ __forceinline__ void quad_matvec(RT (&acc)[ROWS], const CP C, const RT (&src)[SK]) {
+    constexpr bool SPLIT = (SL * SK > 6) && SL >= 3;
+    RT acc2[ROWS];
+#pragma unroll
+    for (int m = 0; m < ROWS; ++m) acc2[m] = (RT)0;
     sfor<0, SL>([&](auto s) {
         constexpr int S = decltype(s)::value;
 #pragma unroll
         for (int k = 0; k < SK; ++k) {
-            const RT xv = qbcast<S>(src[k]);
+            const RT xv = gbcast<G, S>(src[k]);
 #pragma unroll
-            for (int m = 0; m < ROWS; ++m) acc[m] = tfma((RT)C[m * CW + S * SK + k], xv, acc[m]);
+            for (int m = 0; m < ROWS; ++m) {
+                if constexpr (SPLIT && S >= 2)
+                    acc2[m] = tfma((RT)C[m * CW + S * SK + k], xv, acc2[m]);
+                else
+                    acc[m] = tfma((RT)C[m * CW + S * SK + k], xv, acc[m]);
+            }
         }
     });
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int m = 0; m < ROWS; ++m) acc[m] += acc2[m];
+    }
 }
 
 template <class S, int REFS, class RT, bool XB>
 __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
-    constexpr int NX = S::NX, NU = S::NU, N = S::N;
+    constexpr int NX = S::NX, NU = S::NU, N = S::N, G = S::G;
     constexpr int RX = S::RX, RU = S::RU, NXP = S::NXP, NUP = S::NUP;
     constexpr int NXL = S::NXL, NUL = S::NUL;
     constexpr int EX = NX * N, EU = NU * (N - 1);
     constexpr bool COEF_LDS = S::template coef_in_lds<RT>();
-    constexpr bool OLD_LDS = S::OLD_IN_LDS;
+    constexpr bool COEF_SCALAR = (G == 1);  // wave-uniform rows: scalar loads straight from memory
+    constexpr bool OLD_LDS = S::template old_in_lds<RT>();
+    constexpr int OLD_LEN = OLD_LDS ? S::OLD_FLOATS : 1;
     constexpr int T = S::THREADS;
     constexpr bool UREP = S::UREP;
     // two copies of the forward sweep (with / without the residual maxima) only where the code stays small
@@ -150,21 +201,22 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
 
     __shared__ float s_bnd[S::BOUNDS_LEN];
     __shared__ float s_ref[REFS == REF_SHARED ? S::REFS_LEN : 1];
-    __shared__ RT s_coef[COEF_LDS ? 4 * S::CP : 1];
-    __shared__ float s_old[S::OLD_LEN];
-    static_assert(sizeof(float) * (S::BOUNDS_LEN + S::REFS_LEN + S::OLD_LEN) + sizeof(RT) * 4 * S::CP <=
+    __shared__ RT s_coef[COEF_LDS ? G * S::CP : 1];
+    __shared__ float s_old[OLD_LEN];
+    static_assert(sizeof(float) * (S::BOUNDS_LEN + (REFS == REF_SHARED ? S::REFS_LEN : 1) + OLD_LEN) +
+                          sizeof(RT) * (COEF_LDS ? G * S::CP : 1) <=
                       160 * 1024,
                   "workgroup LDS budget exceeded");
 
     const int tid = threadIdx.x;
     const RT *gcoef = reinterpret_cast<const RT *>(P.coef);
     for (int i = tid; i < S::BOUNDS_LEN; i += T) s_bnd[i] = P.bounds[i];
-    if constexpr (COEF_LDS)
-        for (int i = tid; i < 4 * S::CP; i += T) s_coef[i] = gcoef[i];
+    if constexpr (COEF_LDS)  // role-major in HBM -> role-interleaved 16-byte chunks in LDS
+        for (int i = tid; i < G * S::CP; i += T) s_coef[CoefLds<RT, G>::slot(i % S::CP, i / S::CP)] = gcoef[i];
     if constexpr (REFS == REF_SHARED) {
-        // pack [N][4][xref[RX] uref[RU]] from knot-major xref [N][nx], uref [N-1][nu]
+        // pack [N][G][xref[RX] uref[RU]] from knot-major xref [N][nx], uref [N-1][nu]
         for (int i = tid; i < S::REFS_LEN; i += T) {
-            const int k = i / (4 * S::RW), rem = i % (4 * S::RW);
+            const int k = i / (G * S::RW), rem = i % (G * S::RW);
             const int qq = rem / S::RW, j = rem % S::RW;
             float val = 0.f;
             if (j < RX) {
@@ -179,27 +231,29 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
     }
     __syncthreads();
 
-    const int q = tid & 3;
-    const long b = (long)blockIdx.x * S::INST_PER_BLOCK + (tid >> 2);
+    const int q = tid & (G - 1);
+    const long b = (long)blockIdx.x * S::INST_PER_BLOCK + tid / G;
     const bool active = b < P.batch;
     const float *lb = s_bnd + q * S::BW;
     const float *lr = s_ref + q * S::RW;
-    const float *ld = s_bnd + N * 4 * S::BW + q * S::DW;  // diag(Q)+rho, diag(R)+rho
+    const float *ld = s_bnd + N * G * S::BW + q * S::DW;  // diag(Q)+rho, diag(R)+rho
 
-    // ---- per-lane coefficient rows: registers, or LDS for the big shapes ----
-    RT rcoef[COEF_LDS ? 1 : S::CP];
-    const RT *cbase;
+    // ---- per-lane coefficient rows: VGPRs, LDS (big shapes) or scalar loads (G = 1) ----
+    RT rcoef[(COEF_LDS || COEF_SCALAR) ? 1 : S::CP];
+    using CPtr = std::conditional_t<COEF_LDS, CoefLds<RT, G>, const RT *>;
+    CPtr cbase;
     if constexpr (COEF_LDS) {
-        cbase = s_coef + q * S::CP;
+        cbase = CoefLds<RT, G>{s_coef + q * CoefLds<RT, G>::VEC};
+    } else if constexpr (COEF_SCALAR) {
+        cbase = gcoef;
     } else {
         const RT *cp = gcoef + q * S::CP;
 #pragma unroll
         for (int i = 0; i < S::CP; ++i) rcoef[i] = cp[i];
         cbase = rcoef;
     }
-    const RT *cA = cbase + S::O_A, *cAT = cbase + S::O_AT, *cK = cbase + S::O_K, *cB = cbase + S::O_B,
-             *cBT = cbase + S::O_BT, *cKT = cbase + S::O_KT, *cQI = cbase + S::O_QI,
-             *cPT = cbase + S::O_PT;
+    const CPtr cA = cbase + S::O_A, cAT = cbase + S::O_AT, cK = cbase + S::O_K, cB = cbase + S::O_B,
+               cBT = cbase + S::O_BT, cKT = cbase + S::O_KT, cQI = cbase + S::O_QI, cPT = cbase + S::O_PT;
     float cQD[RX], cRD[RU];
 #pragma unroll
     for (int m = 0; m < RX; ++m) cQD[m] = ld[m];
@@ -307,13 +361,13 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
 
     auto ref_x = [&](auto kk, int m) -> float {
         constexpr int K = decltype(kk)::value;
-        if constexpr (REFS == REF_SHARED) return lr[K * 4 * S::RW + m];
+        if constexpr (REFS == REF_SHARED) return lr[K * G * S::RW + m];
         else if constexpr (REFS == REF_PER_INSTANCE) return xr[K][m];
         else return 0.f;
     };
     auto ref_u = [&](auto kk, int m) -> float {
         constexpr int K = decltype(kk)::value;
-        if constexpr (REFS == REF_SHARED) return lr[K * 4 * S::RW + RX + m];
+        if constexpr (REFS == REF_SHARED) return lr[K * G * S::RW + RX + m];
         else if constexpr (REFS == REF_PER_INSTANCE) return ur[K][m];
         else return 0.f;
     };
@@ -352,14 +406,14 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
         for (int k = 0; k < N; ++k) {
             // LDS-resident constants are re-read at every knot instead of being hoisted
             // into (and spilled from) registers for the whole solve.
-            if constexpr (COEF_LDS) asm volatile("" ::: "memory");
+            if constexpr (COEF_LDS || COEF_SCALAR) asm volatile("" ::: "memory");
 #pragma unroll
             for (int m = 0; m < RX; ++m) {
                 const float xf = (float)x[m];
                 float vn = xf + g[k][m];                                        // vnew = x + g
                 if constexpr (XB)
-                    vn = fminf(lb[k * 4 * S::BW + RX + m],                      // x_max.cwiseMin(
-                               fmaxf(lb[k * 4 * S::BW + m], vn));               //   x_min.cwiseMax(vnew))
+                    vn = fminf(lb[k * G * S::BW + RX + m],                      // x_max.cwiseMin(
+                               fmaxf(lb[k * G * S::BW + m], vn));               //   x_min.cwiseMax(vnew))
                 g[k][m] = (g[k][m] + xf) - vn;                                  // g = g + x - vnew
                 if constexpr (RES) {
                     pri_x = fmaxf(pri_x, fabsf(xf - vn));
@@ -368,17 +422,20 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
                 w[k][m] = vn;
             }
             if (k < N - 1) {
-                RT u[RU];
+                RT u[RU], xn[RX];
 #pragma unroll
                 for (int m = 0; m < RU; ++m) u[m] = (RT)0;
-                quad_matvec<RU, NXL, RX, NXP>(u, cK, x);                        // Kinf x
+#pragma unroll
+                for (int m = 0; m < RX; ++m) xn[m] = (RT)0;
+                quad_matvec<G, RU, NXL, RX, NXP>(u, cK, x);                        // Kinf x
+                quad_matvec<G, RX, NXL, RX, NXP>(xn, cA, x);                       // A x
 #pragma unroll
                 for (int m = 0; m < RU; ++m) {
                     u[m] = -u[m] - (RT)d[k][m];                                 // u = -Kinf x - d
                     const float uf = (float)u[m];
                     float zn = uf + y[k][m];                                    // znew = u + y
-                    zn = fminf(lb[k * 4 * S::BW + 2 * RX + RU + m],
-                               fmaxf(lb[k * 4 * S::BW + 2 * RX + m], zn));
+                    zn = fminf(lb[k * G * S::BW + 2 * RX + RU + m],
+                               fmaxf(lb[k * G * S::BW + 2 * RX + m], zn));
                     y[k][m] = (y[k][m] + uf) - zn;                              // y = y + u - znew
                     if constexpr (RES) {
                         pri_u = fmaxf(pri_u, fabsf(uf - zn));
@@ -386,16 +443,13 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
                     }
                     zw[k][m] = zn;
                 }
-                RT xn[RX];
+                // A x does not wait for u: both mat-vecs of x issue side by side, B u joins last
                 if constexpr (UREP) {
 #pragma unroll
-                    for (int m = 0; m < RX; ++m) xn[m] = (RT)cB[m * NUP] * u[0];  // B u, u on every lane
+                    for (int m = 0; m < RX; ++m) xn[m] = tfma((RT)cB[m * NUP], u[0], xn[m]);  // + B u
                 } else {
-#pragma unroll
-                    for (int m = 0; m < RX; ++m) xn[m] = (RT)0;
-                    quad_matvec<RX, NUL, RU, NUP>(xn, cB, u);                   // B u
+                    quad_matvec<G, RX, NUL, RU, NUP>(xn, cB, u);                   // + B u
                 }
-                quad_matvec<RX, NXL, RX, NXP>(xn, cA, x);                       //   + A x
 #pragma unroll
                 for (int m = 0; m < RX; ++m) x[m] = xn[m];
             }
@@ -424,10 +478,10 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
 
             // ================= termination_condition (admm.cpp:89-107) =================
             if (need_res) {
-                res0 = quad_max(pri_x);
-                res1 = quad_max(dua_x) * rho;
-                res2 = quad_max(pri_u);
-                res3 = quad_max(dua_u) * rho;
+                res0 = group_max<G>(pri_x);
+                res1 = group_max<G>(dua_x) * rho;
+                res2 = group_max<G>(pri_u);
+                res3 = group_max<G>(dua_u) * rho;
                 if (res0 < P.abs_pri_tol && res2 < P.abs_pri_tol && res1 < P.abs_dua_tol &&
                     res3 < P.abs_dua_tol)
                     conv = 1;
@@ -445,7 +499,7 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
                         RT xrl[RX];
 #pragma unroll
                         for (int m = 0; m < RX; ++m) xrl[m] = (RT)ref_x(std::integral_constant<int, N - 1>{}, m);
-                        quad_matvec<RX, NXL, RX, NXP>(acc, cPT, xrl);           // (Xref_{N-1}^T Pinf)^T
+                        quad_matvec<G, RX, NXL, RX, NXP>(acc, cPT, xrl);           // (Xref_{N-1}^T Pinf)^T
                     }
 #pragma unroll
                     for (int m = 0; m < RX; ++m) {
@@ -456,7 +510,7 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
                 sfor<0, N - 1>([&](auto kk) {
                     constexpr int k = N - 2 - decltype(kk)::value;
                     constexpr std::integral_constant<int, k> kc{};
-                    if constexpr (COEF_LDS) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+                    if constexpr (COEF_LDS || COEF_SCALAR) asm volatile("" ::: "memory");
                     RT r[RU], qk[RX];
 #pragma unroll
                     for (int m = 0; m < RU; ++m) {
@@ -475,28 +529,28 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
                     RT t[RU];
 #pragma unroll
                     for (int m = 0; m < RU; ++m) t[m] = r[m];
-                    quad_matvec<RU, NXL, RX, NXP>(t, cBT, p);                   // B^T p_{k+1} + r_k
+                    quad_matvec<G, RU, NXL, RX, NXP>(t, cBT, p);                   // B^T p_{k+1} + r_k
                     RT dn[RU];
                     if constexpr (UREP) {
                         dn[0] = (RT)cQI[0] * t[0];                              // d_k = Quu_inv (...)
                     } else {
 #pragma unroll
                         for (int m = 0; m < RU; ++m) dn[m] = (RT)0;
-                        quad_matvec<RU, NUL, RU, NUP>(dn, cQI, t);
+                        quad_matvec<G, RU, NUL, RU, NUP>(dn, cQI, t);
                     }
 #pragma unroll
                     for (int m = 0; m < RU; ++m) d[k][m] = (float)dn[m];
                     RT ap[RX], kr[RX];
 #pragma unroll
                     for (int m = 0; m < RX; ++m) ap[m] = qk[m];
-                    quad_matvec<RX, NXL, RX, NXP>(ap, cAT, p);                  // q_k + AmBKt p_{k+1}
+                    quad_matvec<G, RX, NXL, RX, NXP>(ap, cAT, p);                  // q_k + AmBKt p_{k+1}
                     if constexpr (UREP) {
 #pragma unroll
                         for (int m = 0; m < RX; ++m) kr[m] = (RT)cKT[m * NUP] * r[0];  // Kinf^T r_k
                     } else {
 #pragma unroll
                         for (int m = 0; m < RX; ++m) kr[m] = (RT)0;
-                        quad_matvec<RX, NUL, RU, NUP>(kr, cKT, r);
+                        quad_matvec<G, RX, NUL, RU, NUP>(kr, cKT, r);
                     }
 #pragma unroll
                     for (int m = 0; m < RX; ++m) p[m] = ap[m] - kr[m];          // admm.cpp:18
@@ -565,7 +619,7 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
         float m0 = active ? res0 : 0.f, m1 = active ? res1 : 0.f, m2 = active ? res2 : 0.f,
               m3 = active ? res3 : 0.f;
 #pragma unroll
-        for (int off = 4; off < 64; off <<= 1) {
+        for (int off = G; off < 64; off <<= 1) {
             m0 = fmaxf(m0, __shfl_xor(m0, off, 64));
             m1 = fmaxf(m1, __shfl_xor(m1, off, 64));
             m2 = fmaxf(m2, __shfl_xor(m2, off, 64));

@@ -10,21 +10,22 @@ namespace tmpc {
 // Shapes with a specialised kernel: the BASELINE.json configs plus the shapes the
 // reference's own tests/examples use (tests/test_basic.jl N=10, test_settings.jl N=2,
 // examples/*: cartpole N=20, quadrotor N=20, rocket N=10).
-const KernelEntry *quad_entry_4_1_20();
-const KernelEntry *quad_entry_4_1_10();
-const KernelEntry *quad_entry_4_1_2();
-const KernelEntry *quad_entry_12_4_30();
-const KernelEntry *quad_entry_12_4_20();
-const KernelEntry *quad_entry_6_3_10();
-const KernelEntry *quad_entry_6_3_50();
+// Table order = preference: the first entry matching (nx, nu, N) is the shape's default variant.
+#define TMPC_ENTRY(NX, NU, NN, GG) const KernelEntry *quad_entry_##NX##_##NU##_##NN##_g##GG();
+TMPC_ENTRY(4, 1, 20, 4) TMPC_ENTRY(4, 1, 20, 2) TMPC_ENTRY(4, 1, 20, 1)
+TMPC_ENTRY(4, 1, 10, 4) TMPC_ENTRY(4, 1, 10, 2) TMPC_ENTRY(4, 1, 2, 4)
+TMPC_ENTRY(12, 4, 30, 4) TMPC_ENTRY(12, 4, 20, 4)
+TMPC_ENTRY(6, 3, 10, 4) TMPC_ENTRY(6, 3, 10, 2) TMPC_ENTRY(6, 3, 50, 4)
+#undef TMPC_ENTRY
 
-const KernelEntry *find_quad_kernel(int nx, int nu, int N) {
+const KernelEntry *find_quad_kernel(int nx, int nu, int N, int group) {
     static const KernelEntry *const table[] = {
-        quad_entry_4_1_20(),  quad_entry_4_1_10(), quad_entry_4_1_2(),  quad_entry_12_4_30(),
-        quad_entry_12_4_20(), quad_entry_6_3_10(), quad_entry_6_3_50(),
+        quad_entry_4_1_20_g2(),  quad_entry_4_1_20_g4(),  quad_entry_4_1_20_g1(), quad_entry_4_1_10_g2(),
+        quad_entry_4_1_10_g4(),  quad_entry_4_1_2_g4(),   quad_entry_12_4_30_g4(), quad_entry_12_4_20_g4(),
+        quad_entry_6_3_10_g4(),  quad_entry_6_3_10_g2(),  quad_entry_6_3_50_g4(),
     };
     for (const KernelEntry *e : table)
-        if (e->nx == nx && e->nu == nu && e->N == N) return e;
+        if (e->nx == nx && e->nu == nu && e->N == N && (group < 0 || e->G == group)) return e;
     return nullptr;
 }
 

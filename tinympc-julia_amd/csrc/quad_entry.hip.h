@@ -19,9 +19,9 @@ inline void put_coef(std::vector<unsigned char> &out, size_t idx, double val) {
 template <class S, class RT>
 void fill_quad_coef(const Solver &sv, std::vector<unsigned char> &out) {
     constexpr int NX = S::NX, NU = S::NU, RX = S::RX, RU = S::RU, NXP = S::NXP, NUP = S::NUP;
-    out.assign((size_t)4 * S::CP * sizeof(RT), 0);
+    out.assign((size_t)S::G * S::CP * sizeof(RT), 0);
     const Cache &c = sv.cache;
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < S::G; ++q) {
         const size_t o = (size_t)q * S::CP;
         for (int m = 0; m < RX; ++m) {
             const int row = q * RX + m;
@@ -62,8 +62,8 @@ void build_quad_bounds(const Solver &sv, std::vector<float> &out) {
     constexpr int NX = S::NX, NU = S::NU, N = S::N, RX = S::RX, RU = S::RU, BW = S::BW;
     out.assign((size_t)S::BOUNDS_LEN, 0.f);
     for (int k = 0; k < N; ++k)
-        for (int q = 0; q < 4; ++q) {
-            float *p = out.data() + ((size_t)k * 4 + q) * BW;
+        for (int q = 0; q < S::G; ++q) {
+            float *p = out.data() + ((size_t)k * S::G + q) * BW;
             for (int m = 0; m < RX; ++m) {
                 const int row = q * RX + m;
                 const bool on = sv.st.en_state_bound && row < NX;
@@ -78,8 +78,8 @@ void build_quad_bounds(const Solver &sv, std::vector<float> &out) {
             }
         }
     // diag(Q)+rho, diag(R)+rho per role (tiny_api.cpp:90-91)
-    float *dg = out.data() + (size_t)N * 4 * BW;
-    for (int q = 0; q < 4; ++q) {
+    float *dg = out.data() + (size_t)N * S::G * BW;
+    for (int q = 0; q < S::G; ++q) {
         for (int m = 0; m < RX; ++m) {
             const int row = q * RX + m;
             dg[q * S::DW + m] = row < NX ? (float)sv.cache.Qd[row] : 0.f;
@@ -122,10 +122,10 @@ hipError_t launch_quad(const AdmmParams &P, int precision, bool state_bounds_act
                                : launch_quad_rt<S, float, false>(P, stream);
 }
 
-#define TMPC_DEFINE_QUAD_ENTRY(NX, NU, NN)                                                     \
-    const KernelEntry *quad_entry_##NX##_##NU##_##NN() {                                       \
-        using S = QuadShape<NX, NU, NN>;                                                       \
-        static const KernelEntry e = {NX, NU, NN, "quad<" #NX "," #NU "," #NN ">",            \
+#define TMPC_DEFINE_QUAD_ENTRY(NX, NU, NN, GG)                                                 \
+    const KernelEntry *quad_entry_##NX##_##NU##_##NN##_g##GG() {                               \
+        using S = QuadShape<NX, NU, NN, GG>;                                                   \
+        static const KernelEntry e = {NX, NU, NN, GG, "quad<" #NX "," #NU "," #NN ",g" #GG ">", \
                                       &build_quad_coef<S>, &build_quad_bounds<S>, &launch_quad<S>}; \
         return &e;                                                                             \
     }

@@ -16,13 +16,14 @@ struct Solver;
 
 // One specialised quad-kernel instantiation (admm_quad.hip.h) and its pack builders.
 struct KernelEntry {
-    int nx, nu, N;
+    int nx, nu, N, G;  // G = lanes per instance
     const char *name;
     void (*build_coef)(const Solver &, std::vector<unsigned char> &);  // typed by Solver::precision
     void (*build_bounds)(const Solver &, std::vector<float> &);
     hipError_t (*launch)(const AdmmParams &, int precision, bool state_bounds_active, hipStream_t);
 };
-const KernelEntry *find_quad_kernel(int nx, int nu, int N);
+// group < 0: the shape's default group size; otherwise that exact variant (nullptr if not built)
+const KernelEntry *find_quad_kernel(int nx, int nu, int N, int group = -1);
 hipError_t launch_generic(const AdmmParams &, int precision, hipStream_t);
 void build_generic_coef(const Solver &, std::vector<unsigned char> &);
 void build_generic_bounds(const Solver &, std::vector<float> &);

@@ -3,6 +3,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 
@@ -102,7 +103,12 @@ int Solver::init(const double *A_, const double *B_, const double *Q_, const dou
     x_max.assign((size_t)ex(), 1e17);
     u_min.assign((size_t)eu(), -1e17);
     u_max.assign((size_t)eu(), 1e17);
-    ke = find_quad_kernel(nx, nu, N);
+    {
+        // TINYMPC_HIP_GROUP=1|2|4 picks a non-default lanes-per-instance variant (tuning aid)
+        const char *genv = std::getenv("TINYMPC_HIP_GROUP");
+        ke = find_quad_kernel(nx, nu, N, genv ? std::atoi(genv) : -1);
+        if (!ke) ke = find_quad_kernel(nx, nu, N);
+    }
     if (!ke && (nx > GEN_MAX_NX || nu > GEN_MAX_NU)) {
         set_error("problem shape exceeds the generic kernel limits (nx <= 64, nu <= 32)");
         return -1;
