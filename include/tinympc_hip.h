@@ -148,6 +148,16 @@ int tinympc_set_ref_mode(tinympc_solver *s, int ref_mode);
 int tinympc_solve_async(tinympc_solver *s, void *hip_stream);
 /* After the stream has been synchronised: 0 all converged / 1 otherwise (reads gstat). */
 int tinympc_solve_status(tinympc_solver *s);
+/* Fused closed loop (the caller pattern of examples/cartpole_example_mpc.jl:35-51):
+ * `steps` repetitions of  solve -> u0 = controls[:,0] -> x0 = A x0 + B u0 -> set_x0  in ONE launch,
+ * the warm-start workspace staying on chip between steps.  Needs warm-start mode and a specialised
+ * kernel for the shape.  Synchronous; returns the solve status of the LAST step (0/1) or -1.
+ * Afterwards x0 holds the plant state after the last step and get_states/get_controls/get_status
+ * describe the last solve.  Logs, instance-major: x [batch][steps][nx] (plant state after each
+ * step), u [batch][steps][nu] (control applied), iter [batch][steps] (ADMM iterations of the step,
+ * negated when the step hit max_iter).  Any log pointer may be NULL. */
+int tinympc_mpc_rollout(tinympc_solver *s, int steps, void *hip_stream);
+int tinympc_get_mpc_log(tinympc_solver *s, double *x, double *u, int *iter);
 /* Kernel timing: when enabled, every solve records HIP events immediately around the ADMM kernel
  * launch on the launch stream; tinympc_kernel_elapsed_ms returns the last kernel's duration
  * (call after the stream has been synchronised; < 0 if unavailable). */

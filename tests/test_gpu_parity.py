@@ -444,3 +444,81 @@ def test_set_cache_terms(hip_lib, oracle_built):
     assert nrel(sol["states"][:, :, 0], r["x"]) <= FP32_TOL
     assert nrel(sol["controls"][:, :, 0], r["u"]) <= FP32_TOL
     bs.close()
+
+
+@pytest.mark.parametrize("name", ["G5_cartpole_mpc_warm", "G5b_cartpole_mpc_warm_bounded"])
+def test_fused_mpc_rollout_vs_golden(hip_lib, name):
+    """the closed loop solve -> u0 -> x+ = A x + B u0 -> set_x0 fused into one launch,
+    against the reference's own loop (examples/cartpole_example_mpc.jl:35-51, fixture G5)."""
+    g = load_golden(name)
+    prob = problem_of(g)
+    steps = len(g["steps"])
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=1)
+    bs.update_settings(**g["settings"])
+    if prob.has_bounds():
+        bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    bs.set_x0(np.array(g["x0"]))
+    log = bs.mpc_rollout(steps)
+    assert log["status"] == g["steps"][-1]["status"]
+    for k, step in enumerate(g["steps"]):
+        assert int(log["iter"][k, 0]) == step["iter"], f"step {k}"
+        assert int(log["solved"][k, 0]) == step["solved"]
+        u0 = np.array(step["u"][: prob.nu])
+        assert np.abs(log["u"][:, k, 0] - u0).max() <= 2e-5 * max(1.0, np.abs(np.array(step["u"])).max())
+        if k + 1 < steps:
+            xn = np.array(g["steps"][k + 1]["x0"])
+            assert np.abs(log["x"][:, k, 0] - xn).max() <= 2e-5 * max(1.0, np.abs(xn).max())
+    # the last solve is what get_solution / get_workspace describe
+    sol = bs.get_solution()
+    _check_instance(sol["states"][:, :, 0], sol["controls"][:, :, 0], g["steps"][-1], prob.nx, prob.nu, prob.N, tol=5e-5)
+    bs.close()
+
+
+def test_fused_mpc_rollout_batch_vs_oracle(hip_lib, oracle_built):
+    """A batch of closed loops (different x0 per instance, input bound active early on) against the
+    fp64 oracle driven step by step on the host."""
+    B, steps = 24, 15
+    prob = t.problems.cartpole(20, u_bound=0.8)
+    x0 = t.problems.cartpole_x0(B, seed=31)
+    kw = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=10, check_termination=1)
+    ref_u = np.zeros((1, steps, B))
+    ref_x = np.zeros((4, steps, B))
+    ref_it = np.zeros((steps, B), dtype=int)
+    for b in range(B):
+        o = oracle_built.CpuSolver("orc64", prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N)
+        o.update_settings(**kw)
+        o.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        x = x0[:, b].copy()
+        for k in range(steps):
+            o.set_x0(x)
+            o.solve()
+            r = o.get_solution()
+            x = prob.A @ x + prob.B @ r["u"][:, 0]
+            ref_u[:, k, b], ref_x[:, k, b], ref_it[k, b] = r["u"][:, 0], x, r["iter"]
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+    bs.update_settings(**kw)
+    bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    bs.set_x0(x0)
+    log = bs.mpc_rollout(steps)
+    # iteration counts decide the trajectory; allow a rare +-1 near the tolerance, then compare the rest
+    same = np.all(log["iter"] == ref_it, axis=0)
+    assert same.mean() >= 0.9
+    assert np.abs(log["u"][:, :, same] - ref_u[:, :, same]).max() <= 3e-5 * np.abs(ref_u).max()
+    assert np.abs(log["x"][:, :, same] - ref_x[:, :, same]).max() <= 3e-5 * np.abs(ref_x).max()
+    # same thing as `steps` separate launches with the host applying the model in between
+    bs2 = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+    bs2.update_settings(**kw)
+    bs2.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    x = x0.copy()
+    for k in range(steps):
+        bs2.set_x0(x)
+        bs2.solve()
+        u0 = bs2.get_solution()["controls"][:, 0, :]
+        x = prob.A @ x + prob.B @ u0
+        assert np.abs(u0 - log["u"][:, k, :])[:, same].max() <= 3e-5 * np.abs(ref_u).max()
+    # generic-path shapes refuse the fused loop instead of silently doing something else
+    pg = t.problems.cartpole(15, u_bound=0.5)
+    bg = t.BatchSolver(pg.A, pg.B, pg.Q, pg.R, pg.rho, pg.N, batch=2)
+    with pytest.raises(t.TinyMPCError):
+        bg.mpc_rollout(3)
+    bs.close(); bs2.close(); bg.close()

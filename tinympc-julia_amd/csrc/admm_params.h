@@ -49,6 +49,12 @@ struct AdmmParams {
     int save_state;  // 1: write sd..sv back at exit
     float abs_pri_tol, abs_dua_tol, rho;
     int nx, nu, N;  // generic kernel only
+    // fused closed loop (0 = plain solve): steps per launch and per-step logs
+    int mpc_steps;
+    float *mpc_x;    // [B][steps][nx]  plant state after each step
+    float *mpc_u;    // [B][steps][nu]  control applied at each step
+    int *mpc_iter;   // [B][steps]      ADMM iterations of each step, negative if it hit max_iter
+    float *x0_out;   // [B][nx]         plant state after the last step (aliases x0)
 };
 
 }  // namespace tmpc

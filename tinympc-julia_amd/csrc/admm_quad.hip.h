@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
                   "workgroup LDS budget exceeded");
 
     const int tid = threadIdx.x;
-    const RT *gcoef = reinterpret_cast<const RT *>(P.coef);
+    const RT *__restrict__ gcoef = reinterpret_cast<const RT *>(P.coef);
     for (int i = tid; i < S::BOUNDS_LEN; i += T) s_bnd[i] = P.bounds[i];
     if constexpr (COEF_LDS)  // role-major in HBM -> role-interleaved 16-byte chunks in LDS
         for (int i = tid; i < G * S::CP; i += T) s_coef[CoefLds<RT, G>::slot(i % S::CP, i / S::CP)] = gcoef[i];
@@ -283,14 +283,14 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
         if constexpr (OLD_LDS) lz[(k * RU + m) * T] = val;
         else zreg[k][m] = val;
     };
-    float x0[RX];
+    RT x0[RX];  // plant state; RT so a fused closed loop does not round it to fp32 every step
     float xr[REFS == REF_PER_INSTANCE ? N : 1][RX];
     float ur[REFS == REF_PER_INSTANCE ? N - 1 : 1][RU];
 
 #pragma unroll
     for (int m = 0; m < RX; ++m) {
         const int row = q * RX + m;
-        x0[m] = (active && row < NX) ? P.x0[b * NX + row] : 0.f;
+        x0[m] = (active && row < NX) ? (RT)P.x0[b * NX + row] : (RT)0;
     }
     const bool warm = active && !P.cold_start;
     // cold start = the zero workspace tiny_setup leaves (tiny_api.cpp:73-88)
@@ -400,13 +400,13 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
         constexpr bool RES = decltype(res_tag)::value;
         RT x[RX];
 #pragma unroll
-        for (int m = 0; m < RX; ++m) x[m] = (RT)x0[m];
+        for (int m = 0; m < RX; ++m) x[m] = x0[m];
         if constexpr (RES) pri_x = dua_x = pri_u = dua_u = 0.f;
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             // LDS-resident constants are re-read at every knot instead of being hoisted
             // into (and spilled from) registers for the whole solve.
-            if constexpr (COEF_LDS || COEF_SCALAR) asm volatile("" ::: "memory");
+            if constexpr (COEF_LDS) asm volatile("" ::: "memory");
 #pragma unroll
             for (int m = 0; m < RX; ++m) {
                 const float xf = (float)x[m];
@@ -456,6 +456,16 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
         }
     };
 
+    // Closed loop (examples/cartpole_example_mpc.jl:35-51): mpc_steps > 1 repeats
+    //   solve -> u0 = controls[:,0] -> x0 = A x0 + B u0 -> set_x0
+    // inside the launch, the warm-start workspace never leaving the registers.
+    const int n_steps = P.mpc_steps > 1 ? P.mpc_steps : 1;
+    for (int step = 0; step < n_steps; ++step) {
+    if (step > 0) {  // solve() entry: only the counters are reset (admm.cpp:112-115)
+        it = 0;
+        conv = 0;
+        ct_count = ct;
+    }
     for (int i = 0; i < P.max_iter; ++i) {
         if (active && !conv) {
             bool check = false;
@@ -510,7 +520,7 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
                 sfor<0, N - 1>([&](auto kk) {
                     constexpr int k = N - 2 - decltype(kk)::value;
                     constexpr std::integral_constant<int, k> kc{};
-                    if constexpr (COEF_LDS || COEF_SCALAR) asm volatile("" ::: "memory");
+                    if constexpr (COEF_LDS) asm volatile("" ::: "memory");
                     RT r[RU], qk[RX];
 #pragma unroll
                     for (int m = 0; m < RU; ++m) {
@@ -560,6 +570,38 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
         // every instance of this wavefront finished?  (wave-uniform exit)
         if (!__builtin_amdgcn_ballot_w64(active && !conv)) break;
     }
+    if (P.mpc_steps > 0) {
+        // apply the first control to the plant model and log the step
+        RT u0[RU], xn[RX];
+#pragma unroll
+        for (int m = 0; m < RU; ++m) u0[m] = (RT)zw[0][m];
+#pragma unroll
+        for (int m = 0; m < RX; ++m) xn[m] = (RT)0;
+        quad_matvec<G, RX, NXL, RX, NXP>(xn, cA, x0);
+        if constexpr (UREP) {
+#pragma unroll
+            for (int m = 0; m < RX; ++m) xn[m] = tfma((RT)cB[m * NUP], u0[0], xn[m]);
+        } else {
+            quad_matvec<G, RX, NUL, RU, NUP>(xn, cB, u0);
+        }
+#pragma unroll
+        for (int m = 0; m < RX; ++m) x0[m] = xn[m];
+        if (active) {
+            const long so = (b * n_steps + step);
+#pragma unroll
+            for (int m = 0; m < RX; ++m) {
+                const int row = q * RX + m;
+                if (row < NX) P.mpc_x[so * NX + row] = (float)x0[m];
+            }
+#pragma unroll
+            for (int m = 0; m < RU; ++m) {
+                const int row = q * RU + m;
+                if (row < NU) P.mpc_u[so * NU + row] = zw[0][m];
+            }
+            if (q == 0) P.mpc_iter[so] = conv ? it : -it;  // sign carries the solved flag
+        }
+    }
+    }  // mpc step
 
     // ================= epilogue: solution, status, warm-start state =================
     if (active) {
@@ -578,6 +620,13 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
             if (row < NU) {
 #pragma unroll
                 for (int k = 0; k < N - 1; ++k) P.uout[b * EU + k * NU + row] = zw[k][m];
+            }
+        }
+        if (P.mpc_steps > 0) {
+#pragma unroll
+            for (int m = 0; m < RX; ++m) {
+                const int row = q * RX + m;
+                if (row < NX) P.x0_out[b * NX + row] = (float)x0[m];
             }
         }
         if (q == 0) {

@@ -153,6 +153,18 @@ int tinympc_solve_async(tinympc_solver *s, void *hip_stream) {
 }
 int tinympc_solve_status(tinympc_solver *s) { return s ? s->s.solve_status() : -1; }
 
+int tinympc_mpc_rollout(tinympc_solver *s, int steps, void *hip_stream) {
+    if (!s || steps < 1) return -1;
+    return guarded("mpc_rollout", [&]() -> int {
+        if (s->s.solve_async((hipStream_t)hip_stream, steps)) return -1;
+        return sync_status(s, (hipStream_t)hip_stream);
+    });
+}
+int tinympc_get_mpc_log(tinympc_solver *s, double *x, double *u, int *iter) {
+    if (!s) return -1;
+    return guarded("get_mpc_log", [&] { return s->s.get_mpc_log(x, u, iter); });
+}
+
 int tinympc_get_states(tinympc_solver *s, double *buf) {
     if (!s || !buf) return -1;
     return guarded("get_states", [&] { return s->s.get_traj(true, buf); });

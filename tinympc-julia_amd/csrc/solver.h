@@ -65,6 +65,9 @@ struct Solver {
     uint32_t *d_gstat = nullptr;
     uint32_t *h_gstat = nullptr;  // pinned
     float *d_scratch = nullptr;
+    float *d_mpc_x = nullptr, *d_mpc_u = nullptr;  // fused closed-loop logs
+    int *d_mpc_iter = nullptr;
+    int mpc_cap = 0, mpc_steps_last = 0;
     size_t scratch_cap = 0;
     bool solved_once = false;
     bool profiling = false;
@@ -85,7 +88,8 @@ struct Solver {
     int set_ref(bool is_x, const double *ref, int cols);
     int set_bounds(const double *xmin, const double *xmax, const double *umin, const double *umax);
     int reset();
-    int solve_async(hipStream_t stream);
+    int solve_async(hipStream_t stream, int mpc_steps = 0);
+    int get_mpc_log(double *x, double *u, int *iter);
     int solve_status();
     double kernel_elapsed_ms();
     int get_traj(bool states, double *buf);

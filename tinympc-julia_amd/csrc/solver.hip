@@ -67,6 +67,10 @@ void Solver::free_batch() {
     dev_free(d_sg);
     dev_free(d_sv);
     dev_free(d_scratch);
+    dev_free(d_mpc_x);
+    dev_free(d_mpc_u);
+    dev_free(d_mpc_iter);
+    mpc_cap = 0;
     xref_cap = uref_cap = scratch_cap = 0;
 }
 
@@ -284,8 +288,24 @@ int Solver::set_bounds(const double *xmin, const double *xmax, const double *umi
     return 0;
 }
 
-int Solver::solve_async(hipStream_t stream) {
+int Solver::solve_async(hipStream_t stream, int mpc_steps) {
     HIP_TRY(hipSetDevice(device));
+    if (mpc_steps > 0) {
+        if (!ke) {
+            set_error("mpc_rollout: this problem shape has no specialised kernel (generic path does plain solves only)");
+            return -1;
+        }
+        if (!warm_start) {
+            set_error("mpc_rollout needs the persistent workspace (set_warm_start(1))");
+            return -1;
+        }
+        if (mpc_cap < mpc_steps) {
+            const size_t n = (size_t)batch * mpc_steps;
+            if (dev_alloc(d_mpc_x, n * nx) || dev_alloc(d_mpc_u, n * nu) || dev_alloc(d_mpc_iter, n)) return -1;
+            mpc_cap = mpc_steps;
+        }
+        mpc_steps_last = mpc_steps;
+    }
     if (packs_dirty && upload_packs()) return -1;
     if (upload_refs()) return -1;
     AdmmParams P;
@@ -319,6 +339,11 @@ int Solver::solve_async(hipStream_t stream) {
     P.nx = nx;
     P.nu = nu;
     P.N = N;
+    P.mpc_steps = mpc_steps;
+    P.mpc_x = d_mpc_x;
+    P.mpc_u = d_mpc_u;
+    P.mpc_iter = d_mpc_iter;
+    P.x0_out = d_x0;
     HIP_TRY(hipMemsetAsync(d_gstat, 0, GSTAT_WORDS * sizeof(uint32_t), stream));
     if (profiling) {
         if (!ev0) HIP_TRY(hipEventCreate(&ev0));
@@ -338,6 +363,28 @@ int Solver::solve_status() {
         return -1;
     }
     return h_gstat[4] == 0 ? 0 : 1;  // admm.cpp:192 / :206 folded over the batch
+}
+
+int Solver::get_mpc_log(double *x, double *u, int *iter) {
+    if (mpc_steps_last <= 0) {
+        set_error("get_mpc_log: no mpc_rollout has run");
+        return -1;
+    }
+    HIP_TRY(hipSetDevice(device));
+    const size_t n = (size_t)batch * mpc_steps_last;
+    std::vector<float> h;
+    if (x) {
+        h.resize(n * nx);
+        HIP_TRY(hipMemcpy(h.data(), d_mpc_x, h.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < h.size(); ++i) x[i] = (double)h[i];
+    }
+    if (u) {
+        h.resize(n * nu);
+        HIP_TRY(hipMemcpy(h.data(), d_mpc_u, h.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < h.size(); ++i) u[i] = (double)h[i];
+    }
+    if (iter) HIP_TRY(hipMemcpy(iter, d_mpc_iter, n * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
 }
 
 double Solver::kernel_elapsed_ms() {

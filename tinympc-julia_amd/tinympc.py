@@ -85,6 +85,8 @@ SIGNATURES = {
     "tinympc_set_ref_mode": (c_int, [c_vp, c_int]),
     "tinympc_solve_async": (c_int, [c_vp, c_vp]),
     "tinympc_solve_status": (c_int, [c_vp]),
+    "tinympc_mpc_rollout": (c_int, [c_vp, c_int, c_vp]),
+    "tinympc_get_mpc_log": (c_int, [c_vp, c_dp, c_dp, c_ip]),
     "tinympc_set_profiling": (c_int, [c_vp, c_int]),
     "tinympc_kernel_elapsed_ms": (c_dbl, [c_vp]),
     "tinympc_set_precision": (c_int, [c_vp, c_int]),
@@ -479,6 +481,20 @@ class BatchSolver:
 
     def set_ref_mode(self, mode):
         self._chk(self.lib.tinympc_set_ref_mode(self.h, int(mode)), "set_ref_mode")
+
+    def mpc_rollout(self, steps, stream=None):
+        """`steps` fused closed-loop MPC steps in one launch (plant = the family's own A, B).
+        Returns dict(status, x=(nx, steps, B), u=(nu, steps, B), iter=(steps, B), solved=(steps, B))."""
+        st = int(self.lib.tinympc_mpc_rollout(self.h, int(steps), c_vp(stream or 0)))
+        if st < 0:
+            raise TinyMPCError(f"mpc_rollout failed ({_err()})")
+        nx, nu, B = self.nx, self.nu, self.batch
+        x, u = np.zeros(nx * steps * B), np.zeros(nu * steps * B)
+        it = np.zeros(steps * B, dtype=np.int32)
+        self._chk(self.lib.tinympc_get_mpc_log(self.h, _dp(x), _dp(u), it.ctypes.data_as(c_ip)), "get_mpc_log")
+        it = it.reshape((steps, B), order="F")
+        return dict(status=st, x=x.reshape((nx, steps, B), order="F"), u=u.reshape((nu, steps, B), order="F"),
+                    iter=np.abs(it), solved=(it > 0).astype(np.int32))
 
     def set_profiling(self, on):
         self._chk(self.lib.tinympc_set_profiling(self.h, 1 if on else 0), "set_profiling")
