@@ -1,0 +1,39 @@
+"""Full-size parity: every instance of BASELINE configs 2 and 3 (batch 65 536, 100 fixed iterations)
+against the fp64 CPU oracle, for both kernel precisions.  Prints the error distribution."""
+import os, sys, json, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import tinympc_julia_amd as t
+from oracle import cpu_oracle
+
+def nrel_batch(a, ref):
+    den = np.abs(ref).max(axis=(0, 1)); den = np.where(den == 0, 1.0, den)
+    return np.abs(a - ref).max(axis=(0, 1)) / den
+
+out = {}
+cores = len(os.sched_getaffinity(0))
+for fam in ("cartpole", "quadrotor"):
+    B = int(os.environ.get("FULL_B", 65536))
+    if fam == "cartpole":
+        prob, x0 = t.problems.cartpole(20, u_bound=0.5), t.problems.cartpole_x0(B, seed=0)
+    else:
+        prob, x0 = t.problems.quadrotor(30), t.problems.quadrotor_x0(B, seed=1)
+    t0 = time.time()
+    ref = cpu_oracle.solve_batch("orc64", prob, x0, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=100, nthreads=cores)
+    t_cpu = time.time() - t0
+    for prec in (0, 1):
+        bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+        bs.update_settings(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=100, check_termination=1)
+        bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        bs.set_precision(prec); bs.set_warm_start(False); bs.set_x0(x0)
+        bs.solve()
+        sol = bs.get_solution()
+        ex, eu = nrel_batch(sol["states"], ref["x"]), nrel_batch(sol["controls"], ref["u"])
+        key = f"{fam}_{'f64rec' if prec == 0 else 'f32'}"
+        out[key] = dict(kernel=bs.kernel_name, batch=B, x_max=float(ex.max()), u_max=float(eu.max()),
+                        x_p999=float(np.quantile(ex, 0.999)), u_p999=float(np.quantile(eu, 0.999)),
+                        x_median=float(np.median(ex)), u_median=float(np.median(eu)),
+                        n_over_1e5=int(((ex > 1e-5) | (eu > 1e-5)).sum()), oracle_seconds=t_cpu, oracle_threads=cores)
+        print(key, json.dumps(out[key]), flush=True)
+        bs.close()
+json.dump(out, open(os.path.join("gpurun_out", "full_batch_parity.json"), "w"), indent=1)

@@ -522,3 +522,29 @@ def test_fused_mpc_rollout_batch_vs_oracle(hip_lib, oracle_built):
     with pytest.raises(t.TinyMPCError):
         bg.mpc_rollout(3)
     bs.close(); bs2.close(); bg.close()
+
+
+@pytest.mark.parametrize("family", ["cartpole", "quadrotor"])
+def test_full_size_parity_every_instance(hip_lib, oracle_built, family):
+    """BASELINE configs 2 and 3 exactly as benchmarked (batch 65 536, seeded x0, 100 fixed iterations):
+    EVERY instance within 1e-5 (norm-relative) of the fp64 oracle, default precision.
+    (All-fp32 misses this on 3 / 40 of the 65 536 instances — profiles/r01_full_batch_parity.json.)"""
+    import os
+    B = 65536
+    if family == "cartpole":
+        prob, x0 = t.problems.cartpole(20, u_bound=0.5), t.problems.cartpole_x0(B, seed=0)
+    else:
+        prob, x0 = t.problems.quadrotor(30), t.problems.quadrotor_x0(B, seed=1)
+    ref = _oracle_batch(oracle_built, prob, x0, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=100,
+                        nthreads=len(os.sched_getaffinity(0)))
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+    bs.update_settings(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=100, check_termination=1)
+    bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    bs.set_warm_start(False)
+    bs.set_x0(x0)
+    assert bs.solve() == 1
+    sol = bs.get_solution()
+    ex, eu = nrel_batch(sol["states"], ref["x"]), nrel_batch(sol["controls"], ref["u"])
+    assert ex.max() <= FP32_TOL, f"x worst {ex.max():.3e} at {ex.argmax()}"
+    assert eu.max() <= FP32_TOL, f"u worst {eu.max():.3e} at {eu.argmax()}"
+    bs.close()
