@@ -4,6 +4,8 @@ vectors and against the fp64 CPU oracle on seeded batches.
 Tolerance: the fp32 kernel must satisfy
     max|a - b| <= 1e-5 * ||ref||_inf   per trajectory (x and u separately, per instance).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -548,3 +550,66 @@ def test_full_size_parity_every_instance(hip_lib, oracle_built, family):
     assert ex.max() <= FP32_TOL, f"x worst {ex.max():.3e} at {ex.argmax()}"
     assert eu.max() <= FP32_TOL, f"u worst {eu.max():.3e} at {eu.argmax()}"
     bs.close()
+
+
+def test_sharded_solver_single_rank_gpu(hip_lib, oracle_built):
+    """The GPU side of the multi-GPU driver on one rank: zero-copy torch view of the library's status
+    block (__cuda_array_interface__), stream-ordered solve on torch's current stream, status decode."""
+    import torch
+    from tinympc_julia_amd import sharding
+    B = 96
+    prob, x0 = t.problems.cartpole(20, u_bound=0.5), t.problems.cartpole_x0(B, seed=3)
+
+    def make_local(n, lo, hi):
+        bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=n, device=0)
+        bs.update_settings(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1)
+        bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        bs.set_x0(np.asfortranarray(x0[:, lo:hi]))
+        return sharding.local_from_batch_solver(bs, "cuda:0")
+
+    ss = sharding.ShardedSolver(make_local, B)
+    assert (ss.lo, ss.hi, ss.world) == (0, B, 1)
+    status, res = ss.solve()
+    ref = _oracle_batch(oracle_built, prob, x0, abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100)
+    assert status == int(np.any(ref["solved"] == 0))
+    st = ss.local.bs.get_status()
+    assert np.allclose(res, st["residuals"].max(axis=0), rtol=0, atol=0)
+    assert np.allclose(res, ref["res"].max(axis=0), rtol=2e-2, atol=1e-5)
+    # states/controls are viewable in place as torch tensors too (device-resident consumers)
+    ptr = ss.local.bs.device_buffers()
+    U = sharding.device_tensor(ptr["controls"], (B, prob.N - 1, prob.nu), torch.float32, torch.device("cuda:0"))
+    sol = ss.local.bs.get_solution()
+    assert np.array_equal(U.cpu().numpy().transpose(2, 1, 0), sol["controls"].astype(np.float32))
+    ss.local.bs.close()
+
+
+def test_rccl_status_allreduce_one_rank(hip_lib, tmp_path):
+    """bench.py's exchange step through RCCL itself (backend 'nccl', world_size 1 — one GPU is all this
+    box has): the all-reduce must accept the aliased status tensor and leave its bits intact."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import os, sys, numpy as np, torch, torch.distributed as dist
+        sys.path.insert(0, os.getcwd())
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+        import tinympc_julia_amd as t
+        from tinympc_julia_amd import sharding
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+        prob = t.problems.cartpole(20, u_bound=0.5)
+        bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=64, device=0)
+        bs.update_settings(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=20)
+        bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        bs.set_x0(t.problems.cartpole_x0(64, seed=1))
+        g = sharding.device_tensor(bs.device_buffers()["gstat"], (8,), torch.int32, torch.device("cuda", 0))
+        bs.solve_async(torch.cuda.current_stream().cuda_stream)
+        dist.all_reduce(g, op=dist.ReduceOp.MAX)          # what sharding.allreduce_status does for world > 1
+        torch.cuda.synchronize()
+        status, res = sharding.decode_status(g.cpu().numpy())
+        want = bs.get_status()["residuals"].max(axis=0).astype(np.float32)
+        assert status == 1 and np.array_equal(res, want), (status, res, want)
+        dist.barrier(); dist.destroy_process_group()
+        print("RCCL_OK")
+    ''')
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
