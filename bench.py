@@ -38,6 +38,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--precision", type=int, default=0, help="0: fp64 recurrences (default), 1: all fp32")
+    ap.add_argument("--mode", default="solve", choices=["solve", "mpc"],
+                    help="solve: BASELINE configs[1] (default).  mpc: warm-started closed loop (SURVEY 8f), extra")
+    ap.add_argument("--mpc-steps", type=int, default=50)
+    ap.add_argument("--mpc-max-iter", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -87,6 +91,46 @@ def cpu_baseline(prob, x0, refs, iters, seconds):
             "sample": f"{done} cold-start solves of the same workload ({iters} fixed iters) in {spent:.1f} s on "
                       f"{cores} threads" + (" (compiled reference snapshot, oracle/_ref)" if kind == "ref"
                                             else " (fp64 C restatement, oracle/)")}
+
+
+def measured_traffic(family, precision, batch, kernel):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json): FETCH_SIZE and
+    WRITE_SIZE collected in separate --pmc runs of this same command; FETCH_SIZE doubled as the gfx950
+    guide prescribes.  None when no matching measurement is committed."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.isfile(path):
+        return None
+    for e in json.load(open(path)):
+        if (e["family"], e["precision"], e["batch"], e["kernel"]) == (family, precision, batch, kernel):
+            return e["hbm_bytes_per_launch"]
+    return None
+
+
+def run_mpc_mode(args, t, bs, prob, x0, dev, stream, torch):
+    """Extra (not the headline): the closed-loop regime of SURVEY 8(f) — warm-started solves, max_iter 10,
+    tol 1e-3 — as K launches of one step (workspace round-trips through HBM every step) and as one fused
+    launch of K steps (workspace stays on chip)."""
+    K = args.mpc_steps
+    bs.update_settings(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=args.mpc_max_iter, check_termination=1,
+                       en_state_bound=1, en_input_bound=1)
+    bs.set_warm_start(True)
+    res = {}
+    for label, launches, steps in (("one_step_per_launch", K, 1), ("fused", 1, K)):
+        bs.reset()
+        bs.set_x0(x0)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(launches):
+            bs.lib.tinympc_mpc_rollout(bs.h, steps, None)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        n = bs.batch * K
+        # compulsory bytes of one closed-loop step when the workspace lives in HBM between launches
+        E_x, E_u = prob.nx * prob.N, prob.nu * (prob.N - 1)
+        per_step = 4 * (2 * prob.nx + prob.nu) + 4 + (4 * (E_x + E_u) + 24 + 8 * (3 * E_u + 2 * E_x) + 16) / steps
+        res[label] = {"mpc_steps_per_sec": n / dt, "ms_per_launch": 1e3 * dt / launches,
+                      "algorithmic_GBps": per_step * n / dt / 1e9}
+    return res
 
 
 def main():
@@ -178,12 +222,15 @@ def main():
             "admm_iters_per_sec": value * args.iters,
             "solve_status": status,
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach_gbs / HBM_PEAK_GBS,
+                         "traffic": measured_traffic(args.config, args.precision, batch, bs.kernel_name),
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "compute-bound path (SURVEY 8d): ~430 FLOP/B; see valu"},
             "valu": {"achieved_tflops": ach_tf, "peak_tflops": FP32_PEAK_TFLOPS,
                      "frac": ach_tf / FP32_PEAK_TFLOPS, "algorithmic_flops_per_launch": alg_flops},
         }
+        if args.mode == "mpc" and world == 1:
+            out["mpc_closed_loop"] = run_mpc_mode(args, t, bs, prob, x0, dev, stream, torch)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prob, x0, refs, args.iters, args.cpu_seconds)
         print(json.dumps(out), flush=True)

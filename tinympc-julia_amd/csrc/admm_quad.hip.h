@@ -76,25 +76,59 @@ struct QuadShape {
     static constexpr int THREADS = 256;
     static constexpr int INST_PER_BLOCK = THREADS / G;
     // ---- storage policy ----
-    // coefficients: VGPRs when small, LDS when their register footprint would exceed ~1/4 of the
-    // VGPR file; with one lane per instance (G = 1) they are wave-uniform and are read straight from
-    // memory with scalar loads instead.
-    template <class RT>
-    static constexpr int coef_regs() {
-        return CP * (int)(sizeof(RT) / 4);
+    // ---- storage policy -------------------------------------------------------------------
+    // Coefficient rows: VGPRs when small, LDS when their (live) register footprint would exceed
+    // ~1/4 of the VGPR file; with one lane per instance (G = 1) they are wave-uniform values.
+    template <class RT, int REFS>
+    static constexpr int coef_regs() {  // Pinf^T is only read when a reference trajectory exists
+        return (CP - (REFS == REF_ZERO ? RX * NXP : 0)) * (int)(sizeof(RT) / 4);
     }
-    template <class RT>
+    template <class RT, int REFS>
     static constexpr bool coef_in_lds() {
-        return G > 1 && coef_regs<RT>() > 72;
+        return G > 1 && coef_regs<RT, REFS>() > 72;
     }
-    // previous-slack arrays v, z in LDS when the register-resident state (+ coefficient rows) would
-    // not leave room for two wavefronts per SIMD / would not fit at all
-    static constexpr int STATE_REGS = 3 * RX * N + 4 * RU * (N - 1);
-    template <class RT>
-    static constexpr bool old_in_lds() {
-        return STATE_REGS + ((G > 1 && !coef_in_lds<RT>()) ? coef_regs<RT>() : 0) > 230;
+    // The seven per-instance trajectories (floats per lane) and where each lives.  Arrays are moved
+    // to LDS ([element][thread], conflict-free) in order of how rarely an iteration touches them,
+    // first to make room for two wavefronts per SIMD (<= 250 VGPRs, <= ~78 KB LDS per workgroup),
+    // else to fit one wavefront per SIMD (VGPRs + AGPRs, <= ~150 KB LDS).
+    enum { A_V = 0, A_Z, A_ZW, A_D, A_Y, A_W, A_G, A_COUNT };
+    struct Placement {
+        bool lds[A_COUNT];
+        int off[A_COUNT];  // float offset of the array inside the LDS state block, per thread-stride
+        int lds_floats;    // floats per lane in LDS
+    };
+    static constexpr int arr_size(int a) { return (a == A_V || a == A_W || a == A_G) ? RX * N : RU * (N - 1); }
+    template <class RT, int REFS>
+    static constexpr Placement place() {
+        Placement p{};
+        const int fixed = (coef_in_lds<RT, REFS>() || G == 1 ? 0 : coef_regs<RT, REFS>()) +
+                          (sizeof(RT) == 8 ? 60 : 45) + (REFS == REF_PER_INSTANCE ? RX * N + RU * (N - 1) : 0);
+        const int total = 3 * RX * N + 4 * RU * (N - 1);
+        // (register budget, LDS floats per lane) for 2 waves/SIMD, then 1 wave/SIMD
+        const int budget[2] = {250 - fixed, 380 - fixed};
+        const int cap[2] = {78, 150};
+        for (int pass = 0; pass < 2; ++pass) {
+            int regs = total, lds = 0;
+            bool sel[A_COUNT] = {};
+            for (int a = 0; a < A_COUNT && regs > budget[pass]; ++a) {
+                if (lds + arr_size(a) > cap[pass]) continue;
+                sel[a] = true;
+                regs -= arr_size(a);
+                lds += arr_size(a);
+            }
+            if (regs <= budget[pass] || pass == 1) {
+                int o = 0;
+                for (int a = 0; a < A_COUNT; ++a) {
+                    p.lds[a] = sel[a];
+                    p.off[a] = o;
+                    if (sel[a]) o += arr_size(a);
+                }
+                p.lds_floats = lds;
+                return p;
+            }
+        }
+        return p;
     }
-    static constexpr int OLD_FLOATS = (RX * N + RU * (N - 1)) * THREADS;
 };
 
 // ---- compile-time loop, so DPP controls are integer constant expressions ----
@@ -190,10 +224,9 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
     constexpr int RX = S::RX, RU = S::RU, NXP = S::NXP, NUP = S::NUP;
     constexpr int NXL = S::NXL, NUL = S::NUL;
     constexpr int EX = NX * N, EU = NU * (N - 1);
-    constexpr bool COEF_LDS = S::template coef_in_lds<RT>();
-    constexpr bool COEF_SCALAR = (G == 1);  // wave-uniform rows: scalar loads straight from memory
-    constexpr bool OLD_LDS = S::template old_in_lds<RT>();
-    constexpr int OLD_LEN = OLD_LDS ? S::OLD_FLOATS : 1;
+    constexpr bool COEF_LDS = S::template coef_in_lds<RT, REFS>();
+    constexpr auto PL = S::template place<RT, REFS>();
+    constexpr int STATE_LEN = PL.lds_floats > 0 ? PL.lds_floats * S::THREADS : 1;
     constexpr int T = S::THREADS;
     constexpr bool UREP = S::UREP;
     // two copies of the forward sweep (with / without the residual maxima) only where the code stays small
@@ -202,8 +235,8 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
     __shared__ float s_bnd[S::BOUNDS_LEN];
     __shared__ float s_ref[REFS == REF_SHARED ? S::REFS_LEN : 1];
     __shared__ RT s_coef[COEF_LDS ? G * S::CP : 1];
-    __shared__ float s_old[OLD_LEN];
-    static_assert(sizeof(float) * (S::BOUNDS_LEN + (REFS == REF_SHARED ? S::REFS_LEN : 1) + OLD_LEN) +
+    __shared__ float s_state[STATE_LEN];
+    static_assert(sizeof(float) * (S::BOUNDS_LEN + (REFS == REF_SHARED ? S::REFS_LEN : 1) + STATE_LEN) +
                           sizeof(RT) * (COEF_LDS ? G * S::CP : 1) <=
                       160 * 1024,
                   "workgroup LDS budget exceeded");
@@ -239,14 +272,12 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
     const float *ld = s_bnd + N * G * S::BW + q * S::DW;  // diag(Q)+rho, diag(R)+rho
 
     // ---- per-lane coefficient rows: VGPRs, LDS (big shapes) or scalar loads (G = 1) ----
-    RT rcoef[(COEF_LDS || COEF_SCALAR) ? 1 : S::CP];
+    RT rcoef[COEF_LDS ? 1 : S::CP];
     using CPtr = std::conditional_t<COEF_LDS, CoefLds<RT, G>, const RT *>;
     CPtr cbase;
     if constexpr (COEF_LDS) {
         cbase = CoefLds<RT, G>{s_coef + q * CoefLds<RT, G>::VEC};
-    } else if constexpr (COEF_SCALAR) {
-        cbase = gcoef;
-    } else {
+    } else {  // (G = 1: q = 0 on every lane, the rows are wave-uniform values)
         const RT *cp = gcoef + q * S::CP;
 #pragma unroll
         for (int i = 0; i < S::CP; ++i) rcoef[i] = cp[i];
@@ -262,27 +293,27 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
     const float rho = P.rho;
 
     // ---- per-instance state ----
-    float g[N][RX], w[N][RX];
-    float y[N - 1][RU], zw[N - 1][RU], d[N - 1][RU];
-    float vreg[OLD_LDS ? 1 : N][RX], zreg[OLD_LDS ? 1 : N - 1][RU];
-    float *lv = s_old + tid;                    // v: [k][m][T]
-    float *lz = s_old + RX * N * T + tid;       // z: [k][m][T]
-    auto v_get = [&](int k, int m) -> float {
-        if constexpr (OLD_LDS) return lv[(k * RX + m) * T];
-        else return vreg[k][m];
+    // One accessor per trajectory: a statically indexed register array, or a per-thread column of
+    // the LDS state block, as the placement says.
+#define TMPC_STATE_ARRAY(name, ID, KN, RW_)                                                      \
+    float name##_reg[PL.lds[S::ID] ? 1 : (KN)][PL.lds[S::ID] ? 1 : (RW_)];                      \
+    float *const name##_lds = s_state + PL.off[S::ID] * T + tid;                                \
+    auto name##_get = [&](int k, int m) -> float {                                              \
+        if constexpr (PL.lds[S::ID]) return name##_lds[(k * (RW_) + m) * T];                    \
+        else return name##_reg[k][m];                                                           \
+    };                                                                                          \
+    auto name##_set = [&](int k, int m, float val) {                                            \
+        if constexpr (PL.lds[S::ID]) name##_lds[(k * (RW_) + m) * T] = val;                     \
+        else name##_reg[k][m] = val;                                                            \
     };
-    auto v_set = [&](int k, int m, float val) {
-        if constexpr (OLD_LDS) lv[(k * RX + m) * T] = val;
-        else vreg[k][m] = val;
-    };
-    auto z_get = [&](int k, int m) -> float {
-        if constexpr (OLD_LDS) return lz[(k * RU + m) * T];
-        else return zreg[k][m];
-    };
-    auto z_set = [&](int k, int m, float val) {
-        if constexpr (OLD_LDS) lz[(k * RU + m) * T] = val;
-        else zreg[k][m] = val;
-    };
+    TMPC_STATE_ARRAY(g, A_G, N, RX)        // state dual
+    TMPC_STATE_ARRAY(w, A_W, N, RX)        // vnew
+    TMPC_STATE_ARRAY(v, A_V, N, RX)        // v (previous slack)
+    TMPC_STATE_ARRAY(y, A_Y, N - 1, RU)    // input dual
+    TMPC_STATE_ARRAY(zw, A_ZW, N - 1, RU)  // znew
+    TMPC_STATE_ARRAY(z, A_Z, N - 1, RU)    // z (previous slack)
+    TMPC_STATE_ARRAY(d, A_D, N - 1, RU)    // feed-forward
+#undef TMPC_STATE_ARRAY
     RT x0[RX];  // plant state; RT so a fused closed loop does not round it to fp32 every step
     float xr[REFS == REF_PER_INSTANCE ? N : 1][RX];
     float ur[REFS == REF_PER_INSTANCE ? N - 1 : 1][RU];
@@ -298,8 +329,8 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
     for (int k = 0; k < N; ++k)
 #pragma unroll
         for (int m = 0; m < RX; ++m) {
-            g[k][m] = 0.f;
-            w[k][m] = 0.f;
+            g_set(k, m, 0.f);
+            w_set(k, m, 0.f);
             v_set(k, m, 0.f);
             if constexpr (REFS == REF_PER_INSTANCE) xr[k][m] = 0.f;
         }
@@ -307,9 +338,9 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
     for (int k = 0; k < N - 1; ++k)
 #pragma unroll
         for (int m = 0; m < RU; ++m) {
-            y[k][m] = 0.f;
-            d[k][m] = 0.f;
-            zw[k][m] = 0.f;
+            y_set(k, m, 0.f);
+            d_set(k, m, 0.f);
+            zw_set(k, m, 0.f);
             z_set(k, m, 0.f);
             if constexpr (REFS == REF_PER_INSTANCE) ur[k][m] = 0.f;
         }
@@ -320,7 +351,7 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
             if (row < NX) {
 #pragma unroll
                 for (int k = 0; k < N; ++k) {
-                    g[k][m] = P.sg[b * EX + k * NX + row];
+                    g_set(k, m, P.sg[b * EX + k * NX + row]);
                     v_set(k, m, P.sv[b * EX + k * NX + row]);
                 }
             }
@@ -331,9 +362,9 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
             if (row < NU) {
 #pragma unroll
                 for (int k = 0; k < N - 1; ++k) {
-                    y[k][m] = P.sy[b * EU + k * NU + row];
+                    y_set(k, m, P.sy[b * EU + k * NU + row]);
                     z_set(k, m, P.sz[b * EU + k * NU + row]);
-                    d[k][m] = P.sd[b * EU + k * NU + row];
+                    d_set(k, m, P.sd[b * EU + k * NU + row]);
                 }
             }
         }
@@ -404,22 +435,23 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
         if constexpr (RES) pri_x = dua_x = pri_u = dua_u = 0.f;
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-            // LDS-resident constants are re-read at every knot instead of being hoisted
-            // into (and spilled from) registers for the whole solve.
-            if constexpr (COEF_LDS) asm volatile("" ::: "memory");
+            // LDS-resident constants (bounds, shared references, big coefficient packs) are re-read
+            // at every knot instead of being hoisted into registers for the whole solve.
+            asm volatile("" ::: "memory");
 #pragma unroll
             for (int m = 0; m < RX; ++m) {
                 const float xf = (float)x[m];
-                float vn = xf + g[k][m];                                        // vnew = x + g
+                const float gk = g_get(k, m);
+                float vn = xf + gk;                                             // vnew = x + g
                 if constexpr (XB)
                     vn = fminf(lb[k * G * S::BW + RX + m],                      // x_max.cwiseMin(
                                fmaxf(lb[k * G * S::BW + m], vn));               //   x_min.cwiseMax(vnew))
-                g[k][m] = (g[k][m] + xf) - vn;                                  // g = g + x - vnew
+                g_set(k, m, (gk + xf) - vn);                                    // g = g + x - vnew
                 if constexpr (RES) {
                     pri_x = fmaxf(pri_x, fabsf(xf - vn));
                     dua_x = fmaxf(dua_x, fabsf(v_get(k, m) - vn));
                 }
-                w[k][m] = vn;
+                w_set(k, m, vn);
             }
             if (k < N - 1) {
                 RT u[RU], xn[RX];
@@ -431,17 +463,18 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
                 quad_matvec<G, RX, NXL, RX, NXP>(xn, cA, x);                       // A x
 #pragma unroll
                 for (int m = 0; m < RU; ++m) {
-                    u[m] = -u[m] - (RT)d[k][m];                                 // u = -Kinf x - d
+                    u[m] = -u[m] - (RT)d_get(k, m);                             // u = -Kinf x - d
                     const float uf = (float)u[m];
-                    float zn = uf + y[k][m];                                    // znew = u + y
+                    const float yk = y_get(k, m);
+                    float zn = uf + yk;                                         // znew = u + y
                     zn = fminf(lb[k * G * S::BW + 2 * RX + RU + m],
                                fmaxf(lb[k * G * S::BW + 2 * RX + m], zn));
-                    y[k][m] = (y[k][m] + uf) - zn;                              // y = y + u - znew
+                    y_set(k, m, (yk + uf) - zn);                                // y = y + u - znew
                     if constexpr (RES) {
                         pri_u = fmaxf(pri_u, fabsf(uf - zn));
                         dua_u = fmaxf(dua_u, fabsf(z_get(k, m) - zn));
                     }
-                    zw[k][m] = zn;
+                    zw_set(k, m, zn);
                 }
                 // A x does not wait for u: both mat-vecs of x issue side by side, B u joins last
                 if constexpr (UREP) {
@@ -513,28 +546,31 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
                     }
 #pragma unroll
                     for (int m = 0; m < RX; ++m) {
-                        p[m] = -acc[m] - (RT)(rho * (w[N - 1][m] - g[N - 1][m]));  // admm.cpp:81-82
-                        v_set(N - 1, m, w[N - 1][m]);
+                        const float wN = w_get(N - 1, m);
+                        p[m] = -acc[m] - (RT)(rho * (wN - g_get(N - 1, m)));    // admm.cpp:81-82
+                        v_set(N - 1, m, wN);
                     }
                 }
                 sfor<0, N - 1>([&](auto kk) {
                     constexpr int k = N - 2 - decltype(kk)::value;
                     constexpr std::integral_constant<int, k> kc{};
-                    if constexpr (COEF_LDS) asm volatile("" ::: "memory");
+                    asm volatile("" ::: "memory");
                     RT r[RU], qk[RX];
 #pragma unroll
                     for (int m = 0; m < RU; ++m) {
                         float rr = 0.f;
                         if constexpr (REFS != REF_ZERO) rr = -(ref_u(kc, m) * cRD[m]);  // -(Uref .* R)
-                        r[m] = (RT)(rr - rho * (zw[k][m] - y[k][m]));           // admm.cpp:77-78
-                        z_set(k, m, zw[k][m]);
+                        const float zk = zw_get(k, m);
+                        r[m] = (RT)(rr - rho * (zk - y_get(k, m)));             // admm.cpp:77-78
+                        z_set(k, m, zk);
                     }
 #pragma unroll
                     for (int m = 0; m < RX; ++m) {
                         float qq = 0.f;
                         if constexpr (REFS != REF_ZERO) qq = -(ref_x(kc, m) * cQD[m]);  // -(Xref .* Q)
-                        qk[m] = (RT)(qq - rho * (w[k][m] - g[k][m]));           // admm.cpp:79-80
-                        v_set(k, m, w[k][m]);
+                        const float wk = w_get(k, m);
+                        qk[m] = (RT)(qq - rho * (wk - g_get(k, m)));            // admm.cpp:79-80
+                        v_set(k, m, wk);
                     }
                     RT t[RU];
 #pragma unroll
@@ -549,7 +585,7 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
                         quad_matvec<G, RU, NUL, RU, NUP>(dn, cQI, t);
                     }
 #pragma unroll
-                    for (int m = 0; m < RU; ++m) d[k][m] = (float)dn[m];
+                    for (int m = 0; m < RU; ++m) d_set(k, m, (float)dn[m]);
                     RT ap[RX], kr[RX];
 #pragma unroll
                     for (int m = 0; m < RX; ++m) ap[m] = qk[m];
@@ -574,7 +610,7 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
         // apply the first control to the plant model and log the step
         RT u0[RU], xn[RX];
 #pragma unroll
-        for (int m = 0; m < RU; ++m) u0[m] = (RT)zw[0][m];
+        for (int m = 0; m < RU; ++m) u0[m] = (RT)zw_get(0, m);
 #pragma unroll
         for (int m = 0; m < RX; ++m) xn[m] = (RT)0;
         quad_matvec<G, RX, NXL, RX, NXP>(xn, cA, x0);
@@ -596,7 +632,7 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
 #pragma unroll
             for (int m = 0; m < RU; ++m) {
                 const int row = q * RU + m;
-                if (row < NU) P.mpc_u[so * NU + row] = zw[0][m];
+                if (row < NU) P.mpc_u[so * NU + row] = zw_get(0, m);
             }
             if (q == 0) P.mpc_iter[so] = conv ? it : -it;  // sign carries the solved flag
         }
@@ -611,7 +647,7 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
             const int row = q * RX + m;
             if (row < NX) {
 #pragma unroll
-                for (int k = 0; k < N; ++k) P.xout[b * EX + k * NX + row] = w[k][m];
+                for (int k = 0; k < N; ++k) P.xout[b * EX + k * NX + row] = w_get(k, m);
             }
         }
 #pragma unroll
@@ -619,7 +655,7 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
             const int row = q * RU + m;
             if (row < NU) {
 #pragma unroll
-                for (int k = 0; k < N - 1; ++k) P.uout[b * EU + k * NU + row] = zw[k][m];
+                for (int k = 0; k < N - 1; ++k) P.uout[b * EU + k * NU + row] = zw_get(k, m);
             }
         }
         if (P.mpc_steps > 0) {
@@ -644,7 +680,7 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
                 if (row < NX) {
 #pragma unroll
                     for (int k = 0; k < N; ++k) {
-                        P.sg[b * EX + k * NX + row] = g[k][m];
+                        P.sg[b * EX + k * NX + row] = g_get(k, m);
                         P.sv[b * EX + k * NX + row] = v_get(k, m);
                     }
                 }
@@ -655,9 +691,9 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
                 if (row < NU) {
 #pragma unroll
                     for (int k = 0; k < N - 1; ++k) {
-                        P.sy[b * EU + k * NU + row] = y[k][m];
+                        P.sy[b * EU + k * NU + row] = y_get(k, m);
                         P.sz[b * EU + k * NU + row] = z_get(k, m);
-                        P.sd[b * EU + k * NU + row] = d[k][m];
+                        P.sd[b * EU + k * NU + row] = d_get(k, m);
                     }
                 }
             }

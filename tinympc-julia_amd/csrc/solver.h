@@ -24,6 +24,8 @@ struct KernelEntry {
 };
 // group < 0: the shape's default group size; otherwise that exact variant (nullptr if not built)
 const KernelEntry *find_quad_kernel(int nx, int nu, int N, int group = -1);
+// the variant best suited to `batch` instances (nullptr: no specialised kernel for the shape)
+const KernelEntry *select_quad_kernel(int nx, int nu, int N, int batch);
 hipError_t launch_generic(const AdmmParams &, int precision, hipStream_t);
 void build_generic_coef(const Solver &, std::vector<unsigned char> &);
 void build_generic_bounds(const Solver &, std::vector<float> &);
@@ -81,6 +83,7 @@ struct Solver {
     int init(const double *A_, const double *B_, const double *Q_, const double *R_, double rho,
              int nx_, int nu_, int N_, int batch_, int device_, int verbose_);
     int alloc_batch(int batch_);
+    int select_kernel();
     void free_batch();
     int upload_packs();
     int upload_refs();

@@ -107,22 +107,29 @@ int Solver::init(const double *A_, const double *B_, const double *Q_, const dou
     x_max.assign((size_t)ex(), 1e17);
     u_min.assign((size_t)eu(), -1e17);
     u_max.assign((size_t)eu(), 1e17);
-    {
-        // TINYMPC_HIP_GROUP=1|2|4 picks a non-default lanes-per-instance variant (tuning aid)
-        const char *genv = std::getenv("TINYMPC_HIP_GROUP");
-        ke = find_quad_kernel(nx, nu, N, genv ? std::atoi(genv) : -1);
-        if (!ke) ke = find_quad_kernel(nx, nu, N);
-    }
-    if (!ke && (nx > GEN_MAX_NX || nu > GEN_MAX_NU)) {
-        set_error("problem shape exceeds the generic kernel limits (nx <= 64, nu <= 32)");
-        return -1;
-    }
-    kernel_name = ke ? ke->name : "generic";
+    batch = batch_;
+    if (select_kernel()) return -1;
     if (dev_alloc(d_gstat, (size_t)GSTAT_WORDS)) return -1;
     HIP_TRY(hipHostMalloc((void **)&h_gstat, GSTAT_WORDS * sizeof(uint32_t), hipHostMallocDefault));
     std::memset(h_gstat, 0, GSTAT_WORDS * sizeof(uint32_t));
     packs_dirty = true;
     return alloc_batch(batch_);
+}
+
+// Picks the kernel variant for (shape, batch).  TINYMPC_HIP_GROUP=1|2|4 forces a lanes-per-instance
+// variant (tuning aid); shapes without a specialised kernel run on the generic one.
+int Solver::select_kernel() {
+    const char *genv = std::getenv("TINYMPC_HIP_GROUP");
+    const KernelEntry *k = genv ? find_quad_kernel(nx, nu, N, std::atoi(genv)) : nullptr;
+    if (!k) k = select_quad_kernel(nx, nu, N, batch);
+    if (!k && (nx > GEN_MAX_NX || nu > GEN_MAX_NU)) {
+        set_error("problem shape exceeds the generic kernel limits (nx <= 64, nu <= 32)");
+        return -1;
+    }
+    if (k != ke) packs_dirty = true;
+    ke = k;
+    kernel_name = ke ? ke->name : "generic";
+    return 0;
 }
 
 int Solver::alloc_batch(int batch_) {
@@ -133,6 +140,7 @@ int Solver::alloc_batch(int batch_) {
     HIP_TRY(hipSetDevice(device));
     free_batch();
     batch = batch_;
+    if (select_kernel()) return -1;
     const size_t Bn = (size_t)batch, EX = (size_t)ex(), EU = (size_t)eu();
     if (dev_alloc(d_x0, Bn * nx) || dev_alloc(d_xout, Bn * EX) || dev_alloc(d_uout, Bn * EU) ||
         dev_alloc(d_res, Bn * 4) || dev_alloc(d_iter, Bn) || dev_alloc(d_solved, Bn) ||
