@@ -40,10 +40,16 @@
 
 #include "admm_params.h"
 
+#ifndef TMPC_COEF_LDS_THRESHOLD_G1
+#define TMPC_COEF_LDS_THRESHOLD_G1 100000
+#endif
+
 namespace tmpc {
 
 // G = lanes per problem instance (a "group"): 4 = one DPP quad, 2 = half a quad, 1 = one lane.
-template <int NX_, int NU_, int N_, int G_ = 4>
+// BUD64 / BUD32: register budget per lane (fp64 / fp32 recurrences) the placement aims at when only one
+// wavefront per SIMD fits; tuned per shape on MI355X ("Where state lives").
+template <int NX_, int NU_, int N_, int G_ = 4, int BUD64_ = 380, int BUD32_ = 380>
 struct QuadShape {
     static_assert(G_ == 1 || G_ == 2 || G_ == 4, "group size must be 1, 2 or 4 lanes");
     static constexpr int NX = NX_, NU = NU_, N = N_, G = G_;
@@ -85,7 +91,7 @@ struct QuadShape {
     }
     template <class RT, int REFS>
     static constexpr bool coef_in_lds() {
-        return G > 1 && coef_regs<RT, REFS>() > 72;
+        return coef_regs<RT, REFS>() > TMPC_COEF_LDS_THRESHOLD_G1 || (G > 1 && coef_regs<RT, REFS>() > 72);
     }
     // The seven per-instance trajectories (floats per lane) and where each lives.  Arrays are moved
     // to LDS ([element][thread], conflict-free) in order of how rarely an iteration touches them,
@@ -101,11 +107,11 @@ struct QuadShape {
     template <class RT, int REFS>
     static constexpr Placement place() {
         Placement p{};
-        const int fixed = (coef_in_lds<RT, REFS>() || G == 1 ? 0 : coef_regs<RT, REFS>()) +
+        const int fixed = (coef_in_lds<RT, REFS>() ? 0 : coef_regs<RT, REFS>()) +
                           (sizeof(RT) == 8 ? 60 : 45) + (REFS == REF_PER_INSTANCE ? RX * N + RU * (N - 1) : 0);
         const int total = 3 * RX * N + 4 * RU * (N - 1);
         // (register budget, LDS floats per lane) for 2 waves/SIMD, then 1 wave/SIMD
-        const int budget[2] = {250 - fixed, 380 - fixed};
+        const int budget[2] = {250 - fixed, (sizeof(RT) == 8 ? BUD64_ : BUD32_) - fixed};
         const int cap[2] = {78, 150};
         for (int pass = 0; pass < 2; ++pass) {
             int regs = total, lds = 0;

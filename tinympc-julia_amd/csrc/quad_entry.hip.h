@@ -122,9 +122,9 @@ hipError_t launch_quad(const AdmmParams &P, int precision, bool state_bounds_act
                                : launch_quad_rt<S, float, false>(P, stream);
 }
 
-#define TMPC_DEFINE_QUAD_ENTRY(NX, NU, NN, GG)                                                 \
+#define TMPC_DEFINE_QUAD_ENTRY(NX, NU, NN, GG, ...)                                            \
     const KernelEntry *quad_entry_##NX##_##NU##_##NN##_g##GG() {                               \
-        using S = QuadShape<NX, NU, NN, GG>;                                                   \
+        using S = QuadShape<NX, NU, NN, GG, ##__VA_ARGS__>;                                    \
         static const KernelEntry e = {NX, NU, NN, GG, "quad<" #NX "," #NU "," #NN ",g" #GG ">", \
                                       &build_quad_coef<S>, &build_quad_bounds<S>, &launch_quad<S>}; \
         return &e;                                                                             \
