@@ -62,15 +62,22 @@ struct QuadShape {
     static constexpr bool UREP = (NU == 1);
     // Coefficient pack per lane role q (elements of RT); rows beyond nx/nu and columns
     // beyond nx/nu are zero.  Filled by the host (kernels.hip: build_quad_coef).
-    static constexpr int O_A = 0;                 // A       rows [RX][NXP]
-    static constexpr int O_AT = O_A + RX * NXP;   // AmBKt   rows [RX][NXP]
-    static constexpr int O_K = O_AT + RX * NXP;   // Kinf    rows [RU][NXP]
-    static constexpr int O_B = O_K + RU * NXP;    // B       rows [RX][NUP]
-    static constexpr int O_BT = O_B + RX * NUP;   // B^T     rows [RU][NXP]
-    static constexpr int O_KT = O_BT + RU * NXP;  // Kinf^T  rows [RX][NUP]
-    static constexpr int O_QI = O_KT + RX * NUP;  // Quu_inv rows [RU][NUP]
-    static constexpr int O_PT = O_QI + RU * NUP;  // Pinf^T  rows [RX][NXP]
-    static constexpr int CP = O_PT + RX * NXP;
+    // Three blocks, each padded to 8 elements so a block can be fetched with 8-element scalar
+    // loads: what the forward sweep reads | what the backward sweep reads | the terminal-cost rows.
+    static constexpr int pad8(int n) { return (n + 7) / 8 * 8; }
+    static constexpr int O_A = 0;                          // A       rows [RX][NXP]
+    static constexpr int O_K = O_A + RX * NXP;             // Kinf    rows [RU][NXP]
+    static constexpr int O_B = O_K + RU * NXP;             // B       rows [RX][NUP]
+    static constexpr int FWD_LEN = pad8(O_B + RX * NUP);
+    static constexpr int O_AT = FWD_LEN;                   // AmBKt   rows [RX][NXP]
+    static constexpr int O_BT = O_AT + RX * NXP;           // B^T     rows [RU][NXP]
+    static constexpr int O_KT = O_BT + RU * NXP;           // Kinf^T  rows [RX][NUP]
+    static constexpr int O_QI = O_KT + RX * NUP;           // Quu_inv rows [RU][NUP]
+    static constexpr int BWD_LEN = pad8(O_QI + RU * NUP - O_AT);
+    static constexpr int O_PT = O_AT + BWD_LEN;            // Pinf^T  rows [RX][NXP]
+    static constexpr int PT_LEN = pad8(RX * NXP);
+    static constexpr int CP = O_PT + PT_LEN;
+    static constexpr int CP_LIVE = 3 * RX * NXP + 2 * RU * NXP + 2 * RX * NUP + RU * NUP;
     // fp32 side pack per role: diag(Q)+rho [RX], diag(R)+rho [RU]
     static constexpr int DW = RX + RU;
     // Bounds pack: [N][G roles][xmin[RX] xmax[RX] umin[RU] umax[RU]]
@@ -87,7 +94,7 @@ struct QuadShape {
     // ~1/4 of the VGPR file; with one lane per instance (G = 1) they are wave-uniform values.
     template <class RT, int REFS>
     static constexpr int coef_regs() {  // Pinf^T is only read when a reference trajectory exists
-        return (CP - (REFS == REF_ZERO ? RX * NXP : 0)) * (int)(sizeof(RT) / 4);
+        return (CP_LIVE - (REFS == REF_ZERO ? RX * NXP : 0)) * (int)(sizeof(RT) / 4);
     }
     template <class RT, int REFS>
     static constexpr bool coef_in_lds() {
@@ -107,7 +114,8 @@ struct QuadShape {
     template <class RT, int REFS>
     static constexpr Placement place() {
         Placement p{};
-        const int fixed = (coef_in_lds<RT, REFS>() ? 0 : coef_regs<RT, REFS>()) +
+        const int fixed = ((coef_in_lds<RT, REFS>() || G == 1) ? 0 : coef_regs<RT, REFS>()) +  // G = 1: SGPRs
+                         
                           (sizeof(RT) == 8 ? 60 : 45) + (REFS == REF_PER_INSTANCE ? RX * N + RU * (N - 1) : 0);
         const int total = 3 * RX * N + 4 * RU * (N - 1);
         // (register budget, LDS floats per lane) for 2 waves/SIMD, then 1 wave/SIMD
@@ -191,6 +199,44 @@ struct CoefLds {
         // offsets used are multiples of VEC (every pack section is a multiple of G rows), so chunking commutes
         return CoefLds{base + (off / VEC) * G * VEC};
     }
+};
+// G = 1: a lane is an instance, so the coefficient rows are wave-uniform.  Each sweep fetches the
+// block it needs with scalar loads into SGPRs (8 elements per s_load) and its FMAs read them as
+// scalar operands — no VGPRs, no LDS, no per-use moves.  (Left to the compiler, the rows are kept
+// for the whole kernel, overflow the ~100 SGPRs and come back through v_readlane on every use.)
+template <class RT, int NLOADS>
+struct SBlock {
+    using V8 = RT __attribute__((ext_vector_type(8)));
+    V8 c[NLOADS];
+    __device__ __forceinline__ explicit SBlock(const RT *p) {
+        static_assert(NLOADS >= 1 && NLOADS <= 6, "coefficient block too large for SGPRs");
+        // one asm statement: every load, then the wait, so no output is consumed early
+        if constexpr (sizeof(RT) == 8) {
+            if constexpr (NLOADS == 2)
+                asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&s"(c[0]), "=&s"(c[1]) : "s"(p) : "memory");
+            else if constexpr (NLOADS == 3)
+                asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx16 %1, %3, 0x40\n\t"
+                             "s_load_dwordx16 %2, %3, 0x80\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&s"(c[0]), "=&s"(c[1]), "=&s"(c[2]) : "s"(p) : "memory");
+            else if constexpr (NLOADS == 4)
+                asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx16 %1, %4, 0x40\n\t"
+                             "s_load_dwordx16 %2, %4, 0x80\n\ts_load_dwordx16 %3, %4, 0xc0\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&s"(c[0]), "=&s"(c[1]), "=&s"(c[2]), "=&s"(c[3]) : "s"(p) : "memory");
+            else
+                for (int i = 0; i < NLOADS; ++i)
+                    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(c[i]) : "s"(p + 8 * i) : "memory");
+        } else {
+            for (int i = 0; i < NLOADS; ++i)
+                asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(c[i]) : "s"(p + 8 * i) : "memory");
+        }
+    }
+    struct View {
+        const SBlock &b;
+        int off;
+        __device__ __forceinline__ RT operator[](int i) const { return b.c[(off + i) / 8][(off + i) % 8]; }
+    };
+    __device__ __forceinline__ View at(int off) const { return View{*this, off}; }
 };
 __device__ __forceinline__ float tfma(float a, float b, float c) { return fmaf(a, b, c); }
 __device__ __forceinline__ double tfma(double a, double b, double c) { return fma(a, b, c); }
@@ -278,12 +324,14 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
     const float *ld = s_bnd + N * G * S::BW + q * S::DW;  // diag(Q)+rho, diag(R)+rho
 
     // ---- per-lane coefficient rows: VGPRs, LDS (big shapes) or scalar loads (G = 1) ----
-    RT rcoef[COEF_LDS ? 1 : S::CP];
+    RT rcoef[(COEF_LDS || G == 1) ? 1 : S::CP];
     using CPtr = std::conditional_t<COEF_LDS, CoefLds<RT, G>, const RT *>;
     CPtr cbase;
     if constexpr (COEF_LDS) {
         cbase = CoefLds<RT, G>{s_coef + q * CoefLds<RT, G>::VEC};
-    } else {  // (G = 1: q = 0 on every lane, the rows are wave-uniform values)
+    } else if constexpr (G == 1) {
+        cbase = gcoef;  // only the sweeps' scalar blocks read it
+    } else {
         const RT *cp = gcoef + q * S::CP;
 #pragma unroll
         for (int i = 0; i < S::CP; ++i) rcoef[i] = cp[i];
@@ -433,7 +481,7 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
     // ================= fused forward sweep =================
     // forward_pass (admm.cpp:25-35) + update_slack (:43-59) + update_dual (:65-69)
     // + (RES) the residual maxima of termination_condition (:93-96), knot by knot.
-    auto forward_sweep = [&](auto res_tag) {
+    auto forward_body = [&](auto res_tag, const auto cA, const auto cK, const auto cB) {
         constexpr bool RES = decltype(res_tag)::value;
         RT x[RX];
 #pragma unroll
@@ -505,6 +553,104 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
         conv = 0;
         ct_count = ct;
     }
+    auto backward_body = [&](const auto cAT, const auto cBT, const auto cKT, const auto cQI, const auto cPT) {
+            // ================= fused backward sweep =================
+            // v = vnew, z = znew (admm.cpp:196-197); update_linear_cost (:75-83) and
+            // backward_pass_grad (:13-20) knot by knot, q/r/p never stored.
+            RT p[RX];
+            {
+                RT acc[RX];
+#pragma unroll
+                for (int m = 0; m < RX; ++m) acc[m] = (RT)0;
+                if constexpr (REFS != REF_ZERO) {
+                    RT xrl[RX];
+#pragma unroll
+                    for (int m = 0; m < RX; ++m) xrl[m] = (RT)ref_x(std::integral_constant<int, N - 1>{}, m);
+                    quad_matvec<G, RX, NXL, RX, NXP>(acc, cPT, xrl);           // (Xref_{N-1}^T Pinf)^T
+                }
+#pragma unroll
+                for (int m = 0; m < RX; ++m) {
+                    const float wN = w_get(N - 1, m);
+                    p[m] = -acc[m] - (RT)(rho * (wN - g_get(N - 1, m)));    // admm.cpp:81-82
+                    v_set(N - 1, m, wN);
+                }
+            }
+            sfor<0, N - 1>([&](auto kk) {
+                constexpr int k = N - 2 - decltype(kk)::value;
+                constexpr std::integral_constant<int, k> kc{};
+                asm volatile("" ::: "memory");
+                RT r[RU], qk[RX];
+#pragma unroll
+                for (int m = 0; m < RU; ++m) {
+                    float rr = 0.f;
+                    if constexpr (REFS != REF_ZERO) rr = -(ref_u(kc, m) * cRD[m]);  // -(Uref .* R)
+                    const float zk = zw_get(k, m);
+                    r[m] = (RT)(rr - rho * (zk - y_get(k, m)));             // admm.cpp:77-78
+                    z_set(k, m, zk);
+                }
+#pragma unroll
+                for (int m = 0; m < RX; ++m) {
+                    float qq = 0.f;
+                    if constexpr (REFS != REF_ZERO) qq = -(ref_x(kc, m) * cQD[m]);  // -(Xref .* Q)
+                    const float wk = w_get(k, m);
+                    qk[m] = (RT)(qq - rho * (wk - g_get(k, m)));            // admm.cpp:79-80
+                    v_set(k, m, wk);
+                }
+                RT t[RU];
+#pragma unroll
+                for (int m = 0; m < RU; ++m) t[m] = r[m];
+                quad_matvec<G, RU, NXL, RX, NXP>(t, cBT, p);                   // B^T p_{k+1} + r_k
+                RT dn[RU];
+                if constexpr (UREP) {
+                    dn[0] = (RT)cQI[0] * t[0];                              // d_k = Quu_inv (...)
+                } else {
+#pragma unroll
+                    for (int m = 0; m < RU; ++m) dn[m] = (RT)0;
+                    quad_matvec<G, RU, NUL, RU, NUP>(dn, cQI, t);
+                }
+#pragma unroll
+                for (int m = 0; m < RU; ++m) d_set(k, m, (float)dn[m]);
+                RT ap[RX], kr[RX];
+#pragma unroll
+                for (int m = 0; m < RX; ++m) ap[m] = qk[m];
+                quad_matvec<G, RX, NXL, RX, NXP>(ap, cAT, p);                  // q_k + AmBKt p_{k+1}
+                if constexpr (UREP) {
+#pragma unroll
+                    for (int m = 0; m < RX; ++m) kr[m] = (RT)cKT[m * NUP] * r[0];  // Kinf^T r_k
+                } else {
+#pragma unroll
+                    for (int m = 0; m < RX; ++m) kr[m] = (RT)0;
+                    quad_matvec<G, RX, NUL, RU, NUP>(kr, cKT, r);
+                }
+#pragma unroll
+                for (int m = 0; m < RX; ++m) p[m] = ap[m] - kr[m];          // admm.cpp:18
+            });
+    };
+    auto backward_sweep = [&]() {
+        if constexpr (G == 1) {
+            const SBlock<RT, S::BWD_LEN / 8> blk(gcoef + S::O_AT);
+            if constexpr (REFS != REF_ZERO) {
+                const SBlock<RT, S::PT_LEN / 8> pt(gcoef + S::O_PT);
+                backward_body(blk.at(0), blk.at(S::O_BT - S::O_AT), blk.at(S::O_KT - S::O_AT),
+                              blk.at(S::O_QI - S::O_AT), pt.at(0));
+            } else {
+                backward_body(blk.at(0), blk.at(S::O_BT - S::O_AT), blk.at(S::O_KT - S::O_AT),
+                              blk.at(S::O_QI - S::O_AT), blk.at(0));  // Pinf^T unused without references
+            }
+        } else {
+            backward_body(cAT, cBT, cKT, cQI, cPT);
+        }
+    };
+
+    auto forward_sweep = [&](auto res_tag) {
+        if constexpr (G == 1) {
+            const SBlock<RT, S::FWD_LEN / 8> blk(gcoef + S::O_A);
+            forward_body(res_tag, blk.at(S::O_A), blk.at(S::O_K), blk.at(S::O_B));
+        } else {
+            forward_body(res_tag, cA, cK, cB);
+        }
+    };
+
     for (int i = 0; i < P.max_iter; ++i) {
         if (active && !conv) {
             bool check = false;
@@ -535,79 +681,7 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
                     res3 < P.abs_dua_tol)
                     conv = 1;
             }
-            if (!conv) {
-                // ================= fused backward sweep =================
-                // v = vnew, z = znew (admm.cpp:196-197); update_linear_cost (:75-83) and
-                // backward_pass_grad (:13-20) knot by knot, q/r/p never stored.
-                RT p[RX];
-                {
-                    RT acc[RX];
-#pragma unroll
-                    for (int m = 0; m < RX; ++m) acc[m] = (RT)0;
-                    if constexpr (REFS != REF_ZERO) {
-                        RT xrl[RX];
-#pragma unroll
-                        for (int m = 0; m < RX; ++m) xrl[m] = (RT)ref_x(std::integral_constant<int, N - 1>{}, m);
-                        quad_matvec<G, RX, NXL, RX, NXP>(acc, cPT, xrl);           // (Xref_{N-1}^T Pinf)^T
-                    }
-#pragma unroll
-                    for (int m = 0; m < RX; ++m) {
-                        const float wN = w_get(N - 1, m);
-                        p[m] = -acc[m] - (RT)(rho * (wN - g_get(N - 1, m)));    // admm.cpp:81-82
-                        v_set(N - 1, m, wN);
-                    }
-                }
-                sfor<0, N - 1>([&](auto kk) {
-                    constexpr int k = N - 2 - decltype(kk)::value;
-                    constexpr std::integral_constant<int, k> kc{};
-                    asm volatile("" ::: "memory");
-                    RT r[RU], qk[RX];
-#pragma unroll
-                    for (int m = 0; m < RU; ++m) {
-                        float rr = 0.f;
-                        if constexpr (REFS != REF_ZERO) rr = -(ref_u(kc, m) * cRD[m]);  // -(Uref .* R)
-                        const float zk = zw_get(k, m);
-                        r[m] = (RT)(rr - rho * (zk - y_get(k, m)));             // admm.cpp:77-78
-                        z_set(k, m, zk);
-                    }
-#pragma unroll
-                    for (int m = 0; m < RX; ++m) {
-                        float qq = 0.f;
-                        if constexpr (REFS != REF_ZERO) qq = -(ref_x(kc, m) * cQD[m]);  // -(Xref .* Q)
-                        const float wk = w_get(k, m);
-                        qk[m] = (RT)(qq - rho * (wk - g_get(k, m)));            // admm.cpp:79-80
-                        v_set(k, m, wk);
-                    }
-                    RT t[RU];
-#pragma unroll
-                    for (int m = 0; m < RU; ++m) t[m] = r[m];
-                    quad_matvec<G, RU, NXL, RX, NXP>(t, cBT, p);                   // B^T p_{k+1} + r_k
-                    RT dn[RU];
-                    if constexpr (UREP) {
-                        dn[0] = (RT)cQI[0] * t[0];                              // d_k = Quu_inv (...)
-                    } else {
-#pragma unroll
-                        for (int m = 0; m < RU; ++m) dn[m] = (RT)0;
-                        quad_matvec<G, RU, NUL, RU, NUP>(dn, cQI, t);
-                    }
-#pragma unroll
-                    for (int m = 0; m < RU; ++m) d_set(k, m, (float)dn[m]);
-                    RT ap[RX], kr[RX];
-#pragma unroll
-                    for (int m = 0; m < RX; ++m) ap[m] = qk[m];
-                    quad_matvec<G, RX, NXL, RX, NXP>(ap, cAT, p);                  // q_k + AmBKt p_{k+1}
-                    if constexpr (UREP) {
-#pragma unroll
-                        for (int m = 0; m < RX; ++m) kr[m] = (RT)cKT[m * NUP] * r[0];  // Kinf^T r_k
-                    } else {
-#pragma unroll
-                        for (int m = 0; m < RX; ++m) kr[m] = (RT)0;
-                        quad_matvec<G, RX, NUL, RU, NUP>(kr, cKT, r);
-                    }
-#pragma unroll
-                    for (int m = 0; m < RX; ++m) p[m] = ap[m] - kr[m];          // admm.cpp:18
-                });
-            }
+            if (!conv) backward_sweep();
         }
         // every instance of this wavefront finished?  (wave-uniform exit)
         if (!__builtin_amdgcn_ballot_w64(active && !conv)) break;
@@ -619,12 +693,20 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
         for (int m = 0; m < RU; ++m) u0[m] = (RT)zw_get(0, m);
 #pragma unroll
         for (int m = 0; m < RX; ++m) xn[m] = (RT)0;
-        quad_matvec<G, RX, NXL, RX, NXP>(xn, cA, x0);
-        if constexpr (UREP) {
+        auto plant = [&](const auto pA, const auto pB) {
+            quad_matvec<G, RX, NXL, RX, NXP>(xn, pA, x0);
+            if constexpr (UREP) {
 #pragma unroll
-            for (int m = 0; m < RX; ++m) xn[m] = tfma((RT)cB[m * NUP], u0[0], xn[m]);
+                for (int m = 0; m < RX; ++m) xn[m] = tfma((RT)pB[m * NUP], u0[0], xn[m]);
+            } else {
+                quad_matvec<G, RX, NUL, RU, NUP>(xn, pB, u0);
+            }
+        };
+        if constexpr (G == 1) {
+            const SBlock<RT, S::FWD_LEN / 8> blk(gcoef + S::O_A);
+            plant(blk.at(S::O_A), blk.at(S::O_B));
         } else {
-            quad_matvec<G, RX, NUL, RU, NUP>(xn, cB, u0);
+            plant(cA, cB);
         }
 #pragma unroll
         for (int m = 0; m < RX; ++m) x0[m] = xn[m];
