@@ -32,9 +32,10 @@ extern "C" {
 /* (1) process-global solver: the reference's own entry points               */
 /* ------------------------------------------------------------------------- */
 
-/* replaces bindings.cpp:21-73 setup_solver.  fdyn must be all zero (the affine
- * term exists only in the un-vendored TinyMPC submodule) —
- * a non-zero fdyn returns -1.  Batch starts at 1; see set_batch_size. */
+/* replaces bindings.cpp:21-73 setup_solver.  A non-zero fdyn (affine dynamics x+ = A x + B u + f)
+ * is honoured, but its arithmetic lives only in the un-vendored TinyMPC submodule (SURVEY.md §0
+ * fact 2): parity for it is UNPINNED, and such problems run on the generic kernel.
+ * Batch starts at 1; see set_batch_size. */
 int setup_solver(double *A_data, int A_rows, int A_cols, double *B_data, int B_rows, int B_cols,
                  double *fdyn_data, int fdyn_rows, int fdyn_cols, double *Q_data, int Q_rows,
                  int Q_cols, double *R_data, int R_rows, int R_cols, double rho, int nx, int nu,
@@ -54,8 +55,8 @@ int get_states(double *states_buffer, int *rows, int *cols);
 int get_controls(double *controls_buffer, int *rows, int *cols);
 /* replaces bindings.cpp:205-208 */
 void cleanup_solver(void);
-/* replaces bindings.cpp:336-376.  en_*_soc / en_*_linear must be 0 and adaptive_rho must be 0
- * (out of scope this round; non-zero returns -1).  check_termination <= 0 means "never check"
+/* replaces bindings.cpp:336-376.  en_*_linear and adaptive_rho must be 0 (non-zero returns -1);
+ * en_*_soc switch the cone sets given to set_cone_constraints on and off (parity unpinned).  check_termination <= 0 means "never check"
  * (the reference divides by it, admm.cpp:91). */
 int update_settings(double abs_pri_tol, double abs_dua_tol, int max_iter, int check_termination,
                     int en_state_bound, int en_input_bound, int en_state_soc, int en_input_soc,
@@ -75,8 +76,11 @@ int set_cache_terms(double *Kinf_data, int Kinf_rows, int Kinf_cols, double *Pin
                     int verbose);
 /* replaces bindings.cpp:228-259 */
 int print_problem_data(int verbose);
-/* replace bindings.cpp:413-490: accepted only when every block is empty; otherwise -1
- * (SOC / linear constraints live in the absent submodule — parity unpinned). */
+/* replace bindings.cpp:413-490.  set_linear_constraints is accepted only when every block is empty
+ * (otherwise -1).  set_cone_constraints: per-knot second-order cones, inputs first; cone i covers rows
+ * [Ac[i], Ac[i]+qc[i]) of each knot, the LAST row is the axis: ||head|| <= c[i] * axis
+ * (rocket_landing_constraints.jl:51-57,132); at most 8 cones per side; enables the non-empty halves.
+ * Cone and fdyn arithmetic lives only in the absent submodule — parity UNPINNED. */
 int set_linear_constraints(double *Alin_x_data, int Alin_x_rows, int Alin_x_cols,
                            double *blin_x_data, int blin_x_len, double *Alin_u_data,
                            int Alin_u_rows, int Alin_u_cols, double *blin_u_data, int blin_u_len,
@@ -114,6 +118,12 @@ int tinympc_set_bound_constraints(tinympc_solver *s, const double *x_min, const 
                                   const double *u_min, const double *u_max);
 int tinympc_set_cache_terms(tinympc_solver *s, const double *Kinf, const double *Pinf,
                             const double *Quu_inv, const double *AmBKt);
+/* Unpinned extensions (see setup_solver / set_cone_constraints above). */
+int tinympc_set_fdyn(tinympc_solver *s, const double *fdyn /* nx, NULL = zero */);
+int tinympc_set_cone_constraints(tinympc_solver *s, const int *Acu, const int *qcu, const double *cu,
+                                 int n_input_cones, const int *Acx, const int *qcx, const double *cx,
+                                 int n_state_cones);
+int tinympc_enable_cones(tinympc_solver *s, int en_state_soc, int en_input_soc);
 int tinympc_get_cache_terms(tinympc_solver *s, double *Kinf, double *Pinf, double *Quu_inv,
                             double *AmBKt);
 int tinympc_set_x0(tinympc_solver *s, const double *x0, int cols);       /* cols: 1 | batch */

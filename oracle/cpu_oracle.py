@@ -106,6 +106,20 @@ class CpuSolver:
         ur = _f(ur)
         self._call("set_u_ref", _dp(ur))
 
+    def set_fdyn(self, f):
+        """UNPINNED extension (not available on the compiled reference snapshot)"""
+        assert self.kind != "ref", "the vendored snapshot has no affine term"
+        f = np.ascontiguousarray(np.asarray(f, dtype=np.float64))
+        self._call("set_fdyn", _dp(f))
+
+    def set_cone_constraints(self, Acu, qcu, cu, Acx, qcx, cx):
+        """UNPINNED extension; inputs first (bindings.cpp:453-459)"""
+        assert self.kind != "ref", "the vendored snapshot has no cone constraints"
+        ia = [np.ascontiguousarray(np.asarray(a, dtype=np.int32)) for a in (Acu, qcu, Acx, qcx)]
+        da = [np.ascontiguousarray(np.asarray(a, dtype=np.float64)) for a in (cu, cx)]
+        self._call("set_cone_constraints", ia[0].ctypes.data_as(_c_ip), ia[1].ctypes.data_as(_c_ip), _dp(da[0]),
+                   len(da[0]), ia[2].ctypes.data_as(_c_ip), ia[3].ctypes.data_as(_c_ip), _dp(da[1]), len(da[1]))
+
     def set_cache_terms(self, Kinf, Pinf, Quu_inv, AmBKt):
         a = [_f(m) for m in (Kinf, Pinf, Quu_inv, AmBKt)]
         self._call("set_cache_terms", *[_dp(m) for m in a])
@@ -143,6 +157,14 @@ class CpuSolver:
         v = np.zeros((nx, N), order="F")
         self._call("get_state", _dp(d), _dp(y), _dp(g), _dp(v), _dp(z))
         return dict(d=d, y=y, g=g, v=v, z=z)
+
+
+def project_soc(block, mu, kind="orc64"):
+    """The oracle's cone projection of one block (head..., axis) — for property tests."""
+    lib = _load(kind)
+    b = np.ascontiguousarray(np.asarray(block, dtype=np.float64)).copy()
+    getattr(lib, kind + "_project_soc_block")(_dp(b), len(b), ctypes.c_double(mu))
+    return b
 
 
 def solve_batch(kind, prob, x0, xref=None, uref=None, abs_pri_tol=1e-3, abs_dua_tol=1e-3,

@@ -32,6 +32,11 @@ extern "C" {
     void P##set_x0(void *h, const double *x0);                                                 \
     void P##set_x_ref(void *h, const double *xref);                                            \
     void P##set_u_ref(void *h, const double *uref);                                            \
+    void P##project_soc_block(double *blk, int q, double mu);                                 \
+    void P##set_fdyn(void *h, const double *fdyn);                                            \
+    void P##set_cone_constraints(void *h, const int *Acu, const int *qcu, const double *cu,   \
+                                 int ncu, const int *Acx, const int *qcx, const double *cx,   \
+                                 int ncx);                                                    \
     void P##set_cache_terms(void *h, const double *Kinf, const double *Pinf,                  \
                             const double *Quu_inv, const double *AmBKt);                      \
     void P##reset(void *h);                                                                    \

@@ -1,0 +1,109 @@
+"""CPU tests of the UNPINNED extensions' oracle (affine dynamics term, second-order cones).
+
+No reference source, test or vector exists for these: the oracle restates the public
+TinyMPC solver's construction and is validated here by PROPERTIES, not by golden vectors:
+projection idempotence / feasibility / fixed points, zero-extension == pinned path, and — at
+convergence — dynamics consistency and cone feasibility of the returned trajectory."""
+import numpy as np
+import pytest
+
+import tinympc_julia_amd as t
+
+
+def _np_proj(s, mu):
+    """independent numpy statement of the same map"""
+    s = np.asarray(s, dtype=np.float64)
+    w, tt = s[:-1], s[-1]
+    a, u0 = np.linalg.norm(w), mu * tt
+    if a <= -u0:
+        return np.zeros_like(s)
+    if a <= u0:
+        return s.copy()
+    sc = 0.5 * (1.0 + u0 / a)
+    return np.concatenate([sc * w, [sc * a / mu]])
+
+
+@pytest.mark.parametrize("mu", [0.25, 0.5, 1.0, 2.0])
+def test_soc_projection_properties(oracle_built, mu):
+    rng = np.random.default_rng(7)
+    for q in (2, 3, 4, 6):
+        for _ in range(200):
+            s = rng.standard_normal(q) * rng.choice([0.1, 1.0, 10.0])
+            p = oracle_built.project_soc(s, mu)
+            assert np.allclose(p, _np_proj(s, mu), rtol=1e-12, atol=1e-14)
+            # feasibility: ||head|| <= mu * axis
+            assert np.linalg.norm(p[:-1]) <= mu * p[-1] + 1e-12 * max(1.0, np.abs(p).max())
+            # idempotence
+            assert np.allclose(oracle_built.project_soc(p, mu), p, rtol=1e-12, atol=1e-14)
+            # points of the cone are fixed; points of the polar cone map to the origin
+            inside = np.concatenate([s[:-1], [np.linalg.norm(s[:-1]) / mu + abs(s[-1])]])
+            assert np.array_equal(oracle_built.project_soc(inside, mu), inside)
+            polar = np.concatenate([s[:-1], [-np.linalg.norm(s[:-1]) / mu - abs(s[-1])]])
+            assert np.all(oracle_built.project_soc(polar, mu) == 0.0)
+
+
+def _rocket_solver(oracle_built, kind, N, fdyn=True, cones=True, **settings):
+    prob = t.problems.rocket(N)
+    s = oracle_built.CpuSolver(kind, prob.A, prob.B, prob.Q, prob.R, prob.rho, N)
+    s.update_settings(**settings)
+    s.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    if fdyn:
+        s.set_fdyn(prob.fdyn)
+    if cones:
+        s.set_cone_constraints([0], [3], [prob.extra["cone_mu_u"]], [0], [3], [prob.extra["cone_mu_x"]])
+    xr, ur = t.problems.rocket_refs(N)
+    s.set_x_ref(xr)
+    s.set_u_ref(ur)
+    return prob, s
+
+
+def test_zero_extensions_equal_pinned_path(oracle_built):
+    """fdyn = 0 and no cones must reproduce the pinned (golden-checked) path bit for bit."""
+    prob, a = _rocket_solver(oracle_built, "orc64", 10, fdyn=False, cones=False, abs_pri_tol=0.0, abs_dua_tol=0.0,
+                             max_iter=50)
+    _, b = _rocket_solver(oracle_built, "orc64", 10, fdyn=False, cones=False, abs_pri_tol=0.0, abs_dua_tol=0.0,
+                          max_iter=50)
+    b.set_fdyn(np.zeros(6))
+    b.set_cone_constraints([], [], [], [], [], [])
+    x0 = t.problems.rocket_x0(1, seed=2)[:, 0]
+    for s in (a, b):
+        s.set_x0(x0)
+        s.solve()
+    ra, rb = a.get_solution(), b.get_solution()
+    assert np.array_equal(ra["x"], rb["x"]) and np.array_equal(ra["u"], rb["u"])
+
+
+def test_rocket_with_fdyn_and_cones_converges_feasible(oracle_built):
+    """examples/rocket_landing_constraints.jl set-up (N = 10): at convergence the trajectory obeys the
+    affine dynamics and the thrust cone the example itself checks (:132)."""
+    prob, s = _rocket_solver(oracle_built, "orc64", 10, abs_pri_tol=1e-5, abs_dua_tol=1e-5, max_iter=3000)
+    x0 = 1.1 * prob.extra["xinit"]
+    s.set_x0(x0)
+    status = s.solve()
+    r = s.get_solution()
+    assert status == 0, (r["iter"], r["res"])
+    x, u = r["x"], r["u"]
+    assert np.abs(x[:, 0] - x0).max() <= 1e-4 * np.abs(x0).max()
+    for k in range(prob.N - 1):
+        pred = prob.A @ x[:, k] + prob.B @ u[:, k] + prob.fdyn
+        assert np.abs(x[:, k + 1] - pred).max() <= 5e-4, k
+    # thrust cone ||u[0:2]|| <= 0.25 |u[2]| and glide cone ||x[0:2]|| <= 0.5 x[2], up to the ADMM tolerance
+    assert np.all(np.linalg.norm(u[:2], axis=0) <= 0.25 * np.abs(u[2]) + 1e-3)
+    assert np.all(np.linalg.norm(x[:2], axis=0) <= 0.5 * x[2] + 1e-3)
+    assert np.all(u <= 105.0 + 1e-9) and np.all(u >= -10.0 - 1e-9)
+    # gravity is really being compensated: hover-level vertical thrust appears
+    assert u[2].max() > 5.0
+
+
+def test_fdyn_changes_the_answer_and_cones_bind(oracle_built):
+    outs = {}
+    for key, (fd, cn) in dict(plain=(False, False), fdyn=(True, False), both=(True, True)).items():
+        prob, s = _rocket_solver(oracle_built, "orc64", 10, fdyn=fd, cones=cn, abs_pri_tol=1e-4, abs_dua_tol=1e-4,
+                                 max_iter=2000)
+        s.set_x0(1.1 * prob.extra["xinit"])
+        s.solve()
+        outs[key] = s.get_solution()
+    assert np.abs(outs["plain"]["u"] - outs["fdyn"]["u"]).max() > 1e-2
+    viol = np.linalg.norm(outs["fdyn"]["u"][:2], axis=0) - 0.25 * np.abs(outs["fdyn"]["u"][2])
+    assert viol.max() > 1e-3, "test problem must violate the cone without the constraint"
+    assert np.abs(outs["both"]["u"] - outs["fdyn"]["u"]).max() > 1e-3

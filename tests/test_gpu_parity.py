@@ -401,17 +401,17 @@ def test_error_behaviour(hip_lib):
     with pytest.raises(t.TinyMPCError):
         t.set_x0(s, np.zeros(4))                        # "Solver not setup" (TinyMPC.jl:116)
     prob = t.problems.cartpole(10)
-    with pytest.raises(t.TinyMPCError):                 # non-zero fdyn is refused, not ignored
-        t.setup(s, prob.A, prob.B, np.array([0, 0, 0.1, 0]), prob.Q, prob.R, 1.0, 4, 1, 10)
+    with pytest.raises(t.TinyMPCError):                 # fdyn of the wrong length
+        t.setup(s, prob.A, prob.B, np.array([0, 0, 0.1]), prob.Q, prob.R, 1.0, 4, 1, 10)
     t.setup(s, prob.A, prob.B, np.zeros(4), prob.Q, prob.R, 1.0, 4, 1, 10)
     with pytest.raises(t.TinyMPCError):
         t.set_x0(s, np.zeros(5))                        # wrong length
     with pytest.raises(t.TinyMPCError):
         t.set_x_ref(s, np.zeros((4, 7)))                # wrong horizon
     with pytest.raises(t.TinyMPCError):
-        t.update_settings(s, en_input_soc=True)         # SOC is refused, not silently dropped
+        t.update_settings(s, adaptive_rho=True)         # adaptive rho is refused, not silently dropped
     with pytest.raises(t.TinyMPCError):
-        t.set_cone_constraints(s, [0], [3], [0.25], [], [], [])
+        t.set_cone_constraints(s, [0], [3], [0.25], [], [], [])   # a 3-row cone on a 1-row input
     assert t.set_cone_constraints(s, [], [], [], [], [], []) == 0
     # update_settings resets en_*_bound like the reference (TinyMPC.jl:181-207 gotcha)
     t.set_bound_constraints(s, np.full((4, 10), -1e17), np.full((4, 10), 1e17), np.full((1, 9), -0.1),
@@ -613,3 +613,120 @@ def test_rccl_status_allreduce_one_rank(hip_lib, tmp_path):
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+# ---------------- UNPINNED extensions: affine dynamics + second-order cones (BASELINE config 4) ----------------
+
+def _oracle_rocket(oracle_built, prob, x0, xr, ur, fdyn, cones, **kw):
+    B = x0.shape[1]
+    X, U = np.zeros((prob.nx, prob.N, B)), np.zeros((prob.nu, prob.N - 1, B))
+    it, so = np.zeros(B, dtype=int), np.zeros(B, dtype=int)
+    for b in range(B):
+        o = oracle_built.CpuSolver("orc64", prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N)
+        o.update_settings(**kw)
+        o.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        if fdyn:
+            o.set_fdyn(prob.fdyn)
+        if cones:
+            o.set_cone_constraints([0], [3], [0.25], [0], [3], [0.5])
+        o.set_x_ref(xr)
+        o.set_u_ref(ur)
+        o.set_x0(x0[:, b])
+        o.solve()
+        r = o.get_solution()
+        X[:, :, b], U[:, :, b], it[b], so[b] = r["x"], r["u"], r["iter"], r["solved"]
+    return X, U, it, so
+
+
+@pytest.mark.parametrize("N,fdyn,cones", [(10, True, False), (10, True, True), (50, True, True), (10, False, True)])
+def test_rocket_fdyn_cones_vs_oracle(hip_lib, oracle_built, N, fdyn, cones):
+    """Config 4's ingredients on the GPU (generic kernel) against the fp64 restatement of the same
+    construction.  Parity with the reference is UNPINNED for these (no source here): this pins the HIP
+    path to the oracle, and tests/test_extensions_cpu.py pins the oracle by properties."""
+    B = 24
+    prob = t.problems.rocket(N)
+    x0 = t.problems.rocket_x0(B, seed=2)
+    xr, ur = t.problems.rocket_refs(N)
+    kw = dict(abs_pri_tol=2e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1)   # rocket_landing_constraints.jl:61-62
+    X, U, it, so = _oracle_rocket(oracle_built, prob, x0, xr, ur, fdyn, cones, **kw)
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+    bs.update_settings(**kw)
+    bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    if fdyn:
+        bs.set_fdyn(prob.fdyn)
+    if cones:
+        bs.set_cone_constraints([0], [3], [0.25], [0], [3], [0.5])
+    assert bs.kernel_name == "generic"
+    bs.set_x_ref(xr)
+    bs.set_u_ref(ur)
+    bs.set_x0(x0)
+    bs.solve()
+    sol, st = bs.get_solution(), bs.get_status()
+    same = st["iter"] == it
+    assert same.mean() >= 0.9 and np.all(np.abs(st["iter"] - it) <= 1)
+    assert nrel_batch(sol["states"], X)[same].max() <= FP32_TOL
+    assert nrel_batch(sol["controls"], U)[same].max() <= FP32_TOL
+    # warm start of the cone pairs persists too: a second solve continues from the stored state
+    bs.solve()
+    st2 = bs.get_status()
+    assert st2["iter"].sum() < st["iter"].sum() or np.all(st2["iter"] <= st["iter"])
+    bs.close()
+
+
+def test_rocket_example_through_dropin_api(hip_lib, oracle_built):
+    """examples/rocket_landing_constraints.jl:59-69 call sequence on the process-global entry points:
+    setup with fdyn, set_bound_constraints, set_cone_constraints (inputs first), solve."""
+    N = 10
+    prob = t.problems.rocket(N)
+    s = t.TinyMPCSolver()
+    t.setup(s, prob.A, prob.B, prob.fdyn, prob.Q, prob.R, 1.0, 6, 3, N, max_iter=100, abs_pri_tol=2e-3,
+            abs_dua_tol=1e-3)
+    t.set_bound_constraints(s, prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    t.set_cone_constraints(s, [0], [3], [0.25], [0], [3], [0.5])
+    xr, ur = t.problems.rocket_refs(N)
+    x0 = 1.1 * prob.extra["xinit"]
+    t.set_x0(s, x0)
+    t.set_x_ref(s, xr)
+    t.set_u_ref(s, ur)
+    status = t.solve(s)
+    sol, st = t.get_solution(s), t.get_status(s)
+    X, U, it, so = _oracle_rocket(oracle_built, prob, x0.reshape(6, 1), xr, ur, True, True, abs_pri_tol=2e-3,
+                                  abs_dua_tol=1e-3, max_iter=100, check_termination=1)
+    assert status == 1 - int(so[0]) and int(st["iter"][0]) == int(it[0])
+    assert nrel(sol["states"], X[:, :, 0]) <= FP32_TOL and nrel(sol["controls"], U[:, :, 0]) <= FP32_TOL
+    with pytest.raises(t.TinyMPCError):
+        t.set_cone_constraints(s, [2], [3], [0.25], [], [], [])      # rows 2..4 of a 3-row input: out of range
+    with pytest.raises(t.TinyMPCError):
+        t.update_settings(s, en_input_linear=True)                   # linear constraints stay refused
+    t.cleanup()
+
+
+def test_config4_full_size_properties(hip_lib):
+    """BASELINE config 4 at its size (rocket N=50, SOC + box + fdyn, batch 32 768, 100 fixed iterations):
+    no reference oracle exists, so size-independent properties only — replication (512 copies of 64
+    instances bit-identical), determinism, finiteness, box feasibility of the returned controls."""
+    B, D, N = 32768, 64, 50
+    prob = t.problems.rocket(N)
+    base = t.problems.rocket_x0(D, seed=2)
+    x0 = np.asfortranarray(np.tile(base, (1, B // D)))
+    xr, ur = t.problems.rocket_refs(N)
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+    bs.update_settings(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=100, check_termination=1)
+    bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    bs.set_fdyn(prob.fdyn)
+    bs.set_cone_constraints([0], [3], [0.25], [0], [3], [0.5])
+    bs.set_warm_start(False)
+    bs.set_x_ref(xr)
+    bs.set_u_ref(ur)
+    bs.set_x0(x0)
+    assert bs.solve() == 1
+    sol = bs.get_solution()
+    U = sol["controls"].reshape(3, N - 1, B // D, D)
+    X = sol["states"].reshape(6, N, B // D, D)
+    assert np.all(np.isfinite(U)) and np.all(np.isfinite(X))
+    assert np.array_equal(U, np.broadcast_to(U[:, :, :1, :], U.shape))
+    assert np.array_equal(X, np.broadcast_to(X[:, :, :1, :], X.shape))
+    assert U.max() <= 105.0 and U.min() >= -10.0
+    bs.solve()
+    assert np.array_equal(bs.get_solution()["controls"], sol["controls"])
+    bs.close()

@@ -15,7 +15,7 @@ namespace tmpc {
 // coefficient pack (column-major, elements of RT): A, B, Kinf, Pinf, Quu_inv, AmBKt;
 // the fp32 diagonals Qd, Rd ride at the end of the bounds pack
 struct GenericPack {
-    int oA, oB, oK, oP, oQi, oAt, len;
+    int oA, oB, oK, oP, oQi, oAt, oF, oAPf, oBPf, len;
     __host__ __device__ GenericPack(int nx, int nu) {
         oA = 0;
         oB = oA + nx * nx;
@@ -23,12 +23,16 @@ struct GenericPack {
         oP = oK + nu * nx;
         oQi = oP + nx * nx;
         oAt = oQi + nu * nu;
-        len = oAt + nx * nx;
+        oF = oAt + nx * nx;  // affine dynamics term and its Riccati-gradient images (zeros without fdyn)
+        oAPf = oF + nx;
+        oBPf = oAPf + nx;
+        len = oBPf + nu;
     }
 };
 // bounds pack: xmin[N*nx] xmax[N*nx] umin[(N-1)*nu] umax[(N-1)*nu] Qd[nx] Rd[nu]
 // scratch arrays, in units of E_x / E_u blocks of [element][batch]
-//   x q v vnew g  (5 x E_x)   then   u r d z znew y  (6 x E_u); p is a running vector
+//   x q v vnew g  (5 x E_x)   then   u r d z znew y  (6 x E_u); p is a running vector;
+//   with cones: + vc vcnew gc (3 x E_x) and zc zcnew yc (3 x E_u)
 
 __device__ __forceinline__ float gfma(float a, float b, float c) { return fmaf(a, b, c); }
 __device__ __forceinline__ double gfma(double a, double b, double c) { return fma(a, b, c); }
@@ -43,13 +47,17 @@ __global__ __launch_bounds__(256) void admm_generic_kernel(const AdmmParams P) {
     const GenericPack pk(nx, nu);
     const RT *coef = reinterpret_cast<const RT *>(P.coef);
     const RT *cA = coef + pk.oA, *cB = coef + pk.oB, *cK = coef + pk.oK, *cP = coef + pk.oP,
-             *cQi = coef + pk.oQi, *cAt = coef + pk.oAt;
+             *cQi = coef + pk.oQi, *cAt = coef + pk.oAt, *cF = coef + pk.oF, *cAPf = coef + pk.oAPf,
+             *cBPf = coef + pk.oBPf;
+    const bool soc_x = P.ncx > 0, soc_u = P.ncu > 0;
     const float *xmin = P.bounds, *xmax = P.bounds + EX, *umin = P.bounds + 2 * EX,
                 *umax = P.bounds + 2 * EX + EU, *cQd = P.bounds + 2 * EX + 2 * EU,
                 *cRd = P.bounds + 2 * EX + 2 * EU + nx;
     float *sx = P.scratch + b, *sq = sx + (long)EX * B, *sv = sq + (long)EX * B, *svn = sv + (long)EX * B, *sg = svn + (long)EX * B;
     float *su = sg + (long)EX * B, *sr = su + (long)EU * B, *sd = sr + (long)EU * B,
           *sz = sd + (long)EU * B, *szn = sz + (long)EU * B, *sy = szn + (long)EU * B;
+    float *svc = sy + (long)EU * B, *svcn = svc + (long)EX * B, *sgc = svcn + (long)EX * B;
+    float *szc = sgc + (long)EX * B, *szcn = szc + (long)EU * B, *syc = szcn + (long)EU * B;
 #define AT(arr, e) arr[(long)(e)*B]
     const float rho = P.rho;
     const bool warm = !P.cold_start;
@@ -59,6 +67,11 @@ __global__ __launch_bounds__(256) void admm_generic_kernel(const AdmmParams P) {
         AT(sv, e) = warm ? P.sv[b * EX + e] : 0.f;
         AT(svn, e) = 0.f;
         AT(sq, e) = 0.f;
+        if (soc_x) {
+            AT(svc, e) = warm ? P.svc[b * EX + e] : 0.f;
+            AT(sgc, e) = warm ? P.sgc[b * EX + e] : 0.f;
+            AT(svcn, e) = 0.f;
+        }
     }
     for (int e = 0; e < EU; ++e) {
         AT(su, e) = 0.f;
@@ -67,6 +80,11 @@ __global__ __launch_bounds__(256) void admm_generic_kernel(const AdmmParams P) {
         AT(sd, e) = warm ? P.sd[b * EU + e] : 0.f;
         AT(sy, e) = warm ? P.sy[b * EU + e] : 0.f;
         AT(sz, e) = warm ? P.sz[b * EU + e] : 0.f;
+        if (soc_u) {
+            AT(szc, e) = warm ? P.szc[b * EU + e] : 0.f;
+            AT(syc, e) = warm ? P.syc[b * EU + e] : 0.f;
+            AT(szcn, e) = 0.f;
+        }
     }
     float res0 = 0.f, res1 = 0.f, res2 = 0.f, res3 = 0.f;
     if (warm) {
@@ -98,7 +116,7 @@ __global__ __launch_bounds__(256) void admm_generic_kernel(const AdmmParams P) {
                 AT(su, k * nu + a) = (float)uv[a];
             }
             for (int r = 0; r < nx; ++r) {
-                RT acc = 0;
+                RT acc = cF[r];  // + fdyn (zero unless set)
                 for (int a = 0; a < nu; ++a) acc = gfma(cB[r + a * nx], uv[a], acc);
                 for (int j = 0; j < nx; ++j) acc = gfma(cA[r + j * nx], xv[j], acc);
                 xn[r] = acc;
@@ -120,6 +138,34 @@ __global__ __launch_bounds__(256) void admm_generic_kernel(const AdmmParams P) {
             pri_u = fmaxf(pri_u, fabsf(u - zn));
             dua_u = fmaxf(dua_u, fabsf(AT(sz, e) - zn));
         }
+        if (soc_u) {  // UNPINNED: cone slack zc = proj(u + yc), dual yc, extra -rho (zc - yc) in r
+            for (int k = 0; k < N - 1; ++k) {
+                for (int a = 0; a < nu; ++a) AT(szcn, k * nu + a) = AT(su, k * nu + a) + AT(syc, k * nu + a);
+                for (int c = 0; c < P.ncu; ++c) {
+                    const int s0 = k * nu + P.Acu[c], qd = P.qcu[c];
+                    const float mu = P.cu[c];
+                    float a2 = 0.f;
+                    for (int j = 0; j < qd - 1; ++j) a2 = fmaf(AT(szcn, s0 + j), AT(szcn, s0 + j), a2);
+                    const float an = sqrtf(a2), u0 = AT(szcn, s0 + qd - 1) * mu;
+                    if (an <= -u0) {
+                        for (int j = 0; j < qd; ++j) AT(szcn, s0 + j) = 0.f;
+                    } else if (an > u0) {
+                        const float sc = 0.5f * (1.f + u0 / an);
+                        for (int j = 0; j < qd - 1; ++j) AT(szcn, s0 + j) *= sc;
+                        AT(szcn, s0 + qd - 1) = sc * (an / mu);
+                    }
+                }
+                for (int a = 0; a < nu; ++a) {
+                    const int e = k * nu + a;
+                    const float u = AT(su, e), zc = AT(szcn, e);
+                    const float yy = (AT(syc, e) + u) - zc;
+                    AT(syc, e) = yy;
+                    AT(sr, e) -= rho * (zc - yy);
+                    pri_u = fmaxf(pri_u, fabsf(u - zc));
+                    dua_u = fmaxf(dua_u, fabsf(AT(szc, e) - zc));
+                }
+            }
+        }
         for (int e = 0; e < EX; ++e) {
             const int k = e / nx, r = e % nx;
             const float x = AT(sx, e);
@@ -132,11 +178,41 @@ __global__ __launch_bounds__(256) void admm_generic_kernel(const AdmmParams P) {
             pri_x = fmaxf(pri_x, fabsf(x - vn));
             dua_x = fmaxf(dua_x, fabsf(AT(sv, e) - vn));
         }
+        if (soc_x) {  // UNPINNED: state cones, same construction
+            for (int k = 0; k < N; ++k) {
+                for (int r = 0; r < nx; ++r) AT(svcn, k * nx + r) = AT(sx, k * nx + r) + AT(sgc, k * nx + r);
+                for (int c = 0; c < P.ncx; ++c) {
+                    const int s0 = k * nx + P.Acx[c], qd = P.qcx[c];
+                    const float mu = P.cx[c];
+                    float a2 = 0.f;
+                    for (int j = 0; j < qd - 1; ++j) a2 = fmaf(AT(svcn, s0 + j), AT(svcn, s0 + j), a2);
+                    const float an = sqrtf(a2), u0 = AT(svcn, s0 + qd - 1) * mu;
+                    if (an <= -u0) {
+                        for (int j = 0; j < qd; ++j) AT(svcn, s0 + j) = 0.f;
+                    } else if (an > u0) {
+                        const float sc = 0.5f * (1.f + u0 / an);
+                        for (int j = 0; j < qd - 1; ++j) AT(svcn, s0 + j) *= sc;
+                        AT(svcn, s0 + qd - 1) = sc * (an / mu);
+                    }
+                }
+                for (int r = 0; r < nx; ++r) {
+                    const int e = k * nx + r;
+                    const float x = AT(sx, e), vc = AT(svcn, e);
+                    const float gg = (AT(sgc, e) + x) - vc;
+                    AT(sgc, e) = gg;
+                    AT(sq, e) -= rho * (vc - gg);
+                    pri_x = fmaxf(pri_x, fabsf(x - vc));
+                    dua_x = fmaxf(dua_x, fabsf(AT(svc, e) - vc));
+                }
+            }
+        }
         for (int r = 0; r < nx; ++r) {
             const int e = (N - 1) * nx + r;
             RT acc = 0;
             for (int j = 0; j < nx; ++j) acc = gfma(cP[j + r * nx], (RT)xref(N - 1, j), acc);
-            xn[r] = -acc - (RT)(rho * (AT(svn, e) - AT(sg, e)));  // p_{N-1}
+            float tail = rho * (AT(svn, e) - AT(sg, e));
+            if (soc_x) tail += rho * (AT(svcn, e) - AT(sgc, e));
+            xn[r] = -acc - (RT)tail;  // p_{N-1}
         }
         it += 1;
         // termination_condition — admm.cpp:89-107
@@ -153,12 +229,16 @@ __global__ __launch_bounds__(256) void admm_generic_kernel(const AdmmParams P) {
         }
         for (int e = 0; e < EX; ++e) AT(sv, e) = AT(svn, e);
         for (int e = 0; e < EU; ++e) AT(sz, e) = AT(szn, e);
+        if (soc_x)
+            for (int e = 0; e < EX; ++e) AT(svc, e) = AT(svcn, e);
+        if (soc_u)
+            for (int e = 0; e < EU; ++e) AT(szc, e) = AT(szcn, e);
         // backward_pass_grad — admm.cpp:13-20
         for (int j = 0; j < nx; ++j) xv[j] = xn[j];  // running p, kept in RT
         for (int k = N - 2; k >= 0; --k) {
             for (int a = 0; a < nu; ++a) {
                 rv[a] = (RT)AT(sr, k * nu + a);
-                RT acc = rv[a];
+                RT acc = rv[a] + cBPf[a];
                 for (int j = 0; j < nx; ++j) acc = gfma(cB[j + a * nx], xv[j], acc);
                 t[a] = acc;
             }
@@ -168,7 +248,7 @@ __global__ __launch_bounds__(256) void admm_generic_kernel(const AdmmParams P) {
                 AT(sd, k * nu + a) = (float)acc;
             }
             for (int r = 0; r < nx; ++r) {
-                RT ap = (RT)AT(sq, k * nx + r), kr = 0;
+                RT ap = (RT)AT(sq, k * nx + r) + cAPf[r], kr = 0;
                 for (int j = 0; j < nx; ++j) ap = gfma(cAt[r + j * nx], xv[j], ap);
                 for (int a = 0; a < nu; ++a) kr = gfma(cK[a + r * nu], rv[a], kr);
                 xn[r] = ap - kr;
@@ -194,6 +274,16 @@ __global__ __launch_bounds__(256) void admm_generic_kernel(const AdmmParams P) {
             P.sz[b * EU + e] = AT(sz, e);
             P.sd[b * EU + e] = AT(sd, e);
         }
+        if (soc_x)
+            for (int e = 0; e < EX; ++e) {
+                P.sgc[b * EX + e] = AT(sgc, e);
+                P.svc[b * EX + e] = AT(svc, e);
+            }
+        if (soc_u)
+            for (int e = 0; e < EU; ++e) {
+                P.syc[b * EU + e] = AT(syc, e);
+                P.szc[b * EU + e] = AT(szc, e);
+            }
     }
     atomicMax(&P.gstat[0], __float_as_uint(res0));
     atomicMax(&P.gstat[1], __float_as_uint(res1));

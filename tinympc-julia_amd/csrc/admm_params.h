@@ -55,6 +55,12 @@ struct AdmmParams {
     float *mpc_u;    // [B][steps][nu]  control applied at each step
     int *mpc_iter;   // [B][steps]      ADMM iterations of each step, negative if it hit max_iter
     float *x0_out;   // [B][nx]         plant state after the last step (aliases x0)
+    // ---- generic kernel only: affine dynamics + second-order cones (parity UNPINNED) ----
+    int has_fdyn;            // coef pack carries fdyn, APf, BPf behind the matrices
+    int ncx, ncu;            // number of state / input cones per knot (0: disabled), at most 8 each
+    int Acx[8], qcx[8], Acu[8], qcu[8];  // first row and dimension of each cone block
+    float cx[8], cu[8];                  // mu of each cone: ||head|| <= mu * (last row)
+    float *sgc, *svc, *syc, *szc;        // warm-start state of the cone slack/dual pairs
 };
 
 }  // namespace tmpc

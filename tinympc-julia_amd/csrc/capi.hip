@@ -92,10 +92,30 @@ int tinympc_update_settings(tinympc_solver *s, double abs_pri_tol, double abs_du
     return 0;
 }
 
+int tinympc_enable_cones(tinympc_solver *s, int en_state_soc, int en_input_soc) {
+    if (!s) return -1;
+    s->s.st.en_state_soc = en_state_soc ? 1 : 0;
+    s->s.st.en_input_soc = en_input_soc ? 1 : 0;
+    return 0;
+}
+
 int tinympc_set_bound_constraints(tinympc_solver *s, const double *x_min, const double *x_max,
                                   const double *u_min, const double *u_max) {
     if (!s || !x_min || !x_max || !u_min || !u_max) return -1;
     return guarded("set_bound_constraints", [&] { return s->s.set_bounds(x_min, x_max, u_min, u_max); });
+}
+
+int tinympc_set_fdyn(tinympc_solver *s, const double *fdyn) {
+    if (!s) return -1;
+    return guarded("set_fdyn", [&] { return s->s.set_fdyn(fdyn); });
+}
+
+int tinympc_set_cone_constraints(tinympc_solver *s, const int *Acu, const int *qcu, const double *cu,
+                                 int n_input_cones, const int *Acx, const int *qcx, const double *cx,
+                                 int n_state_cones) {
+    if (!s || n_input_cones < 0 || n_state_cones < 0) return -1;
+    return guarded("set_cone_constraints",
+                   [&] { return s->s.set_cones(Acu, qcu, cu, n_input_cones, Acx, qcx, cx, n_state_cones); });
 }
 
 int tinympc_set_cache_terms(tinympc_solver *s, const double *Kinf, const double *Pinf,
@@ -296,16 +316,18 @@ int setup_solver(double *A_data, int A_rows, int A_cols, double *B_data, int B_r
             g_solver.reset();
             return -1;
         }
-        if (fdyn_data)
-            for (long i = 0; i < (long)fdyn_rows * fdyn_cols; ++i)
-                if (fdyn_data[i] != 0.0) {
-                    set_error("setup_solver: non-zero fdyn (affine dynamics) is not supported: that term "
-                              "exists only in the un-vendored TinyMPC submodule");
-                    g_solver.reset();
-                    return -1;
-                }
+        if (fdyn_data && (long)fdyn_rows * fdyn_cols != nx) {
+            set_error("setup_solver: fdyn must have nx entries");
+            g_solver.reset();
+            return -1;
+        }
         tinympc_solver *s = nullptr;
         if (tinympc_create(&s, A_data, B_data, Q_data, R_data, rho, nx, nu, N, 1, -1, verbose)) {
+            g_solver.reset();
+            return -1;
+        }
+        if (fdyn_data && tinympc_set_fdyn(s, fdyn_data)) {
+            tinympc_destroy(s);
             g_solver.reset();
             return -1;
         }
@@ -380,10 +402,11 @@ int update_settings(double abs_pri_tol, double abs_dua_tol, int max_iter, int ch
     (void)adaptive_rho_enable_clipping;
     (void)verbose;
     if (need_global("update_settings")) return -1;
-    if (en_state_soc || en_input_soc || en_state_linear || en_input_linear) {
-        set_error("update_settings: SOC / linear constraints are not supported (submodule-only arithmetic)");
+    if (en_state_linear || en_input_linear) {
+        set_error("update_settings: linear constraints are not supported (submodule-only arithmetic)");
         return -1;
     }
+    tinympc_enable_cones(g_solver.get(), en_state_soc, en_input_soc);
     if (adaptive_rho) {
         set_error("update_settings: adaptive_rho is not supported (out of scope, SURVEY.md §2 #7)");
         return -1;
@@ -457,14 +480,15 @@ int set_linear_constraints(double *Alin_x_data, int Alin_x_rows, int Alin_x_cols
 int set_cone_constraints(int *Acu_data, int Acu_len, int *qcu_data, int qcu_len, double *cu_data,
                          int cu_len, int *Acx_data, int Acx_len, int *qcx_data, int qcx_len,
                          double *cx_data, int cx_len, int verbose) {
-    (void)Acu_data; (void)qcu_data; (void)cu_data; (void)Acx_data; (void)qcx_data; (void)cx_data;
     (void)verbose;
     if (need_global("set_cone_constraints")) return -1;
-    if ((Acu_len > 0 && qcu_len > 0 && cu_len > 0) || (Acx_len > 0 && qcx_len > 0 && cx_len > 0)) {
-        set_error("set_cone_constraints: not supported (arithmetic lives only in the absent TinyMPC submodule)");
+    if (Acu_len != qcu_len || Acu_len != cu_len || Acx_len != qcx_len || Acx_len != cx_len) {
+        set_error("set_cone_constraints: Ac, qc and c of one side must have the same length");
         return -1;
     }
-    return 0;
+    // bindings.cpp:478-483: the flags of the non-empty halves are switched on
+    return tinympc_set_cone_constraints(g_solver.get(), Acu_data, qcu_data, cu_data, Acu_len, Acx_data,
+                                        qcx_data, cx_data, Acx_len);
 }
 
 int get_status(int *iter, int *solved, double *residuals4) {

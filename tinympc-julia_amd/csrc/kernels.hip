@@ -73,6 +73,21 @@ static void fill_generic_coef(const Solver &sv, std::vector<unsigned char> &out)
         }
     for (int a = 0; a < nu; ++a)
         for (int b2 = 0; b2 < nu; ++b2) put(pk.oQi + a + b2 * nu, c.Quu_inv(a, b2));
+    // affine dynamics (UNPINNED): f, APf = AmBKt Pinf f, BPf = B^T Pinf f, all formed in fp64
+    std::vector<double> Pf(nx, 0.0);
+    for (int i = 0; i < nx; ++i)
+        for (int l = 0; l < nx; ++l) Pf[i] += c.Pinf(i, l) * sv.fdyn[l];
+    for (int i = 0; i < nx; ++i) {
+        double apf = 0.0;
+        for (int j = 0; j < nx; ++j) apf += c.AmBKt(i, j) * Pf[j];
+        put(pk.oF + i, sv.fdyn[i]);
+        put(pk.oAPf + i, apf);
+    }
+    for (int a = 0; a < nu; ++a) {
+        double bpf = 0.0;
+        for (int j = 0; j < nx; ++j) bpf += sv.B(j, a) * Pf[j];
+        put(pk.oBPf + a, bpf);
+    }
 }
 
 void build_generic_coef(const Solver &sv, std::vector<unsigned char> &out) {

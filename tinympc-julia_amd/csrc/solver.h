@@ -35,6 +35,7 @@ struct Settings {
     int max_iter = 100;                              // TinyMPC.jl:59
     int check_termination = 1;                       // TinyMPC.jl:59,202
     int en_state_bound = 0, en_input_bound = 0;      // TinyMPC.jl:94-95
+    int en_state_soc = 0, en_input_soc = 0;          // TinyMPC.jl:96-97 (parity unpinned)
 };
 
 struct Solver {
@@ -45,6 +46,15 @@ struct Solver {
     Settings st;
     // per-knot bounds, column-major fp64 (nx x N, nu x (N-1)); +-1e17 until set
     std::vector<double> x_min, x_max, u_min, u_max;
+    // affine dynamics term and cone constraints (parity UNPINNED: they exist only in the absent
+    // TinyMPC submodule; run on the generic kernel)
+    std::vector<double> fdyn;  // nx, all zero by default
+    bool has_fdyn = false;
+    int ncx = 0, ncu = 0;
+    int Acx[8] = {0}, qcx[8] = {0}, Acu[8] = {0}, qcu[8] = {0};
+    double cx[8] = {0}, cu[8] = {0};
+    float *d_sgc = nullptr, *d_svc = nullptr, *d_syc = nullptr, *d_szc = nullptr;
+    bool cones_active() const { return (st.en_state_soc && ncx > 0) || (st.en_input_soc && ncu > 0); }
     // references as last set by the host API: kind 0 zero / 1 shared / 2 per instance
     std::vector<float> h_xref, h_uref;
     int xref_kind = 0, uref_kind = 0;
@@ -90,6 +100,10 @@ struct Solver {
     int set_x0(const double *x0, int cols);
     int set_ref(bool is_x, const double *ref, int cols);
     int set_bounds(const double *xmin, const double *xmax, const double *umin, const double *umax);
+    int set_fdyn(const double *f);
+    int set_cones(const int *Acu_, const int *qcu_, const double *cu_, int ncu_, const int *Acx_, const int *qcx_,
+                  const double *cx_, int ncx_);
+    int ensure_extension_buffers();
     int reset();
     int solve_async(hipStream_t stream, int mpc_steps = 0);
     int get_mpc_log(double *x, double *u, int *iter);

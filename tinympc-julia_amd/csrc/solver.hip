@@ -67,6 +67,10 @@ void Solver::free_batch() {
     dev_free(d_sg);
     dev_free(d_sv);
     dev_free(d_scratch);
+    dev_free(d_sgc);
+    dev_free(d_svc);
+    dev_free(d_syc);
+    dev_free(d_szc);
     dev_free(d_mpc_x);
     dev_free(d_mpc_u);
     dev_free(d_mpc_iter);
@@ -103,6 +107,7 @@ int Solver::init(const double *A_, const double *B_, const double *Q_, const dou
     if (verbose)
         std::printf("tinympc_hip: setup nx=%d nu=%d N=%d rho=%g batch=%d (Riccati %d sweeps)\n", nx, nu,
                     N, rho, batch_, cache.riccati_iters);
+    fdyn.assign((size_t)nx, 0.0);
     x_min.assign((size_t)ex(), -1e17);
     x_max.assign((size_t)ex(), 1e17);
     u_min.assign((size_t)eu(), -1e17);
@@ -122,6 +127,7 @@ int Solver::select_kernel() {
     const char *genv = std::getenv("TINYMPC_HIP_GROUP");
     const KernelEntry *k = genv ? find_quad_kernel(nx, nu, N, std::atoi(genv)) : nullptr;
     if (!k) k = select_quad_kernel(nx, nu, N, batch);
+    if (has_fdyn || cones_active()) k = nullptr;  // affine term / cones: generic kernel only
     if (!k && (nx > GEN_MAX_NX || nu > GEN_MAX_NU)) {
         set_error("problem shape exceeds the generic kernel limits (nx <= 64, nu <= 32)");
         return -1;
@@ -164,10 +170,7 @@ int Solver::alloc_batch(int batch_) {
     ref_mode = REF_ZERO;
     refs_dirty = false;
     refs_device_owned = false;
-    if (!ke) {
-        scratch_cap = Bn * (5 * EX + 6 * EU);
-        if (dev_alloc(d_scratch, scratch_cap)) return -1;
-    }
+    if (ensure_extension_buffers()) return -1;
     solved_once = false;
     return reset();
 }
@@ -181,6 +184,12 @@ int Solver::reset() {
     HIP_TRY(hipMemset(d_sg, 0, Bn * EX * sizeof(float)));
     HIP_TRY(hipMemset(d_sv, 0, Bn * EX * sizeof(float)));
     HIP_TRY(hipMemset(d_res, 0, Bn * 4 * sizeof(float)));
+    if (d_sgc) {
+        HIP_TRY(hipMemset(d_sgc, 0, Bn * EX * sizeof(float)));
+        HIP_TRY(hipMemset(d_svc, 0, Bn * EX * sizeof(float)));
+        HIP_TRY(hipMemset(d_syc, 0, Bn * EU * sizeof(float)));
+        HIP_TRY(hipMemset(d_szc, 0, Bn * EU * sizeof(float)));
+    }
     return 0;
 }
 
@@ -296,8 +305,75 @@ int Solver::set_bounds(const double *xmin, const double *xmax, const double *umi
     return 0;
 }
 
+int Solver::set_fdyn(const double *f) {
+    bool nz = false;
+    for (int i = 0; i < nx; ++i) {
+        fdyn[i] = f ? f[i] : 0.0;
+        nz = nz || fdyn[i] != 0.0;
+    }
+    has_fdyn = nz;
+    packs_dirty = true;
+    return select_kernel() || ensure_extension_buffers();
+}
+
+int Solver::set_cones(const int *Acu_, const int *qcu_, const double *cu_, int ncu_, const int *Acx_,
+                      const int *qcx_, const double *cx_, int ncx_) {
+    if (ncu_ > 8 || ncx_ > 8) {
+        set_error("set_cone_constraints: at most 8 cones per knot and side");
+        return -1;
+    }
+    for (int i = 0; i < ncu_; ++i)
+        if (Acu_[i] < 0 || qcu_[i] < 2 || Acu_[i] + qcu_[i] > nu || !(cu_[i] > 0.0)) {
+            set_error("set_cone_constraints: input cone out of range (need 0 <= Ac, qc >= 2, Ac + qc <= nu, mu > 0)");
+            return -1;
+        }
+    for (int i = 0; i < ncx_; ++i)
+        if (Acx_[i] < 0 || qcx_[i] < 2 || Acx_[i] + qcx_[i] > nx || !(cx_[i] > 0.0)) {
+            set_error("set_cone_constraints: state cone out of range (need 0 <= Ac, qc >= 2, Ac + qc <= nx, mu > 0)");
+            return -1;
+        }
+    ncu = ncu_;
+    ncx = ncx_;
+    for (int i = 0; i < ncu; ++i) {
+        Acu[i] = Acu_[i];
+        qcu[i] = qcu_[i];
+        cu[i] = cu_[i];
+    }
+    for (int i = 0; i < ncx; ++i) {
+        Acx[i] = Acx_[i];
+        qcx[i] = qcx_[i];
+        cx[i] = cx_[i];
+    }
+    if (ncu > 0) st.en_input_soc = 1;  // bindings.cpp:478-483: only the non-empty halves are enabled
+    if (ncx > 0) st.en_state_soc = 1;
+    return select_kernel() || ensure_extension_buffers();
+}
+
+// Scratch and cone warm-start buffers of the generic kernel, sized for the current batch / options.
+int Solver::ensure_extension_buffers() {
+    if (ke) return 0;
+    HIP_TRY(hipSetDevice(device));
+    const size_t Bn = (size_t)batch, EX = (size_t)ex(), EU = (size_t)eu();
+    const size_t need = Bn * (cones_active() ? (8 * EX + 9 * EU) : (5 * EX + 6 * EU));
+    if (scratch_cap < need) {
+        if (dev_alloc(d_scratch, need)) return -1;
+        scratch_cap = need;
+    }
+    if (cones_active() && !d_sgc) {
+        if (dev_alloc(d_sgc, Bn * EX) || dev_alloc(d_svc, Bn * EX) || dev_alloc(d_syc, Bn * EU) ||
+            dev_alloc(d_szc, Bn * EU))
+            return -1;
+        HIP_TRY(hipMemset(d_sgc, 0, Bn * EX * sizeof(float)));
+        HIP_TRY(hipMemset(d_svc, 0, Bn * EX * sizeof(float)));
+        HIP_TRY(hipMemset(d_syc, 0, Bn * EU * sizeof(float)));
+        HIP_TRY(hipMemset(d_szc, 0, Bn * EU * sizeof(float)));
+    }
+    return 0;
+}
+
 int Solver::solve_async(hipStream_t stream, int mpc_steps) {
     HIP_TRY(hipSetDevice(device));
+    if (select_kernel() || ensure_extension_buffers()) return -1;
     if (mpc_steps > 0) {
         if (!ke) {
             set_error("mpc_rollout: this problem shape has no specialised kernel (generic path does plain solves only)");
@@ -352,6 +428,21 @@ int Solver::solve_async(hipStream_t stream, int mpc_steps) {
     P.mpc_u = d_mpc_u;
     P.mpc_iter = d_mpc_iter;
     P.x0_out = d_x0;
+    P.has_fdyn = has_fdyn ? 1 : 0;
+    P.ncx = st.en_state_soc ? ncx : 0;
+    P.ncu = st.en_input_soc ? ncu : 0;
+    for (int i = 0; i < 8; ++i) {
+        P.Acx[i] = Acx[i];
+        P.qcx[i] = qcx[i];
+        P.cx[i] = (float)cx[i];
+        P.Acu[i] = Acu[i];
+        P.qcu[i] = qcu[i];
+        P.cu[i] = (float)cu[i];
+    }
+    P.sgc = d_sgc;
+    P.svc = d_svc;
+    P.syc = d_syc;
+    P.szc = d_szc;
     HIP_TRY(hipMemsetAsync(d_gstat, 0, GSTAT_WORDS * sizeof(uint32_t), stream));
     if (profiling) {
         if (!ev0) HIP_TRY(hipEventCreate(&ev0));

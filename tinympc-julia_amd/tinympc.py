@@ -70,6 +70,9 @@ SIGNATURES = {
     "tinympc_set_bound_constraints": (c_int, [c_vp, c_dp, c_dp, c_dp, c_dp]),
     "tinympc_set_cache_terms": (c_int, [c_vp, c_dp, c_dp, c_dp, c_dp]),
     "tinympc_get_cache_terms": (c_int, [c_vp, c_dp, c_dp, c_dp, c_dp]),
+    "tinympc_set_fdyn": (c_int, [c_vp, c_dp]),
+    "tinympc_set_cone_constraints": (c_int, [c_vp, c_ip, c_ip, c_dp, c_int, c_ip, c_ip, c_dp, c_int]),
+    "tinympc_enable_cones": (c_int, [c_vp, c_int, c_int]),
     "tinympc_set_x0": (c_int, [c_vp, c_dp, c_int]),
     "tinympc_set_x_ref": (c_int, [c_vp, c_dp, c_int]),
     "tinympc_set_u_ref": (c_int, [c_vp, c_dp, c_int]),
@@ -318,7 +321,7 @@ def set_linear_constraints(solver, Alin_x, blin_x, Alin_u, blin_u, *, verbose=Fa
 
 
 def set_cone_constraints(solver, Acu, qcu, cu, Acx, qcx, cx, *, verbose=False):
-    """TinyMPC.jl:245-259.  Only empty cone lists are accepted (parity unpinned)."""
+    """TinyMPC.jl:245-259.  Per-knot second-order cones, inputs first; parity unpinned."""
     ia = [np.asarray(a, dtype=np.int32) for a in (Acu, qcu, Acx, qcx)]
     da = [np.asarray(a, dtype=np.float64) for a in (cu, cx)]
     status = load_library().set_cone_constraints(
@@ -412,6 +415,19 @@ class BatchSolver:
     def set_cache_terms(self, Kinf, Pinf, Quu_inv, AmBKt):
         ms = [_mat(m) for m in (Kinf, Pinf, Quu_inv, AmBKt)]
         self._chk(self.lib.tinympc_set_cache_terms(self.h, *[_dp(m) for m in ms]), "set_cache_terms")
+
+    def set_fdyn(self, fdyn):
+        """affine dynamics term x+ = A x + B u + f (parity unpinned; generic kernel)"""
+        f = np.ascontiguousarray(np.asarray(fdyn, dtype=np.float64).reshape(-1))
+        self._chk(self.lib.tinympc_set_fdyn(self.h, _dp(f)), "set_fdyn")
+
+    def set_cone_constraints(self, Acu, qcu, cu, Acx, qcx, cx):
+        """per-knot second-order cones, inputs first (TinyMPC.jl:245-259 argument order); parity unpinned"""
+        ia = [np.ascontiguousarray(np.asarray(a, dtype=np.int32)) for a in (Acu, qcu, Acx, qcx)]
+        da = [np.ascontiguousarray(np.asarray(a, dtype=np.float64)) for a in (cu, cx)]
+        self._chk(self.lib.tinympc_set_cone_constraints(
+            self.h, ia[0].ctypes.data_as(c_ip), ia[1].ctypes.data_as(c_ip), _dp(da[0]), len(da[0]),
+            ia[2].ctypes.data_as(c_ip), ia[3].ctypes.data_as(c_ip), _dp(da[1]), len(da[1])), "set_cone_constraints")
 
     def get_cache_terms(self):
         nx, nu = self.nx, self.nu
