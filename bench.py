@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="cartpole", choices=["cartpole", "quadrotor", "rocket"])
+    ap.add_argument("--config", default="cartpole", choices=["cartpole", "quadrotor", "rocket", "rocket_soc"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--precision", type=int, default=0, help="0: fp64 recurrences (default), 1: all fp32")
@@ -64,6 +64,8 @@ def make_workload(t, name, batch, rank):
         x0 = P.rocket_x0(batch, seed=2 + 1000 * rank)
         refs = P.rocket_refs(50)
         label = "rocket nx=6 nu=3 N=50 box-only sub-problem (no fdyn/SOC), batch=32768/GPU, fixed 100 iters"
+        if name == "rocket_soc":
+            label = "rocket nx=6 nu=3 N=50 SOC thrust/glide cones + box + fdyn (parity unpinned), batch=32768/GPU, fixed 100 iters"
     return prob, x0, refs, label
 
 
@@ -152,12 +154,15 @@ def main():
     import tinympc_julia_amd as t
     from tinympc_julia_amd import sharding
 
-    batch = args.batch or (32768 if args.config == "rocket" else 65536)
+    batch = args.batch or (32768 if args.config.startswith("rocket") else 65536)
     prob, x0, refs, label = make_workload(t, args.config, batch, rank)
     bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=batch, device=local_rank)
     bs.update_settings(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=args.iters, check_termination=1)
     bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
     bs.set_precision(args.precision)
+    if args.config == "rocket_soc":
+        bs.set_fdyn(prob.fdyn)
+        bs.set_cone_constraints([0], [3], [prob.extra["cone_mu_u"]], [0], [3], [prob.extra["cone_mu_x"]])
     bs.set_warm_start(False)          # cold start, no state I/O: compulsory traffic only
     bs.set_x0(x0)                     # H2D once; inputs stay resident in HBM
     if refs is not None:
@@ -231,7 +236,7 @@ def main():
         }
         if args.mode == "mpc" and world == 1:
             out["mpc_closed_loop"] = run_mpc_mode(args, t, bs, prob, x0, dev, stream, torch)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config != "rocket_soc":
             out["cpu_baseline"] = cpu_baseline(prob, x0, refs, args.iters, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     bs.close()

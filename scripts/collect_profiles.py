@@ -1,0 +1,33 @@
+"""Copy the rocprofv3 summaries of scripts/profile_round.sh from gpurun_out/ into profiles/ and rebuild
+profiles/traffic.json (HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB, per the gfx950 guide)."""
+import csv, glob, json, os, shutil, sys
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+traffic = []
+for cfg in ("cartpole", "quadrotor"):
+    ks = sorted(glob.glob(f"{root}/gpurun_out/prof_{tag}_{cfg}/*/*_kernel_stats.csv"), key=os.path.getmtime)
+    if not ks:
+        continue
+    shutil.copy(ks[-1], f"{root}/profiles/{tag}_{cfg}_kernel_stats.csv")
+    vals = {}
+    for kind, ctr in (("F", "FETCH_SIZE"), ("W", "WRITE_SIZE")):
+        f = sorted(glob.glob(f"{root}/gpurun_out/pmc{kind}_{tag}_{cfg}/*/*_counter_collection.csv"), key=os.path.getmtime)[-1]
+        rows = [r for r in csv.DictReader(open(f)) if "admm" in r["Kernel_Name"]]
+        vals[ctr] = sum(float(r["Counter_Value"]) for r in rows) / len(rows)
+        kname = rows[0]["Kernel_Name"]
+        with open(f"{root}/profiles/{tag}_{cfg}_pmc_{ctr.lower()}.csv", "w") as g:
+            w = csv.writer(g)
+            w.writerow(["Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "Counter_Name", "Counter_Value"])
+            for r in rows:
+                w.writerow([r[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "Counter_Name", "Counter_Value")])
+    log = open(f"{root}/gpurun_out/prof_{tag}_{cfg}.log").read()
+    line = [l for l in log.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    traffic.append({"family": cfg, "precision": 0, "batch": d["config"]["batch_per_gpu"], "kernel": d["config"]["kernel"],
+                    "FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"],
+                    "hbm_bytes_per_launch": (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
+                    "algorithmic_bytes_per_launch": d["roofline"]["algorithmic_bytes_per_launch"],
+                    "rocprof_kernel": kname,
+                    "note": "rocprofv3 --pmc, separate passes; FETCH_SIZE doubled (gfx950 reports half of a coalesced read stream)"})
+json.dump(traffic, open(f"{root}/profiles/traffic.json", "w"), indent=1)
+print(json.dumps(traffic, indent=1))

@@ -44,6 +44,10 @@
 #define TMPC_COEF_LDS_THRESHOLD_G1 100000
 #endif
 
+#ifndef TMPC_FENCE_LDS_MATVEC
+#define TMPC_FENCE_LDS_MATVEC 0
+#endif
+
 namespace tmpc {
 
 // G = lanes per problem instance (a "group"): 4 = one DPP quad, 2 = half a quad, 1 = one lane.
@@ -263,11 +267,16 @@ __device__ __forceinline__ void quad_matvec(RT (&acc)[ROWS], const CP C, const R
                     acc[m] = tfma((RT)C[m * CW + S * SK + k], xv, acc[m]);
             }
         }
+        if constexpr (!std::is_pointer<CP>::value && TMPC_FENCE_LDS_MATVEC == 2) __builtin_amdgcn_sched_barrier(0);
     });
     if constexpr (SPLIT) {
 #pragma unroll
         for (int m = 0; m < ROWS; ++m) acc[m] += acc2[m];
     }
+    // Coefficients streamed from LDS: keep the scheduler from hoisting the NEXT product's loads above
+    // this one — at one wavefront per SIMD it front-loads every ds_read of a knot (hundreds of live
+    // VGPRs) and the kernel spills to scratch, i.e. to HBM.
+    if constexpr (!std::is_pointer<CP>::value && TMPC_FENCE_LDS_MATVEC == 1) __builtin_amdgcn_sched_barrier(0);
 }
 
 template <class S, int REFS, class RT, bool XB>
