@@ -276,9 +276,14 @@ def test_refs_shared_and_per_instance(hip_lib, oracle_built):
     bs.close()
 
 
-@pytest.mark.parametrize("shape", ["cartpole_N15", "random_3x2_N7", "rocket_N40"])
-def test_generic_kernel_vs_oracle(hip_lib, oracle_built, shape):
-    """Shapes without a specialised instantiation run on the generic HIP kernel (never on the CPU)."""
+@pytest.mark.parametrize("shape,kernel", [("cartpole_N15", "stream<4,1>"), ("random_3x2_N7", "stream<3,2>"),
+                                          ("rocket_N40", "stream<6,3>"), ("random_5x2_N9", "generic"),
+                                          ("cartpole_N15", "generic")])
+def test_fallback_kernels_vs_oracle(hip_lib, oracle_built, monkeypatch, shape, kernel):
+    """Shapes without a specialised (unrolled) instantiation run on the run-time-horizon stream kernel,
+    and (nx, nu) outside its grid on the generic kernel — always on the GPU, never on the CPU."""
+    if kernel == "generic" and shape == "cartpole_N15":
+        monkeypatch.setenv("TINYMPC_HIP_NO_STREAM", "1")
     rng = np.random.default_rng(11)
     B = 70
     xref = uref = None
@@ -290,16 +295,17 @@ def test_generic_kernel_vs_oracle(hip_lib, oracle_built, shape):
         x0 = t.problems.rocket_x0(B, seed=2)
         xref, uref = t.problems.rocket_refs(40)
     else:
-        A = np.eye(3) + 0.1 * rng.standard_normal((3, 3))
-        Bm = rng.standard_normal((3, 2))
-        prob = t.problems.Problem("rand", A, Bm, np.diag([5.0, 2.0, 1.0]), np.diag([1.0, 2.0]), 2.0, 7)
-        prob.x_min, prob.x_max = np.full((3, 7), -2.0), np.full((3, 7), 2.0)
-        prob.u_min, prob.u_max = np.full((2, 6), -0.3), np.full((2, 6), 0.3)
-        x0 = np.asfortranarray(rng.uniform(-1, 1, (3, B)))
+        n, Nh = (3, 7) if shape == "random_3x2_N7" else (5, 9)
+        A = np.eye(n) + 0.1 * rng.standard_normal((n, n))
+        Bm = rng.standard_normal((n, 2))
+        prob = t.problems.Problem("rand", A, Bm, np.diag([5.0, 2.0, 1.0, 3.0, 0.5][:n]), np.diag([1.0, 2.0]), 2.0, Nh)
+        prob.x_min, prob.x_max = np.full((n, Nh), -2.0), np.full((n, Nh), 2.0)
+        prob.u_min, prob.u_max = np.full((2, Nh - 1), -0.3), np.full((2, Nh - 1), 0.3)
+        x0 = np.asfortranarray(rng.uniform(-1, 1, (n, B)))
     kw = dict(abs_pri_tol=1e-4, abs_dua_tol=1e-4, max_iter=80)
     ref = _oracle_batch(oracle_built, prob, x0, xref=xref, uref=uref, **kw)
     bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
-    assert bs.kernel_name == "generic"
+    assert bs.kernel_name == kernel
     bs.update_settings(check_termination=1, **kw)
     bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
     bs.set_x0(x0)
@@ -519,7 +525,7 @@ def test_fused_mpc_rollout_batch_vs_oracle(hip_lib, oracle_built):
         x = prob.A @ x + prob.B @ u0
         assert np.abs(u0 - log["u"][:, k, :])[:, same].max() <= 3e-5 * np.abs(ref_u).max()
     # generic-path shapes refuse the fused loop instead of silently doing something else
-    pg = t.problems.cartpole(15, u_bound=0.5)
+    pg = t.problems.cartpole(15, u_bound=0.5)   # stream / generic path: plain solves only
     bg = t.BatchSolver(pg.A, pg.B, pg.Q, pg.R, pg.rho, pg.N, batch=2)
     with pytest.raises(t.TinyMPCError):
         bg.mpc_rollout(3)
@@ -638,11 +644,15 @@ def _oracle_rocket(oracle_built, prob, x0, xr, ur, fdyn, cones, **kw):
     return X, U, it, so
 
 
-@pytest.mark.parametrize("N,fdyn,cones", [(10, True, False), (10, True, True), (50, True, True), (10, False, True)])
-def test_rocket_fdyn_cones_vs_oracle(hip_lib, oracle_built, N, fdyn, cones):
+@pytest.mark.parametrize("N,fdyn,cones,kernel", [(10, True, False, "stream<6,3>"), (10, True, True, "stream<6,3>"),
+                                                 (50, True, True, "stream<6,3>"), (10, False, True, "stream<6,3>"),
+                                                 (10, True, True, "generic")])
+def test_rocket_fdyn_cones_vs_oracle(hip_lib, oracle_built, monkeypatch, N, fdyn, cones, kernel):
     """Config 4's ingredients on the GPU (generic kernel) against the fp64 restatement of the same
     construction.  Parity with the reference is UNPINNED for these (no source here): this pins the HIP
     path to the oracle, and tests/test_extensions_cpu.py pins the oracle by properties."""
+    if kernel == "generic":
+        monkeypatch.setenv("TINYMPC_HIP_NO_STREAM", "1")
     B = 24
     prob = t.problems.rocket(N)
     x0 = t.problems.rocket_x0(B, seed=2)
@@ -656,7 +666,7 @@ def test_rocket_fdyn_cones_vs_oracle(hip_lib, oracle_built, N, fdyn, cones):
         bs.set_fdyn(prob.fdyn)
     if cones:
         bs.set_cone_constraints([0], [3], [0.25], [0], [3], [0.5])
-    assert bs.kernel_name == "generic"
+    assert bs.kernel_name == kernel
     bs.set_x_ref(xr)
     bs.set_u_ref(ur)
     bs.set_x0(x0)

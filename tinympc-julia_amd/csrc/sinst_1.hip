@@ -1,0 +1,7 @@
+// stream kernel instantiations (run-time horizon) for (nx, nu) in [(3, 2), (3, 3), (4, 1)]
+#include "stream_entry.hip.h"
+namespace tmpc {
+TMPC_DEFINE_STREAM_ENTRY(3, 2)
+TMPC_DEFINE_STREAM_ENTRY(3, 3)
+TMPC_DEFINE_STREAM_ENTRY(4, 1)
+}

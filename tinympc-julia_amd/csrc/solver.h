@@ -26,6 +26,16 @@ struct KernelEntry {
 const KernelEntry *find_quad_kernel(int nx, int nu, int N, int group = -1);
 // the variant best suited to `batch` instances (nullptr: no specialised kernel for the shape)
 const KernelEntry *select_quad_kernel(int nx, int nu, int N, int batch);
+// One (nx, nu) instantiation of the run-time-horizon stream kernel (admm_stream.hip.h).
+struct StreamEntry {
+    int nx, nu;
+    const char *name;
+    void (*build_coef)(const Solver &, std::vector<unsigned char> &);
+    void (*build_bounds)(const Solver &, std::vector<float> &);
+    size_t (*lds_bytes)(int N, int precision);
+    hipError_t (*launch)(const AdmmParams &, int precision, bool ext, hipStream_t);
+};
+const StreamEntry *find_stream_kernel(int nx, int nu);
 hipError_t launch_generic(const AdmmParams &, int precision, hipStream_t);
 void build_generic_coef(const Solver &, std::vector<unsigned char> &);
 void build_generic_bounds(const Solver &, std::vector<float> &);
@@ -64,7 +74,8 @@ struct Solver {
     bool warm_start = true;
     bool packs_dirty = true;
     bool state_bounds_active = false;  // any finite (|b| < 1e17) enabled state bound
-    const KernelEntry *ke = nullptr;  // nullptr: generic kernel
+    const KernelEntry *ke = nullptr;  // specialised quad kernel, or
+    const StreamEntry *se = nullptr;  // run-time-horizon stream kernel, or (both null) the generic kernel
     std::string kernel_name;
     // device buffers
     unsigned char *d_coef = nullptr;

@@ -132,9 +132,16 @@ int Solver::select_kernel() {
         set_error("problem shape exceeds the generic kernel limits (nx <= 64, nu <= 32)");
         return -1;
     }
-    if (k != ke) packs_dirty = true;
+    // shapes / options without a quad kernel: the stream kernel for (nx, nu) if its LDS image fits
+    const StreamEntry *s2 = nullptr;
+    if (!k && !std::getenv("TINYMPC_HIP_NO_STREAM")) {
+        s2 = find_stream_kernel(nx, nu);
+        if (s2 && s2->lds_bytes(N, precision) > 150 * 1024) s2 = nullptr;
+    }
+    if (k != ke || s2 != se) packs_dirty = true;
     ke = k;
-    kernel_name = ke ? ke->name : "generic";
+    se = s2;
+    kernel_name = ke ? ke->name : (se ? se->name : "generic");
     return 0;
 }
 
@@ -206,6 +213,9 @@ int Solver::upload_packs() {
     if (ke) {
         ke->build_coef(*this, coef);
         ke->build_bounds(*this, bnd);
+    } else if (se) {
+        se->build_coef(*this, coef);
+        se->build_bounds(*this, bnd);
     } else {
         build_generic_coef(*this, coef);
         build_generic_bounds(*this, bnd);
@@ -449,7 +459,9 @@ int Solver::solve_async(hipStream_t stream, int mpc_steps) {
         if (!ev1) HIP_TRY(hipEventCreate(&ev1));
         HIP_TRY(hipEventRecord(ev0, stream));
     }
-    HIP_TRY(ke ? ke->launch(P, precision, state_bounds_active, stream) : launch_generic(P, precision, stream));
+    HIP_TRY(ke ? ke->launch(P, precision, state_bounds_active, stream)
+               : (se ? se->launch(P, precision, has_fdyn || cones_active(), stream)
+                     : launch_generic(P, precision, stream)));
     if (profiling) HIP_TRY(hipEventRecord(ev1, stream));
     HIP_TRY(hipMemcpyAsync(h_gstat, d_gstat, GSTAT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     solved_once = true;
