@@ -58,7 +58,8 @@ _ok(status, what) = status == 0 ? status : error("$what ($(_last_error()))")
     setup(solver, A, B, f, Q, R, rho, nx, nu, N; batch=1, kwargs...)
 
 Same call as the reference (src/TinyMPC.jl:55-112) plus `batch`.  The infinite-horizon Riccati
-precompute runs on the host in Float64 inside the library; `f` must be all zero.  Settings are then
+precompute runs on the host in Float64 inside the library; a non-zero `f` (affine dynamics) is honoured
+but its parity with the upstream solver is unpinned (DESIGN.md §6).  Settings are then
 pushed with every `en_*` flag false, exactly like the reference (src/TinyMPC.jl:89-104).
 """
 function setup(solver::TinyMPCSolver, A::Matrix{Float64}, B::Matrix{Float64}, f::Vector{Float64},
@@ -181,7 +182,8 @@ function set_bound_constraints(solver::TinyMPCSolver, x_min::Matrix{Float64}, x_
         "Failed to set bound constraints")
 end
 
-# Only empty blocks are accepted: linear / cone projections live in the un-vendored TinyMPC submodule.
+# Linear constraints: only empty blocks are accepted.  Cones: per-knot second-order cones, inputs first,
+# 0-based first row `Ac`, dimension `qc`, slope `c` (last row of the block is the axis); parity unpinned.
 function set_linear_constraints(solver::TinyMPCSolver, Alin_x::Matrix{Float64}, blin_x::Vector{Float64},
                                 Alin_u::Matrix{Float64}, blin_u::Vector{Float64}; verbose::Bool=false)
     _ok(ccall((:set_linear_constraints, _lib_path()), Int32,
