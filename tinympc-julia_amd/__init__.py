@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtinympc_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tinympc_hip.h")
 
 
-def build(jobs=4, verbose=False):
+def build(jobs=8, verbose=False):
     """Compile csrc/ for gfx950 with hipcc into lib/libtinympc_hip.so (cross-compiles without a GPU)."""
     cmd = ["make", "-C", os.path.join(_HERE, "csrc"), f"-j{jobs}"]
     if not verbose:

@@ -53,8 +53,11 @@ namespace tmpc {
 // G = lanes per problem instance (a "group"): 4 = one DPP quad, 2 = half a quad, 1 = one lane.
 // BUD64 / BUD32: register budget per lane (fp64 / fp32 recurrences) the placement aims at when only one
 // wavefront per SIMD fits; tuned per shape on MI355X ("Where state lives").
-template <int NX_, int NU_, int N_, int G_ = 4, int BUD64_ = 380, int BUD32_ = 380>
+// LOOPV: which cheaper loop variants are built and used for one-shot solves of this shape (bit 0: vnew/znew
+// in place, bit 1: additionally no per-lane guard when nobody can converge); measured per shape.
+template <int NX_, int NU_, int N_, int G_ = 4, int BUD64_ = 380, int BUD32_ = 380, int LOOPV_ = 0>
 struct QuadShape {
+    static constexpr int LOOPV = LOOPV_;
     static_assert(G_ == 1 || G_ == 2 || G_ == 4, "group size must be 1, 2 or 4 lanes");
     static constexpr int NX = NX_, NU = NU_, N = N_, G = G_;
     static constexpr int RX = (NX + G - 1) / G, RU = (NU + G - 1) / G;
@@ -108,20 +111,24 @@ struct QuadShape {
     // to LDS ([element][thread], conflict-free) in order of how rarely an iteration touches them,
     // first to make room for two wavefronts per SIMD (<= 250 VGPRs, <= ~78 KB LDS per workgroup),
     // else to fit one wavefront per SIMD (VGPRs + AGPRs, <= ~150 KB LDS).
+    static constexpr int STATE_REGS = 3 * RX * N + 4 * RU * (N - 1);  // floats of state per lane
     enum { A_V = 0, A_Z, A_ZW, A_D, A_Y, A_W, A_G, A_COUNT };
     struct Placement {
         bool lds[A_COUNT];
         int off[A_COUNT];  // float offset of the array inside the LDS state block, per thread-stride
         int lds_floats;    // floats per lane in LDS
     };
-    static constexpr int arr_size(int a) { return (a == A_V || a == A_W || a == A_G) ? RX * N : RU * (N - 1); }
-    template <class RT, int REFS>
+    static constexpr int arr_size(int a, bool oneshot) {
+        if (oneshot && (a == A_W || a == A_ZW)) return 0;  // vnew / znew overwrite v / z in place
+        return (a == A_V || a == A_W || a == A_G) ? RX * N : RU * (N - 1);
+    }
+    template <class RT, int REFS, bool OS>
     static constexpr Placement place() {
         Placement p{};
         const int fixed = ((coef_in_lds<RT, REFS>() || G == 1) ? 0 : coef_regs<RT, REFS>()) +  // G = 1: SGPRs
                          
                           (sizeof(RT) == 8 ? 60 : 45) + (REFS == REF_PER_INSTANCE ? RX * N + RU * (N - 1) : 0);
-        const int total = 3 * RX * N + 4 * RU * (N - 1);
+        const int total = (OS ? 2 : 3) * RX * N + (OS ? 3 : 4) * RU * (N - 1);
         // (register budget, LDS floats per lane) for 2 waves/SIMD, then 1 wave/SIMD
         const int budget[2] = {250 - fixed, (sizeof(RT) == 8 ? BUD64_ : BUD32_) - fixed};
         const int cap[2] = {78, 150};
@@ -129,17 +136,17 @@ struct QuadShape {
             int regs = total, lds = 0;
             bool sel[A_COUNT] = {};
             for (int a = 0; a < A_COUNT && regs > budget[pass]; ++a) {
-                if (lds + arr_size(a) > cap[pass]) continue;
+                if (arr_size(a, OS) == 0 || lds + arr_size(a, OS) > cap[pass]) continue;
                 sel[a] = true;
-                regs -= arr_size(a);
-                lds += arr_size(a);
+                regs -= arr_size(a, OS);
+                lds += arr_size(a, OS);
             }
             if (regs <= budget[pass] || pass == 1) {
                 int o = 0;
                 for (int a = 0; a < A_COUNT; ++a) {
                     p.lds[a] = sel[a];
                     p.off[a] = o;
-                    if (sel[a]) o += arr_size(a);
+                    if (sel[a]) o += arr_size(a, OS);
                 }
                 p.lds_floats = lds;
                 return p;
@@ -279,14 +286,20 @@ __device__ __forceinline__ void quad_matvec(RT (&acc)[ROWS], const CP C, const R
     if constexpr (!std::is_pointer<CP>::value && TMPC_FENCE_LDS_MATVEC == 1) __builtin_amdgcn_sched_barrier(0);
 }
 
-template <class S, int REFS, class RT, bool XB>
+// OS ("one shot"): cold start and no workspace kept (the benchmark configs).  vnew / znew then overwrite
+// v / z in place — the separate copies only exist to reproduce what the reference leaves in its
+// workspace after a converged exit (admm.cpp:181-197) — which removes E_x + E_u floats of state per
+// instance.  Same arithmetic, same results.
+// UNI ("uniform"): additionally no instance can converge (fixed-iteration solves): see the loop body.
+template <class S, int REFS, class RT, bool XB, bool OS, bool UNI>
 __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
+    static_assert(!UNI || OS, "the uniform variant is only built for one-shot solves");
     constexpr int NX = S::NX, NU = S::NU, N = S::N, G = S::G;
     constexpr int RX = S::RX, RU = S::RU, NXP = S::NXP, NUP = S::NUP;
     constexpr int NXL = S::NXL, NUL = S::NUL;
     constexpr int EX = NX * N, EU = NU * (N - 1);
     constexpr bool COEF_LDS = S::template coef_in_lds<RT, REFS>();
-    constexpr auto PL = S::template place<RT, REFS>();
+    constexpr auto PL = S::template place<RT, REFS, OS>();
     constexpr int STATE_LEN = PL.lds_floats > 0 ? PL.lds_floats * S::THREADS : 1;
     constexpr int T = S::THREADS;
     constexpr bool UREP = S::UREP;
@@ -370,13 +383,29 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
         else name##_reg[k][m] = val;                                                            \
     };
     TMPC_STATE_ARRAY(g, A_G, N, RX)        // state dual
-    TMPC_STATE_ARRAY(w, A_W, N, RX)        // vnew
     TMPC_STATE_ARRAY(v, A_V, N, RX)        // v (previous slack)
     TMPC_STATE_ARRAY(y, A_Y, N - 1, RU)    // input dual
-    TMPC_STATE_ARRAY(zw, A_ZW, N - 1, RU)  // znew
     TMPC_STATE_ARRAY(z, A_Z, N - 1, RU)    // z (previous slack)
     TMPC_STATE_ARRAY(d, A_D, N - 1, RU)    // feed-forward
+    TMPC_STATE_ARRAY(wx, A_W, OS ? 1 : N, RX)        // vnew  (own storage unless OS)
+    TMPC_STATE_ARRAY(zx, A_ZW, OS ? 1 : N - 1, RU)   // znew  (own storage unless OS)
 #undef TMPC_STATE_ARRAY
+    auto w_get = [&](int k, int m) -> float {
+        if constexpr (OS) return v_get(k, m);
+        else return wx_get(k, m);
+    };
+    auto w_set = [&](int k, int m, float val) {
+        if constexpr (OS) v_set(k, m, val);
+        else wx_set(k, m, val);
+    };
+    auto zw_get = [&](int k, int m) -> float {
+        if constexpr (OS) return z_get(k, m);
+        else return zx_get(k, m);
+    };
+    auto zw_set = [&](int k, int m, float val) {
+        if constexpr (OS) z_set(k, m, val);
+        else zx_set(k, m, val);
+    };
     RT x0[RX];  // plant state; RT so a fused closed loop does not round it to fp32 every step
     float xr[REFS == REF_PER_INSTANCE ? N : 1][RX];
     float ur[REFS == REF_PER_INSTANCE ? N - 1 : 1][RU];
@@ -661,7 +690,8 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
     };
 
     for (int i = 0; i < P.max_iter; ++i) {
-        if (active && !conv) {
+        // One ADMM iteration of this lane's instance.
+        auto iterate = [&]() {
             bool check = false;
             if (ct > 0) {
                 if (--ct_count == 0) {
@@ -686,14 +716,29 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
                 res1 = group_max<G>(dua_x) * rho;
                 res2 = group_max<G>(pri_u);
                 res3 = group_max<G>(dua_u) * rho;
-                if (res0 < P.abs_pri_tol && res2 < P.abs_pri_tol && res1 < P.abs_dua_tol &&
-                    res3 < P.abs_dua_tol)
-                    conv = 1;
+                if constexpr (!UNI) {
+                    if (res0 < P.abs_pri_tol && res2 < P.abs_pri_tol && res1 < P.abs_dua_tol &&
+                        res3 < P.abs_dua_tol)
+                        conv = 1;
+                }
             }
-            if (!conv) backward_sweep();
+            if constexpr (UNI)
+                backward_sweep();
+            else if (!conv)
+                backward_sweep();
+        };
+        if constexpr (UNI) {
+            // No instance can converge (a tolerance is <= 0): every lane runs every iteration, so the
+            // body is straight-line code for the whole wavefront.  With the per-lane guard below, each
+            // loop-carried trajectory value needs a copy at the join of the divergent region — 300+
+            // moves per iteration and, worse, old and new values alive together (twice the registers).
+            // Padding lanes (b >= batch) iterate on zeros; their results are never stored.
+            iterate();
+        } else {
+            if (active && !conv) iterate();
+            // every instance of this wavefront finished?  (wave-uniform exit)
+            if (!__builtin_amdgcn_ballot_w64(active && !conv)) break;
         }
-        // every instance of this wavefront finished?  (wave-uniform exit)
-        if (!__builtin_amdgcn_ballot_w64(active && !conv)) break;
     }
     if (P.mpc_steps > 0) {
         // apply the first control to the plant model and log the step

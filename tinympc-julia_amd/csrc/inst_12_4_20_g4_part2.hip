@@ -1,0 +1,5 @@
+// part 2 of inst_12_4_20_g4: the (float, state bounds true) kernels
+#include "quad_entry.hip.h"
+namespace tmpc {
+TMPC_QUAD_PART(float, true, 12, 4, 20, 4, 380, 470)
+}

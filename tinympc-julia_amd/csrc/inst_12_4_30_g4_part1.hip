@@ -1,0 +1,5 @@
+// part 1 of inst_12_4_30_g4: the (double, state bounds false) kernels
+#include "quad_entry.hip.h"
+namespace tmpc {
+TMPC_QUAD_PART(double, false, 12, 4, 30, 4, 380, 470)
+}
