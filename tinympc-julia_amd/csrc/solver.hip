@@ -4,7 +4,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
+#include <thread>
 
 
 namespace tmpc {
@@ -24,6 +26,36 @@ bool hip_ok(hipError_t e, const char *what) {
     do {                                    \
         if (!hip_ok((expr), #expr)) return -1; \
     } while (0)
+
+// fp32 <-> fp64 conversion of the host-side staging buffers, spread over a few threads: at batch 65 536
+// a solution is 6.5 M elements and a single-threaded loop costs more than the kernel that produced it.
+template <class F>
+static void parallel_chunks(size_t n, F &&f) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t nt = n < (1u << 16) ? 1 : std::min<size_t>(hw ? hw : 1, 16);
+    if (nt <= 1) {
+        f((size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    const size_t chunk = (n + nt - 1) / nt;
+    for (size_t t = 1; t < nt; ++t) {
+        const size_t lo = t * chunk, hi = std::min(n, lo + chunk);
+        if (lo < hi) th.emplace_back([=, &f] { f(lo, hi); });
+    }
+    f((size_t)0, std::min(n, chunk));
+    for (auto &x : th) x.join();
+}
+static void widen(const float *src, double *dst, size_t n) {
+    parallel_chunks(n, [=](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) dst[i] = (double)src[i];
+    });
+}
+static void narrow(const double *src, float *dst, size_t n) {
+    parallel_chunks(n, [=](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) dst[i] = (float)src[i];
+    });
+}
 
 template <class T>
 static int dev_alloc(T *&p, size_t n) {
@@ -510,7 +542,7 @@ int Solver::get_traj(bool states, double *buf) {
     const size_t n = (size_t)batch * (states ? ex() : eu());
     std::vector<float> h(n);
     HIP_TRY(hipMemcpy(h.data(), states ? d_xout : d_uout, n * sizeof(float), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < n; ++i) buf[i] = (double)h[i];
+    widen(h.data(), buf, n);
     return 0;
 }
 
@@ -531,13 +563,13 @@ static int d2h_double(const float *d, double *out, size_t n) {
     if (!out) return 0;
     std::vector<float> h(n);
     HIP_TRY(hipMemcpy(h.data(), d, n * sizeof(float), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < n; ++i) out[i] = (double)h[i];
+    widen(h.data(), out, n);
     return 0;
 }
 static int h2d_float(float *d, const double *in, size_t n) {
     if (!in) return 0;
     std::vector<float> h(n);
-    for (size_t i = 0; i < n; ++i) h[i] = (float)in[i];
+    narrow(in, h.data(), n);
     HIP_TRY(hipMemcpy(d, h.data(), n * sizeof(float), hipMemcpyHostToDevice));
     return 0;
 }
