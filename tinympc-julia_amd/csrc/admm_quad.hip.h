@@ -127,7 +127,8 @@ struct QuadShape {
         Placement p{};
         const int fixed = ((coef_in_lds<RT, REFS>() || G == 1) ? 0 : coef_regs<RT, REFS>()) +  // G = 1: SGPRs
                          
-                          (sizeof(RT) == 8 ? 60 : 45) + (REFS == REF_PER_INSTANCE ? RX * N + RU * (N - 1) : 0);
+                          (G == 1 ? 150 : (sizeof(RT) == 8 ? 60 : 45)) +  // working registers of a knot
+                          (REFS == REF_PER_INSTANCE ? RX * N + RU * (N - 1) : 0);
         const int total = (OS ? 2 : 3) * RX * N + (OS ? 3 : 4) * RU * (N - 1);
         // (register budget, LDS floats per lane) for 2 waves/SIMD, then 1 wave/SIMD
         const int budget[2] = {250 - fixed, (sizeof(RT) == 8 ? BUD64_ : BUD32_) - fixed};

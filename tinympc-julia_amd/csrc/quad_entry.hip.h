@@ -123,9 +123,9 @@ hipError_t launch_quad_rt(const AdmmParams &P, hipStream_t stream) {
         const bool oneshot = P.cold_start && !P.save_state && P.mpc_steps == 0;
         const bool uniform = oneshot && !(P.abs_pri_tol > 0.f && P.abs_dua_tol > 0.f);  // nobody can converge
         if constexpr ((S::LOOPV & 2) != 0)
-            if (uniform) return launch_quad_os<S, RT, XB, true, true>(P, stream);
+            if (uniform && !std::getenv("TINYMPC_HIP_NO_UNI")) return launch_quad_os<S, RT, XB, true, true>(P, stream);
         if constexpr ((S::LOOPV & 1) != 0)
-            if (oneshot) return launch_quad_os<S, RT, XB, true, false>(P, stream);
+            if (oneshot && !std::getenv("TINYMPC_HIP_NO_OS")) return launch_quad_os<S, RT, XB, true, false>(P, stream);
     }
     return launch_quad_os<S, RT, XB, false, false>(P, stream);
 }
