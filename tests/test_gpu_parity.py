@@ -740,3 +740,45 @@ def test_config4_full_size_properties(hip_lib):
     bs.solve()
     assert np.array_equal(bs.get_solution()["controls"], sol["controls"])
     bs.close()
+
+
+def test_config5_shard_tolerance_terminated(hip_lib, oracle_built):
+    """BASELINE config 5 as one rank sees it: a 2^17-instance shard of the 2^20 quadrotor batch (seed 3),
+    tolerance-terminated with check_termination = 10 — every instance against the fp64 oracle, iteration
+    counts multiples of the check interval, per-instance early exit."""
+    B = 2 ** 17
+    prob, x0 = t.problems.quadrotor(30), t.problems.quadrotor_x0(B, seed=3)
+    kw = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=10)
+    ref = _oracle_batch(oracle_built, prob, x0, nthreads=len(os.sched_getaffinity(0)), **kw)
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+    bs.update_settings(**kw)
+    bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    bs.set_warm_start(False)
+    bs.set_x0(x0)
+    status = bs.solve()
+    sol, st = bs.get_solution(), bs.get_status()
+    assert status == int(np.any(ref["solved"] == 0))
+    assert np.all((st["iter"] % 10 == 0))
+    same = st["iter"] == ref["iter"]
+    assert same.mean() >= 0.995, same.mean()
+    assert np.all(np.abs(st["iter"] - ref["iter"]) <= 10)
+    assert nrel_batch(sol["states"], ref["x"])[same].max() <= FP32_TOL
+    assert nrel_batch(sol["controls"], ref["u"])[same].max() <= FP32_TOL
+    bs.close()
+
+
+def test_kernel_selection_by_batch(hip_lib):
+    """Lanes per instance follow the batch size; shapes outside the unrolled table use the stream kernel."""
+    prob = t.problems.cartpole(20, u_bound=0.5)
+    for batch, tag in ((100, "g4>"), (30000, "g2>"), (65536, "g1>")):
+        bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=batch)
+        assert bs.kernel_name.startswith("quad<4,1,20") and bs.kernel_name.endswith(tag), bs.kernel_name
+        bs.close()
+    q = t.problems.quadrotor(30)
+    bs = t.BatchSolver(q.A, q.B, q.Q, q.R, q.rho, q.N, batch=8)
+    assert bs.kernel_name == "quad<12,4,30,g4>"
+    bs.close()
+    q = t.problems.quadrotor(25)
+    bs = t.BatchSolver(q.A, q.B, q.Q, q.R, q.rho, q.N, batch=8)
+    assert bs.kernel_name == "stream<12,4>"
+    bs.close()
