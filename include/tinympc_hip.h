@@ -110,6 +110,14 @@ typedef struct tinympc_solver tinympc_solver;
 int tinympc_create(tinympc_solver **out, const double *A, const double *B, const double *Q,
                    const double *R, double rho, int nx, int nu, int N, int batch, int device,
                    int verbose);
+/* One problem family PER INSTANCE (no counterpart in the reference, whose solver holds one
+ * family): A [batch][nx*nx], B [batch][nx*nu], Q [batch][nx*nx], R [batch][nu*nu] (each block column-major),
+ * rho [batch].  Every instance gets its own host-side fp64 Riccati cache; bounds, settings and references
+ * behave as in the single-family solver.  Needs (nx, nu) in the stream-kernel grid
+ * (nx in {2,3,4,6,8,10,12}, nu <= 4); the batch size is fixed. */
+int tinympc_create_families(tinympc_solver **out, const double *A, const double *B, const double *Q,
+                            const double *R, const double *rho, int nx, int nu, int N, int batch,
+                            int device, int verbose);
 void tinympc_destroy(tinympc_solver *s);
 int tinympc_update_settings(tinympc_solver *s, double abs_pri_tol, double abs_dua_tol,
                             int max_iter, int check_termination, int en_state_bound,

@@ -782,3 +782,61 @@ def test_kernel_selection_by_batch(hip_lib):
     bs = t.BatchSolver(q.A, q.B, q.Q, q.R, q.rho, q.N, batch=8)
     assert bs.kernel_name == "stream<12,4>"
     bs.close()
+
+
+def test_per_instance_families_vs_oracle(hip_lib, oracle_built):
+    """every instance its own (A, B, Q, R, rho) — perturbed cartpoles — each checked
+    against the fp64 oracle set up for that instance; plus the degenerate case (all families equal) against
+    the single-family kernel."""
+    rng = np.random.default_rng(41)
+    B, N = 96, 20
+    base = t.problems.cartpole(N, u_bound=0.5)
+    A = np.repeat(base.A[:, :, None], B, axis=2) * (1.0 + 0.02 * rng.standard_normal((4, 4, B)))
+    Bm = np.repeat(base.B[:, :, None], B, axis=2) * (1.0 + 0.05 * rng.standard_normal((4, 1, B)))
+    Q = np.zeros((4, 4, B))
+    R = np.zeros((1, 1, B))
+    for b in range(B):
+        Q[:, :, b] = np.diag(np.array([10.0, 1.0, 10.0, 1.0]) * rng.uniform(0.5, 2.0, 4))
+        R[:, :, b] = rng.uniform(0.5, 2.0)
+    rho = rng.uniform(0.5, 3.0, B)
+    x0 = t.problems.cartpole_x0(B, seed=5)
+    kw = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1)
+    X, U = np.zeros((4, N, B)), np.zeros((1, N - 1, B))
+    it = np.zeros(B, dtype=int)
+    for b in range(B):
+        o = oracle_built.CpuSolver("orc64", A[:, :, b], Bm[:, :, b], Q[:, :, b], R[:, :, b], float(rho[b]), N)
+        o.update_settings(**kw)
+        o.set_bound_constraints(base.x_min, base.x_max, base.u_min, base.u_max)
+        o.set_x0(x0[:, b])
+        o.solve()
+        r = o.get_solution()
+        X[:, :, b], U[:, :, b], it[b] = r["x"], r["u"], r["iter"]
+    bs = t.BatchSolver.from_families(A, Bm, Q, R, rho, N)
+    assert bs.kernel_name == "stream<4,1>"
+    bs.update_settings(**kw)
+    bs.set_bound_constraints(base.x_min, base.x_max, base.u_min, base.u_max)
+    bs.set_x0(x0)
+    bs.solve()
+    sol, st = bs.get_solution(), bs.get_status()
+    same = st["iter"] == it
+    assert same.mean() >= 0.95 and np.all(np.abs(st["iter"] - it) <= 1)
+    assert nrel_batch(sol["states"], X)[same].max() <= FP32_TOL
+    assert nrel_batch(sol["controls"], U)[same].max() <= FP32_TOL
+    assert len(set(st["iter"].tolist())) > 3          # the families really differ
+    bs.close()
+    # all families equal == the single-family solver (different kernels, same answers to rounding)
+    A1 = np.repeat(base.A[:, :, None], 8, axis=2)
+    B1 = np.repeat(base.B[:, :, None], 8, axis=2)
+    Q1 = np.repeat(base.Q[:, :, None], 8, axis=2)
+    R1 = np.repeat(base.R[:, :, None], 8, axis=2)
+    bh = t.BatchSolver.from_families(A1, B1, Q1, R1, np.full(8, base.rho), N)
+    b1 = t.BatchSolver(base.A, base.B, base.Q, base.R, base.rho, N, batch=8)
+    for s in (bh, b1):
+        s.update_settings(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=50)
+        s.set_bound_constraints(base.x_min, base.x_max, base.u_min, base.u_max)
+        s.set_x0(x0[:, :8])
+        s.solve()
+    assert nrel_batch(bh.get_solution()["controls"], b1.get_solution()["controls"]).max() <= 2e-6
+    with pytest.raises(t.TinyMPCError):
+        bh.set_cache_terms(*[b1.get_cache_terms()[k] for k in ("Kinf", "Pinf", "Quu_inv", "AmBKt")])
+    bh.close(); b1.close()

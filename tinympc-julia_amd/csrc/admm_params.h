@@ -61,6 +61,8 @@ struct AdmmParams {
     int Acx[8], qcx[8], Acu[8], qcu[8];  // first row and dimension of each cone block
     float cx[8], cu[8];                  // mu of each cone: ||head|| <= mu * (last row)
     float *sgc, *svc, *syc, *szc;        // warm-start state of the cone slack/dual pairs
+    // ---- stream kernel only: one problem family PER INSTANCE ----
+    const float *het_aux;                // [nx + nu + 1][batch]: diag(Q)+rho, diag(R)+rho, rho of each instance
 };
 
 }  // namespace tmpc

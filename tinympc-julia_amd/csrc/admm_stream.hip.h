@@ -37,6 +37,17 @@ struct StreamPack {
 __device__ __forceinline__ float sfma(float a, float b, float c) { return fmaf(a, b, c); }
 __device__ __forceinline__ double sfma(double a, double b, double c) { return fma(a, b, c); }
 
+// Coefficient source: one family for the whole batch (LDS broadcast), or one family PER INSTANCE
+// (SURVEY.md §8f-3): pack laid out [element][batch] in HBM, each lane reading its own column — the
+// per-instance cache then streams from L2 / HBM (4(2nx^2 + 2nx nu + nu^2) B per knot and side).
+template <class RT, bool HET>
+struct CoefSrc {
+    const RT *base;
+    long stride;
+    __device__ __forceinline__ RT operator[](int i) const { return HET ? base[(long)i * stride] : base[i]; }
+    __device__ __forceinline__ CoefSrc operator+(int off) const { return CoefSrc{base + (HET ? (long)off * stride : off), stride}; }
+};
+
 template <int Q_MAX>
 __device__ __forceinline__ void project_soc_regs(float (&blk)[Q_MAX], int first, int q, float mu) {
     // block rows [first, first+q), last one the axis: ||head|| <= mu * axis  (same map as the oracle)
@@ -59,7 +70,7 @@ __device__ __forceinline__ void project_soc_regs(float (&blk)[Q_MAX], int first,
     }
 }
 
-template <int NX, int NU, class RT, bool EXT>
+template <int NX, int NU, class RT, bool EXT, bool HET>
 __global__ __launch_bounds__(256) void admm_stream_kernel(const AdmmParams P) {
     using PK = StreamPack<NX, NU>;
     constexpr int T = 256;
@@ -70,7 +81,8 @@ __global__ __launch_bounds__(256) void admm_stream_kernel(const AdmmParams P) {
     const int N = P.N;
     const int tid = threadIdx.x;
     const RT *gcoef = reinterpret_cast<const RT *>(P.coef);
-    for (int i = tid; i < PK::LEN; i += T) s_coef[i] = gcoef[i];
+    if constexpr (!HET)
+        for (int i = tid; i < PK::LEN; i += T) s_coef[i] = gcoef[i];
     const int bnd_len = N * (2 * NX + 2 * NU) + NX + NU;
     for (int i = tid; i < bnd_len; i += T) s_bnd[i] = P.bounds[i];
     __syncthreads();
@@ -79,11 +91,26 @@ __global__ __launch_bounds__(256) void admm_stream_kernel(const AdmmParams P) {
     const long b = (long)blockIdx.x * T + tid;
     const bool active = b < B;
     const long EX = (long)NX * N, EU = (long)NU * (N - 1);
-    const float *cQD = s_bnd + N * (2 * NX + 2 * NU), *cRD = cQD + NX;
-    const RT *cA = s_coef + PK::O_A, *cK = s_coef + PK::O_K, *cB = s_coef + PK::O_B, *cAT = s_coef + PK::O_AT,
-             *cBT = s_coef + PK::O_BT, *cKT = s_coef + PK::O_KT, *cQI = s_coef + PK::O_QI, *cPT = s_coef + PK::O_PT,
-             *cF = s_coef + PK::O_F, *cAPF = s_coef + PK::O_APF, *cBPF = s_coef + PK::O_BPF;
-    const float rho = P.rho;
+    // per-family scalars: shared (bounds pack tail, kernel argument) or per instance (het_aux: [Qd|Rd|rho][batch])
+    float cQD[NX], cRD[NU];
+    float rho = P.rho;
+    if constexpr (HET) {
+        const long bb = active ? b : 0;
+#pragma unroll
+        for (int m = 0; m < NX; ++m) cQD[m] = P.het_aux[(long)m * B + bb];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) cRD[a] = P.het_aux[(long)(NX + a) * B + bb];
+        rho = P.het_aux[(long)(NX + NU) * B + bb];
+    } else {
+#pragma unroll
+        for (int m = 0; m < NX; ++m) cQD[m] = s_bnd[N * (2 * NX + 2 * NU) + m];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) cRD[a] = s_bnd[N * (2 * NX + 2 * NU) + NX + a];
+    }
+    const CoefSrc<RT, HET> cbase{HET ? gcoef + (active ? b : 0) : s_coef, HET ? B : 1};
+    const auto cA = cbase + PK::O_A, cK = cbase + PK::O_K, cB = cbase + PK::O_B, cAT = cbase + PK::O_AT,
+               cBT = cbase + PK::O_BT, cKT = cbase + PK::O_KT, cQI = cbase + PK::O_QI, cPT = cbase + PK::O_PT,
+               cF = cbase + PK::O_F, cAPF = cbase + PK::O_APF, cBPF = cbase + PK::O_BPF;
     const bool soc_x = EXT && P.ncx > 0, soc_u = EXT && P.ncu > 0;
 
     // scratch columns of this instance

@@ -71,6 +71,21 @@ int tinympc_create(tinympc_solver **out, const double *A, const double *B, const
     });
 }
 
+int tinympc_create_families(tinympc_solver **out, const double *A, const double *B, const double *Q,
+                            const double *R, const double *rho, int nx, int nu, int N, int batch, int device,
+                            int verbose) {
+    return guarded("tinympc_create_families", [&]() -> int {
+        if (!out || !A || !B || !Q || !R || !rho) {
+            set_error("tinympc_create_families: null argument");
+            return -1;
+        }
+        std::unique_ptr<tinympc_solver> s(new tinympc_solver());
+        if (s->s.init_families(A, B, Q, R, rho, nx, nu, N, batch, device, verbose)) return -1;
+        *out = s.release();
+        return 0;
+    });
+}
+
 void tinympc_destroy(tinympc_solver *s) { delete s; }
 
 int tinympc_update_settings(tinympc_solver *s, double abs_pri_tol, double abs_dua_tol, int max_iter,
@@ -122,6 +137,10 @@ int tinympc_set_cache_terms(tinympc_solver *s, const double *Kinf, const double 
                             const double *Quu_inv, const double *AmBKt) {
     if (!s || !Kinf || !Pinf || !Quu_inv || !AmBKt) return -1;
     tmpc::Solver &v = s->s;
+    if (v.hetero) {
+        set_error("set_cache_terms: not available on a per-instance-family solver");
+        return -1;
+    }
     v.cache.Kinf = tmpc::Mat(v.nu, v.nx, Kinf);
     v.cache.Pinf = tmpc::Mat(v.nx, v.nx, Pinf);
     v.cache.Quu_inv = tmpc::Mat(v.nu, v.nu, Quu_inv);

@@ -33,7 +33,7 @@ struct StreamEntry {
     void (*build_coef)(const Solver &, std::vector<unsigned char> &);
     void (*build_bounds)(const Solver &, std::vector<float> &);
     size_t (*lds_bytes)(int N, int precision);
-    hipError_t (*launch)(const AdmmParams &, int precision, bool ext, hipStream_t);
+    hipError_t (*launch)(const AdmmParams &, int precision, bool ext, bool het, hipStream_t);
 };
 const StreamEntry *find_stream_kernel(int nx, int nu);
 hipError_t launch_generic(const AdmmParams &, int precision, hipStream_t);
@@ -65,6 +65,12 @@ struct Solver {
     double cx[8] = {0}, cu[8] = {0};
     float *d_sgc = nullptr, *d_svc = nullptr, *d_syc = nullptr, *d_szc = nullptr;
     bool cones_active() const { return (st.en_state_soc && ncx > 0) || (st.en_input_soc && ncu > 0); }
+    // one problem family PER INSTANCE: per-instance A, B (column-major, concatenated),
+    // Riccati caches and diag/rho scalars; runs on the stream kernel with per-lane coefficient columns
+    bool hetero = false;
+    std::vector<double> het_A, het_B;
+    std::vector<Cache> het_cache;
+    float *d_het_aux = nullptr;
     // references as last set by the host API: kind 0 zero / 1 shared / 2 per instance
     std::vector<float> h_xref, h_uref;
     int xref_kind = 0, uref_kind = 0;
@@ -103,6 +109,8 @@ struct Solver {
     ~Solver();
     int init(const double *A_, const double *B_, const double *Q_, const double *R_, double rho,
              int nx_, int nu_, int N_, int batch_, int device_, int verbose_);
+    int init_families(const double *A_, const double *B_, const double *Q_, const double *R_, const double *rho_,
+                      int nx_, int nu_, int N_, int batch_, int device_, int verbose_);
     int alloc_batch(int batch_);
     int select_kernel();
     void free_batch();

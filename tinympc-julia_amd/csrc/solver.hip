@@ -30,9 +30,9 @@ bool hip_ok(hipError_t e, const char *what) {
 // fp32 <-> fp64 conversion of the host-side staging buffers, spread over a few threads: at batch 65 536
 // a solution is 6.5 M elements and a single-threaded loop costs more than the kernel that produced it.
 template <class F>
-static void parallel_chunks(size_t n, F &&f) {
+static void parallel_chunks(size_t n, F &&f, size_t min_parallel = (size_t)1 << 16) {
     const unsigned hw = std::thread::hardware_concurrency();
-    const size_t nt = n < (1u << 16) ? 1 : std::min<size_t>(hw ? hw : 1, 16);
+    const size_t nt = n < min_parallel ? 1 : std::min<size_t>(hw ? hw : 1, 16);
     if (nt <= 1) {
         f((size_t)0, n);
         return;
@@ -99,6 +99,7 @@ void Solver::free_batch() {
     dev_free(d_sg);
     dev_free(d_sv);
     dev_free(d_scratch);
+    dev_free(d_het_aux);
     dev_free(d_sgc);
     dev_free(d_svc);
     dev_free(d_syc);
@@ -153,13 +154,46 @@ int Solver::init(const double *A_, const double *B_, const double *Q_, const dou
     return alloc_batch(batch_);
 }
 
+// One family per instance: B independent (A, B, Q, R, rho) sets, each with its own Riccati cache computed on
+// the host in fp64 (threaded); bounds, settings and references behave as in the single-family solver.
+int Solver::init_families(const double *A_, const double *B_, const double *Q_, const double *R_, const double *rho_,
+                          int nx_, int nu_, int N_, int batch_, int device_, int verbose_) {
+    if (init(A_, B_, Q_, R_, rho_[0], nx_, nu_, N_, batch_, device_, verbose_)) return -1;
+    hetero = true;
+    const size_t Bn = (size_t)batch, nxx = (size_t)nx * nx, nxu = (size_t)nx * nu, nuu = (size_t)nu * nu;
+    het_A.assign(A_, A_ + Bn * nxx);
+    het_B.assign(B_, B_ + Bn * nxu);
+    het_cache.assign(Bn, Cache());
+    std::vector<int> bad(1, 0);
+    parallel_chunks(Bn, [&](size_t lo, size_t hi) {
+        for (size_t b = lo; b < hi; ++b)
+            if (precompute_cache(Mat(nx, nx, A_ + b * nxx), Mat(nx, nu, B_ + b * nxu), Mat(nx, nx, Q_ + b * nxx),
+                                 Mat(nu, nu, R_ + b * nuu), rho_[b], het_cache[b]))
+                bad[0] = 1;
+    }, 64);
+    if (bad[0]) {
+        set_error("Riccati precompute failed for at least one instance (R + B'PB singular)");
+        return -1;
+    }
+    std::vector<float> aux((size_t)(nx + nu + 1) * Bn);
+    for (size_t b = 0; b < Bn; ++b) {
+        for (int i = 0; i < nx; ++i) aux[(size_t)i * Bn + b] = (float)het_cache[b].Qd[i];
+        for (int a = 0; a < nu; ++a) aux[(size_t)(nx + a) * Bn + b] = (float)het_cache[b].Rd[a];
+        aux[(size_t)(nx + nu) * Bn + b] = (float)het_cache[b].rho;
+    }
+    if (dev_alloc(d_het_aux, aux.size())) return -1;
+    HIP_TRY(hipMemcpy(d_het_aux, aux.data(), aux.size() * sizeof(float), hipMemcpyHostToDevice));
+    packs_dirty = true;
+    return select_kernel() || ensure_extension_buffers();
+}
+
 // Picks the kernel variant for (shape, batch).  TINYMPC_HIP_GROUP=1|2|4 forces a lanes-per-instance
 // variant (tuning aid); shapes without a specialised kernel run on the generic one.
 int Solver::select_kernel() {
     const char *genv = std::getenv("TINYMPC_HIP_GROUP");
     const KernelEntry *k = genv ? find_quad_kernel(nx, nu, N, std::atoi(genv)) : nullptr;
     if (!k) k = select_quad_kernel(nx, nu, N, batch);
-    if (has_fdyn || cones_active()) k = nullptr;  // affine term / cones: generic kernel only
+    if (has_fdyn || cones_active() || hetero) k = nullptr;  // extensions run on the stream / generic kernels
     if (!k && (nx > GEN_MAX_NX || nu > GEN_MAX_NU)) {
         set_error("problem shape exceeds the generic kernel limits (nx <= 64, nu <= 32)");
         return -1;
@@ -170,6 +204,10 @@ int Solver::select_kernel() {
         s2 = find_stream_kernel(nx, nu);
         if (s2 && s2->lds_bytes(N, precision) > 150 * 1024) s2 = nullptr;
     }
+    if (hetero && !s2) {
+        set_error("per-instance families need a stream-kernel instantiation for (nx, nu) (nx in {2,3,4,6,8,10,12}, nu <= 4)");
+        return -1;
+    }
     if (k != ke || s2 != se) packs_dirty = true;
     ke = k;
     se = s2;
@@ -178,6 +216,10 @@ int Solver::select_kernel() {
 }
 
 int Solver::alloc_batch(int batch_) {
+    if (hetero && batch_ != batch) {
+        set_error("set_batch_size: a per-instance-family solver has a fixed batch");
+        return -1;
+    }
     if (batch_ < 1) {
         set_error("batch must be >= 1");
         return -1;
@@ -481,6 +523,7 @@ int Solver::solve_async(hipStream_t stream, int mpc_steps) {
         P.qcu[i] = qcu[i];
         P.cu[i] = (float)cu[i];
     }
+    P.het_aux = d_het_aux;
     P.sgc = d_sgc;
     P.svc = d_svc;
     P.syc = d_syc;
@@ -492,7 +535,7 @@ int Solver::solve_async(hipStream_t stream, int mpc_steps) {
         HIP_TRY(hipEventRecord(ev0, stream));
     }
     HIP_TRY(ke ? ke->launch(P, precision, state_bounds_active, stream)
-               : (se ? se->launch(P, precision, has_fdyn || cones_active(), stream)
+               : (se ? se->launch(P, precision, has_fdyn || cones_active(), hetero, stream)
                      : launch_generic(P, precision, stream)));
     if (profiling) HIP_TRY(hipEventRecord(ev1, stream));
     HIP_TRY(hipMemcpyAsync(h_gstat, d_gstat, GSTAT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));

@@ -47,8 +47,57 @@ void fill_stream_coef(const Solver &sv, std::vector<unsigned char> &out) {
     }
 }
 
+// One family per instance: the same pack, laid out [element][batch] so that each lane reads its own column.
+template <int NX, int NU, class RT>
+void fill_stream_coef_het(const Solver &sv, std::vector<unsigned char> &out) {
+    using PK = StreamPack<NX, NU>;
+    const size_t Bn = (size_t)sv.batch;
+    out.assign((size_t)PK::LEN * Bn * sizeof(RT), 0);
+    RT *o = reinterpret_cast<RT *>(out.data());
+    for (size_t b = 0; b < Bn; ++b) {
+        const double *A = sv.het_A.data() + b * NX * NX, *Bm = sv.het_B.data() + b * NX * NU;
+        const Cache &c = sv.het_cache[b];
+        auto put = [&](int idx, double val) { o[(size_t)idx * Bn + b] = (RT)val; };
+        std::vector<double> Pf(NX, 0.0);
+        for (int i = 0; i < NX; ++i)
+            for (int l = 0; l < NX; ++l) Pf[i] += c.Pinf(i, l) * sv.fdyn[l];
+        for (int r = 0; r < NX; ++r) {
+            double apf = 0.0;
+            for (int j = 0; j < NX; ++j) {
+                put(PK::O_A + r * NX + j, A[r + (size_t)j * NX]);
+                put(PK::O_AT + r * NX + j, c.AmBKt(r, j));
+                put(PK::O_PT + r * NX + j, c.Pinf(j, r));
+                apf += c.AmBKt(r, j) * Pf[j];
+            }
+            for (int a = 0; a < NU; ++a) {
+                put(PK::O_B + r * NU + a, Bm[r + (size_t)a * NX]);
+                put(PK::O_KT + r * NU + a, c.Kinf(a, r));
+            }
+            put(PK::O_F + r, sv.fdyn[r]);
+            put(PK::O_APF + r, apf);
+        }
+        for (int a = 0; a < NU; ++a) {
+            double bpf = 0.0;
+            for (int j = 0; j < NX; ++j) {
+                put(PK::O_K + a * NX + j, c.Kinf(a, j));
+                put(PK::O_BT + a * NX + j, Bm[j + (size_t)a * NX]);
+                bpf += Bm[j + (size_t)a * NX] * Pf[j];
+            }
+            for (int c2 = 0; c2 < NU; ++c2) put(PK::O_QI + a * NU + c2, c.Quu_inv(a, c2));
+            put(PK::O_BPF + a, bpf);
+        }
+    }
+}
+
 template <int NX, int NU>
 void build_stream_coef(const Solver &sv, std::vector<unsigned char> &out) {
+    if (sv.hetero) {
+        if (sv.precision == 0)
+            fill_stream_coef_het<NX, NU, double>(sv, out);
+        else
+            fill_stream_coef_het<NX, NU, float>(sv, out);
+        return;
+    }
     if (sv.precision == 0)
         fill_stream_coef<NX, NU, double>(sv, out);
     else
@@ -83,21 +132,27 @@ size_t stream_lds_bytes(int N, int precision) {
 }
 
 template <int NX, int NU>
-hipError_t launch_stream(const AdmmParams &P, int precision, bool ext, hipStream_t stream) {
+hipError_t launch_stream(const AdmmParams &P, int precision, bool ext, bool het, hipStream_t stream) {
     const int grid = (P.batch + 255) / 256;
     const size_t lds = stream_lds_bytes<NX, NU>(P.N, precision);
-#define TMPC_LAUNCH(RT_, EXT_)                                                                            \
+#define TMPC_LAUNCH(RT_, EXT_, HET_)                                                                      \
     do {                                                                                                  \
         if (lds > 48 * 1024)                                                                              \
-            (void)hipFuncSetAttribute((const void *)admm_stream_kernel<NX, NU, RT_, EXT_>,                \
+            (void)hipFuncSetAttribute((const void *)admm_stream_kernel<NX, NU, RT_, EXT_, HET_>,          \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
-        hipLaunchKernelGGL((admm_stream_kernel<NX, NU, RT_, EXT_>), dim3(grid), dim3(256), lds, stream, P); \
+        hipLaunchKernelGGL((admm_stream_kernel<NX, NU, RT_, EXT_, HET_>), dim3(grid), dim3(256), lds, stream, \
+                           P);                                                                            \
     } while (0)
-    if (precision == 0) {
-        if (ext) TMPC_LAUNCH(double, true); else TMPC_LAUNCH(double, false);
-    } else {
-        if (ext) TMPC_LAUNCH(float, true); else TMPC_LAUNCH(float, false);
-    }
+#define TMPC_LAUNCH_RT(RT_)                                                \
+    do {                                                                   \
+        if (het) {                                                         \
+            if (ext) TMPC_LAUNCH(RT_, true, true); else TMPC_LAUNCH(RT_, false, true);   \
+        } else {                                                           \
+            if (ext) TMPC_LAUNCH(RT_, true, false); else TMPC_LAUNCH(RT_, false, false); \
+        }                                                                  \
+    } while (0)
+    if (precision == 0) TMPC_LAUNCH_RT(double); else TMPC_LAUNCH_RT(float);
+#undef TMPC_LAUNCH_RT
 #undef TMPC_LAUNCH
     return hipGetLastError();
 }

@@ -65,6 +65,8 @@ SIGNATURES = {
     "reset_workspace": (c_int, []),
     "tinympc_create": (c_int, [ctypes.POINTER(c_vp), c_dp, c_dp, c_dp, c_dp, c_dbl, c_int, c_int,
                                c_int, c_int, c_int, c_int]),
+    "tinympc_create_families": (c_int, [ctypes.POINTER(c_vp), c_dp, c_dp, c_dp, c_dp, c_dp, c_int, c_int, c_int,
+                                        c_int, c_int, c_int]),
     "tinympc_destroy": (None, [c_vp]),
     "tinympc_update_settings": (c_int, [c_vp, c_dbl, c_dbl, c_int, c_int, c_int, c_int]),
     "tinympc_set_bound_constraints": (c_int, [c_vp, c_dp, c_dp, c_dp, c_dp]),
@@ -385,6 +387,23 @@ class BatchSolver:
         if st != 0:
             raise TinyMPCError(f"tinympc_create failed ({_err()})")
         self.h = h
+
+    @classmethod
+    def from_families(cls, A, B, Q, R, rho, N, device=-1, verbose=False):
+        """One (A, B, Q, R, rho) family PER INSTANCE: A (nx, nx, batch), B (nx, nu, batch), Q (nx, nx, batch),
+        R (nu, nu, batch), rho (batch,).  Each instance gets its own Riccati cache (host, fp64)."""
+        self = cls.__new__(cls)
+        self.lib = load_library()
+        A, B, Q, R = (np.asfortranarray(np.asarray(m, dtype=np.float64)) for m in (A, B, Q, R))
+        rho = np.ascontiguousarray(np.asarray(rho, dtype=np.float64))
+        self.nx, self.nu, self.N, self.batch = A.shape[0], B.shape[1], int(N), A.shape[2]
+        h = c_vp()
+        st = self.lib.tinympc_create_families(ctypes.byref(h), _dp(A), _dp(B), _dp(Q), _dp(R), _dp(rho), self.nx,
+                                              self.nu, self.N, self.batch, int(device), 1 if verbose else 0)
+        if st != 0:
+            raise TinyMPCError(f"tinympc_create_families failed ({_err()})")
+        self.h = h
+        return self
 
     def close(self):
         if getattr(self, "h", None):
