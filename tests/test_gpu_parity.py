@@ -276,7 +276,9 @@ def test_refs_shared_and_per_instance(hip_lib, oracle_built):
     bs.close()
 
 
-@pytest.mark.parametrize("shape,kernel", [("cartpole_N15", "stream<4,1>"), ("random_3x2_N7", "stream<3,2>"),
+@pytest.mark.parametrize("shape,kernel", [("cartpole_N15", "stream4<4,1>"), ("random_3x2_N7", "stream4<3,2>"),
+                                          ("rocket_N40", "stream4<6,3>"), ("quadrotor_N25", "stream4<12,4>"),
+                                          ("cartpole_N15", "stream<4,1>"), ("random_3x2_N7", "stream<3,2>"),
                                           ("rocket_N40", "stream<6,3>"), ("random_5x2_N9", "generic"),
                                           ("cartpole_N15", "generic")])
 def test_fallback_kernels_vs_oracle(hip_lib, oracle_built, monkeypatch, shape, kernel):
@@ -284,6 +286,8 @@ def test_fallback_kernels_vs_oracle(hip_lib, oracle_built, monkeypatch, shape, k
     and (nx, nu) outside its grid on the generic kernel — always on the GPU, never on the CPU."""
     if kernel == "generic" and shape == "cartpole_N15":
         monkeypatch.setenv("TINYMPC_HIP_NO_STREAM", "1")
+    if kernel.startswith("stream<"):
+        monkeypatch.setenv("TINYMPC_HIP_STREAM_LANES", "1")   # one lane per instance instead of four
     rng = np.random.default_rng(11)
     B = 70
     xref = uref = None
@@ -294,6 +298,9 @@ def test_fallback_kernels_vs_oracle(hip_lib, oracle_built, monkeypatch, shape, k
         prob = t.problems.rocket(40)
         x0 = t.problems.rocket_x0(B, seed=2)
         xref, uref = t.problems.rocket_refs(40)
+    elif shape == "quadrotor_N25":
+        prob = t.problems.quadrotor(25)
+        x0 = t.problems.quadrotor_x0(B, seed=3)
     else:
         n, Nh = (3, 7) if shape == "random_3x2_N7" else (5, 9)
         A = np.eye(n) + 0.1 * rng.standard_normal((n, n))
@@ -644,7 +651,9 @@ def _oracle_rocket(oracle_built, prob, x0, xr, ur, fdyn, cones, **kw):
     return X, U, it, so
 
 
-@pytest.mark.parametrize("N,fdyn,cones,kernel", [(10, True, False, "stream<6,3>"), (10, True, True, "stream<6,3>"),
+@pytest.mark.parametrize("N,fdyn,cones,kernel", [(10, True, False, "stream4<6,3>"), (10, True, True, "stream4<6,3>"),
+                                                 (50, True, True, "stream4<6,3>"), (10, False, True, "stream4<6,3>"),
+                                                 (10, True, False, "stream<6,3>"), (10, True, True, "stream<6,3>"),
                                                  (50, True, True, "stream<6,3>"), (10, False, True, "stream<6,3>"),
                                                  (10, True, True, "generic")])
 def test_rocket_fdyn_cones_vs_oracle(hip_lib, oracle_built, monkeypatch, N, fdyn, cones, kernel):
@@ -653,6 +662,8 @@ def test_rocket_fdyn_cones_vs_oracle(hip_lib, oracle_built, monkeypatch, N, fdyn
     path to the oracle, and tests/test_extensions_cpu.py pins the oracle by properties."""
     if kernel == "generic":
         monkeypatch.setenv("TINYMPC_HIP_NO_STREAM", "1")
+    if kernel.startswith("stream<"):
+        monkeypatch.setenv("TINYMPC_HIP_STREAM_LANES", "1")
     B = 24
     prob = t.problems.rocket(N)
     x0 = t.problems.rocket_x0(B, seed=2)
@@ -780,14 +791,16 @@ def test_kernel_selection_by_batch(hip_lib):
     bs.close()
     q = t.problems.quadrotor(25)
     bs = t.BatchSolver(q.A, q.B, q.Q, q.R, q.rho, q.N, batch=8)
-    assert bs.kernel_name == "stream<12,4>"
+    assert bs.kernel_name == "stream4<12,4>"
     bs.close()
 
 
-def test_per_instance_families_vs_oracle(hip_lib, oracle_built):
+@pytest.mark.parametrize("lanes", [4, 1])
+def test_per_instance_families_vs_oracle(hip_lib, oracle_built, monkeypatch, lanes):
     """every instance its own (A, B, Q, R, rho) — perturbed cartpoles — each checked
     against the fp64 oracle set up for that instance; plus the degenerate case (all families equal) against
     the single-family kernel."""
+    monkeypatch.setenv("TINYMPC_HIP_STREAM_LANES", str(lanes))
     rng = np.random.default_rng(41)
     B, N = 96, 20
     base = t.problems.cartpole(N, u_bound=0.5)
@@ -812,7 +825,7 @@ def test_per_instance_families_vs_oracle(hip_lib, oracle_built):
         r = o.get_solution()
         X[:, :, b], U[:, :, b], it[b] = r["x"], r["u"], r["iter"]
     bs = t.BatchSolver.from_families(A, Bm, Q, R, rho, N)
-    assert bs.kernel_name == "stream<4,1>"
+    assert bs.kernel_name == ("stream4<4,1>" if lanes == 4 else "stream<4,1>")
     bs.update_settings(**kw)
     bs.set_bound_constraints(base.x_min, base.x_max, base.u_min, base.u_max)
     bs.set_x0(x0)

@@ -194,6 +194,7 @@ int Solver::select_kernel() {
     const KernelEntry *k = genv ? find_quad_kernel(nx, nu, N, std::atoi(genv)) : nullptr;
     if (!k) k = select_quad_kernel(nx, nu, N, batch);
     if (has_fdyn || cones_active() || hetero) k = nullptr;  // extensions run on the stream / generic kernels
+    if (std::getenv("TINYMPC_HIP_NO_QUAD")) k = nullptr;    // tuning aid: time the fallback kernels on any shape
     if (!k && (nx > GEN_MAX_NX || nu > GEN_MAX_NU)) {
         set_error("problem shape exceeds the generic kernel limits (nx <= 64, nu <= 32)");
         return -1;
@@ -201,8 +202,19 @@ int Solver::select_kernel() {
     // shapes / options without a quad kernel: the stream kernel for (nx, nu) if its LDS image fits
     const StreamEntry *s2 = nullptr;
     if (!k && !std::getenv("TINYMPC_HIP_NO_STREAM")) {
-        s2 = find_stream_kernel(nx, nu);
-        if (s2 && s2->lds_bytes(N, precision) > 150 * 1024) s2 = nullptr;
+        // four lanes per instance unless forced (TINYMPC_HIP_STREAM_LANES=1) or its 32-bit lane offsets /
+        // LDS image do not fit; then one lane per instance
+        const char *lenv = std::getenv("TINYMPC_HIP_STREAM_LANES");
+        const bool cones = cones_active();
+        if (!lenv || std::atoi(lenv) == 4) {
+            s2 = find_stream_kernel(nx, nu, 4);
+            if (s2 && (s2->lds_bytes(N, precision) > 150 * 1024 || 4.0 * batch * 16 >= 4.0e9)) s2 = nullptr;
+        }
+        if (!s2) {
+            s2 = find_stream_kernel(nx, nu, 1);
+            if (s2 && s2->lds_bytes(N, precision) > 150 * 1024) s2 = nullptr;
+        }
+        (void)cones;
     }
     if (hetero && !s2) {
         set_error("per-instance families need a stream-kernel instantiation for (nx, nu) (nx in {2,3,4,6,8,10,12}, nu <= 4)");
@@ -438,7 +450,8 @@ int Solver::ensure_extension_buffers() {
     if (ke) return 0;
     HIP_TRY(hipSetDevice(device));
     const size_t Bn = (size_t)batch, EX = (size_t)ex(), EU = (size_t)eu();
-    const size_t need = Bn * (cones_active() ? (8 * EX + 9 * EU) : (5 * EX + 6 * EU));
+    size_t need = Bn * (cones_active() ? (8 * EX + 9 * EU) : (5 * EX + 6 * EU));
+    if (se) need = std::max(need, Bn * se->scratch_floats(N, cones_active()));
     if (scratch_cap < need) {
         if (dev_alloc(d_scratch, need)) return -1;
         scratch_cap = need;

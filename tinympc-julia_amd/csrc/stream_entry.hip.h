@@ -132,6 +132,12 @@ size_t stream_lds_bytes(int N, int precision) {
 }
 
 template <int NX, int NU>
+size_t stream_scratch_floats(int N, bool cones) {
+    const size_t EX = (size_t)NX * N, EU = (size_t)NU * (N - 1);
+    return cones ? 6 * EX + 7 * EU : 3 * EX + 4 * EU;
+}
+
+template <int NX, int NU>
 hipError_t launch_stream(const AdmmParams &P, int precision, bool ext, bool het, hipStream_t stream) {
     const int grid = (P.batch + 255) / 256;
     const size_t lds = stream_lds_bytes<NX, NU>(P.N, precision);
@@ -159,9 +165,9 @@ hipError_t launch_stream(const AdmmParams &P, int precision, bool ext, bool het,
 
 #define TMPC_DEFINE_STREAM_ENTRY(NX, NU)                                                             \
     const StreamEntry *stream_entry_##NX##_##NU() {                                                  \
-        static const StreamEntry e = {NX, NU, "stream<" #NX "," #NU ">", &build_stream_coef<NX, NU>, \
+        static const StreamEntry e = {NX, NU, 1, "stream<" #NX "," #NU ">", &build_stream_coef<NX, NU>, \
                                       &build_stream_bounds<NX, NU>, &stream_lds_bytes<NX, NU>,       \
-                                      &launch_stream<NX, NU>};                                       \
+                                      &stream_scratch_floats<NX, NU>, &launch_stream<NX, NU>};       \
         return &e;                                                                                   \
     }
 
