@@ -278,16 +278,13 @@ def test_refs_shared_and_per_instance(hip_lib, oracle_built):
 
 @pytest.mark.parametrize("shape,kernel", [("cartpole_N15", "stream4<4,1>"), ("random_3x2_N7", "stream4<3,2>"),
                                           ("rocket_N40", "stream4<6,3>"), ("quadrotor_N25", "stream4<12,4>"),
-                                          ("cartpole_N15", "stream<4,1>"), ("random_3x2_N7", "stream<3,2>"),
-                                          ("rocket_N40", "stream<6,3>"), ("random_5x2_N9", "generic"),
+                                          ("random_10x3_N12", "stream4<10,3>"), ("random_5x2_N9", "generic"),
                                           ("cartpole_N15", "generic")])
 def test_fallback_kernels_vs_oracle(hip_lib, oracle_built, monkeypatch, shape, kernel):
     """Shapes without a specialised (unrolled) instantiation run on the run-time-horizon stream kernel,
     and (nx, nu) outside its grid on the generic kernel — always on the GPU, never on the CPU."""
     if kernel == "generic" and shape == "cartpole_N15":
         monkeypatch.setenv("TINYMPC_HIP_NO_STREAM", "1")
-    if kernel.startswith("stream<"):
-        monkeypatch.setenv("TINYMPC_HIP_STREAM_LANES", "1")   # one lane per instance instead of four
     rng = np.random.default_rng(11)
     B = 70
     xref = uref = None
@@ -302,12 +299,13 @@ def test_fallback_kernels_vs_oracle(hip_lib, oracle_built, monkeypatch, shape, k
         prob = t.problems.quadrotor(25)
         x0 = t.problems.quadrotor_x0(B, seed=3)
     else:
-        n, Nh = (3, 7) if shape == "random_3x2_N7" else (5, 9)
+        n, m, Nh = {"random_3x2_N7": (3, 2, 7), "random_10x3_N12": (10, 3, 12), "random_5x2_N9": (5, 2, 9)}[shape]
         A = np.eye(n) + 0.1 * rng.standard_normal((n, n))
-        Bm = rng.standard_normal((n, 2))
-        prob = t.problems.Problem("rand", A, Bm, np.diag([5.0, 2.0, 1.0, 3.0, 0.5][:n]), np.diag([1.0, 2.0]), 2.0, Nh)
+        Bm = rng.standard_normal((n, m))
+        qd = np.array([5.0, 2.0, 1.0, 3.0, 0.5, 1.5, 2.5, 0.7, 4.0, 1.0])[:n]
+        prob = t.problems.Problem("rand", A, Bm, np.diag(qd), np.diag([1.0, 2.0, 0.5][:m]), 2.0, Nh)
         prob.x_min, prob.x_max = np.full((n, Nh), -2.0), np.full((n, Nh), 2.0)
-        prob.u_min, prob.u_max = np.full((2, Nh - 1), -0.3), np.full((2, Nh - 1), 0.3)
+        prob.u_min, prob.u_max = np.full((m, Nh - 1), -0.3), np.full((m, Nh - 1), 0.3)
         x0 = np.asfortranarray(rng.uniform(-1, 1, (n, B)))
     kw = dict(abs_pri_tol=1e-4, abs_dua_tol=1e-4, max_iter=80)
     ref = _oracle_batch(oracle_built, prob, x0, xref=xref, uref=uref, **kw)
@@ -325,6 +323,13 @@ def test_fallback_kernels_vs_oracle(hip_lib, oracle_built, monkeypatch, shape, k
     assert same.mean() >= 0.95 and np.all(np.abs(st["iter"] - ref["iter"]) <= 1)
     assert nrel_batch(sol["states"], ref["x"])[same].max() <= FP32_TOL
     assert nrel_batch(sol["controls"], ref["u"])[same].max() <= FP32_TOL
+    # one-shot solves (workspace not kept) take the stream kernel's in-place loop: same answers
+    bs.set_warm_start(False)
+    bs.solve()
+    sol1, st1 = bs.get_solution(), bs.get_status()
+    assert np.array_equal(st1["iter"], st["iter"])
+    assert nrel_batch(sol1["states"], ref["x"])[same].max() <= FP32_TOL
+    assert nrel_batch(sol1["controls"], ref["u"])[same].max() <= FP32_TOL
     bs.close()
 
 
@@ -653,8 +658,6 @@ def _oracle_rocket(oracle_built, prob, x0, xr, ur, fdyn, cones, **kw):
 
 @pytest.mark.parametrize("N,fdyn,cones,kernel", [(10, True, False, "stream4<6,3>"), (10, True, True, "stream4<6,3>"),
                                                  (50, True, True, "stream4<6,3>"), (10, False, True, "stream4<6,3>"),
-                                                 (10, True, False, "stream<6,3>"), (10, True, True, "stream<6,3>"),
-                                                 (50, True, True, "stream<6,3>"), (10, False, True, "stream<6,3>"),
                                                  (10, True, True, "generic")])
 def test_rocket_fdyn_cones_vs_oracle(hip_lib, oracle_built, monkeypatch, N, fdyn, cones, kernel):
     """Config 4's ingredients on the GPU (generic kernel) against the fp64 restatement of the same
@@ -662,8 +665,6 @@ def test_rocket_fdyn_cones_vs_oracle(hip_lib, oracle_built, monkeypatch, N, fdyn
     path to the oracle, and tests/test_extensions_cpu.py pins the oracle by properties."""
     if kernel == "generic":
         monkeypatch.setenv("TINYMPC_HIP_NO_STREAM", "1")
-    if kernel.startswith("stream<"):
-        monkeypatch.setenv("TINYMPC_HIP_STREAM_LANES", "1")
     B = 24
     prob = t.problems.rocket(N)
     x0 = t.problems.rocket_x0(B, seed=2)
@@ -691,6 +692,13 @@ def test_rocket_fdyn_cones_vs_oracle(hip_lib, oracle_built, monkeypatch, N, fdyn
     bs.solve()
     st2 = bs.get_status()
     assert st2["iter"].sum() < st["iter"].sum() or np.all(st2["iter"] <= st["iter"])
+    # one-shot solves (workspace not kept) take the stream kernel's in-place loop: same answers as the first solve
+    bs.set_warm_start(False)
+    bs.solve()
+    sol1, st1 = bs.get_solution(), bs.get_status()
+    assert np.array_equal(st1["iter"], st["iter"])
+    assert nrel_batch(sol1["states"], X)[same].max() <= FP32_TOL
+    assert nrel_batch(sol1["controls"], U)[same].max() <= FP32_TOL
     bs.close()
 
 
@@ -795,12 +803,10 @@ def test_kernel_selection_by_batch(hip_lib):
     bs.close()
 
 
-@pytest.mark.parametrize("lanes", [4, 1])
-def test_per_instance_families_vs_oracle(hip_lib, oracle_built, monkeypatch, lanes):
+def test_per_instance_families_vs_oracle(hip_lib, oracle_built):
     """every instance its own (A, B, Q, R, rho) — perturbed cartpoles — each checked
     against the fp64 oracle set up for that instance; plus the degenerate case (all families equal) against
     the single-family kernel."""
-    monkeypatch.setenv("TINYMPC_HIP_STREAM_LANES", str(lanes))
     rng = np.random.default_rng(41)
     B, N = 96, 20
     base = t.problems.cartpole(N, u_bound=0.5)
@@ -825,7 +831,7 @@ def test_per_instance_families_vs_oracle(hip_lib, oracle_built, monkeypatch, lan
         r = o.get_solution()
         X[:, :, b], U[:, :, b], it[b] = r["x"], r["u"], r["iter"]
     bs = t.BatchSolver.from_families(A, Bm, Q, R, rho, N)
-    assert bs.kernel_name == ("stream4<4,1>" if lanes == 4 else "stream<4,1>")
+    assert bs.kernel_name == "stream4<4,1>"
     bs.update_settings(**kw)
     bs.set_bound_constraints(base.x_min, base.x_max, base.u_min, base.u_max)
     bs.set_x0(x0)

@@ -40,32 +40,6 @@ const KernelEntry *select_quad_kernel(int nx, int nu, int N, int batch) {
     return nullptr;
 }
 
-const StreamEntry *stream_entry_2_1();
-const StreamEntry *stream_entry_2_2();
-const StreamEntry *stream_entry_3_1();
-const StreamEntry *stream_entry_3_2();
-const StreamEntry *stream_entry_3_3();
-const StreamEntry *stream_entry_4_1();
-const StreamEntry *stream_entry_4_2();
-const StreamEntry *stream_entry_4_3();
-const StreamEntry *stream_entry_4_4();
-const StreamEntry *stream_entry_6_1();
-const StreamEntry *stream_entry_6_2();
-const StreamEntry *stream_entry_6_3();
-const StreamEntry *stream_entry_6_4();
-const StreamEntry *stream_entry_8_1();
-const StreamEntry *stream_entry_8_2();
-const StreamEntry *stream_entry_8_3();
-const StreamEntry *stream_entry_8_4();
-const StreamEntry *stream_entry_10_1();
-const StreamEntry *stream_entry_10_2();
-const StreamEntry *stream_entry_10_3();
-const StreamEntry *stream_entry_10_4();
-const StreamEntry *stream_entry_12_1();
-const StreamEntry *stream_entry_12_2();
-const StreamEntry *stream_entry_12_3();
-const StreamEntry *stream_entry_12_4();
-
 const StreamEntry *stream4_entry_2_1();
 const StreamEntry *stream4_entry_2_2();
 const StreamEntry *stream4_entry_3_1();
@@ -92,14 +66,11 @@ const StreamEntry *stream4_entry_12_2();
 const StreamEntry *stream4_entry_12_3();
 const StreamEntry *stream4_entry_12_4();
 
-const StreamEntry *find_stream_kernel(int nx, int nu, int lanes) {
-    static const StreamEntry *const table[] = {stream_entry_2_1(), stream_entry_2_2(), stream_entry_3_1(), stream_entry_3_2(), stream_entry_3_3(), stream_entry_4_1(), stream_entry_4_2(), stream_entry_4_3(), stream_entry_4_4(), stream_entry_6_1(), stream_entry_6_2(), stream_entry_6_3(), stream_entry_6_4(), stream_entry_8_1(), stream_entry_8_2(), stream_entry_8_3(), stream_entry_8_4(), stream_entry_10_1(), stream_entry_10_2(), stream_entry_10_3(), stream_entry_10_4(), stream_entry_12_1(), stream_entry_12_2(), stream_entry_12_3(), stream_entry_12_4()};
-    static const StreamEntry *const table4[] = {stream4_entry_2_1(), stream4_entry_2_2(), stream4_entry_3_1(), stream4_entry_3_2(), stream4_entry_3_3(), stream4_entry_4_1(), stream4_entry_4_2(), stream4_entry_4_3(), stream4_entry_4_4(), stream4_entry_6_1(), stream4_entry_6_2(), stream4_entry_6_3(), stream4_entry_6_4(), stream4_entry_8_1(), stream4_entry_8_2(), stream4_entry_8_3(), stream4_entry_8_4(), stream4_entry_10_1(), stream4_entry_10_2(), stream4_entry_10_3(), stream4_entry_10_4(), stream4_entry_12_1(), stream4_entry_12_2(), stream4_entry_12_3(), stream4_entry_12_4()};
-    if (lanes == 4) {
-        for (const StreamEntry *e : table4)
-            if (e->nx == nx && e->nu == nu) return e;
-        return nullptr;
-    }
+// The run-time-horizon kernel (admm_streamg.hip.h) is instantiated with 4 lanes per instance: measured on MI355X
+// (rocket N=50 with cones, batch 4 096 .. 65 536) 1 and 2 lanes per instance are no faster at any batch size - all
+// three are bound by the scratch traffic from ~32 768 instances up - and slower below.
+const StreamEntry *find_stream_kernel(int nx, int nu) {
+    static const StreamEntry *const table[] = {stream4_entry_2_1(), stream4_entry_2_2(), stream4_entry_3_1(), stream4_entry_3_2(), stream4_entry_3_3(), stream4_entry_4_1(), stream4_entry_4_2(), stream4_entry_4_3(), stream4_entry_4_4(), stream4_entry_6_1(), stream4_entry_6_2(), stream4_entry_6_3(), stream4_entry_6_4(), stream4_entry_8_1(), stream4_entry_8_2(), stream4_entry_8_3(), stream4_entry_8_4(), stream4_entry_10_1(), stream4_entry_10_2(), stream4_entry_10_3(), stream4_entry_10_4(), stream4_entry_12_1(), stream4_entry_12_2(), stream4_entry_12_3(), stream4_entry_12_4()};
     for (const StreamEntry *e : table)
         if (e->nx == nx && e->nu == nu) return e;
     return nullptr;

@@ -26,10 +26,10 @@ struct KernelEntry {
 const KernelEntry *find_quad_kernel(int nx, int nu, int N, int group = -1);
 // the variant best suited to `batch` instances (nullptr: no specialised kernel for the shape)
 const KernelEntry *select_quad_kernel(int nx, int nu, int N, int batch);
-// One (nx, nu) instantiation of the run-time-horizon stream kernel (admm_stream.hip.h).
+// One (nx, nu) instantiation of the run-time-horizon stream kernel (admm_streamg.hip.h).
 struct StreamEntry {
     int nx, nu;
-    int lanes;  // lanes per instance: 1 (admm_stream.hip.h) or 4 (admm_stream4.hip.h)
+    int lanes;  // lanes per instance
     const char *name;
     void (*build_coef)(const Solver &, std::vector<unsigned char> &);
     void (*build_bounds)(const Solver &, std::vector<float> &);
@@ -37,7 +37,7 @@ struct StreamEntry {
     size_t (*scratch_floats)(int N, bool cones);  // per instance
     hipError_t (*launch)(const AdmmParams &, int precision, bool ext, bool het, hipStream_t);
 };
-const StreamEntry *find_stream_kernel(int nx, int nu, int lanes = 1);
+const StreamEntry *find_stream_kernel(int nx, int nu);
 hipError_t launch_generic(const AdmmParams &, int precision, hipStream_t);
 void build_generic_coef(const Solver &, std::vector<unsigned char> &);
 void build_generic_bounds(const Solver &, std::vector<float> &);

@@ -202,19 +202,10 @@ int Solver::select_kernel() {
     // shapes / options without a quad kernel: the stream kernel for (nx, nu) if its LDS image fits
     const StreamEntry *s2 = nullptr;
     if (!k && !std::getenv("TINYMPC_HIP_NO_STREAM")) {
-        // four lanes per instance unless forced (TINYMPC_HIP_STREAM_LANES=1) or its 32-bit lane offsets /
-        // LDS image do not fit; then one lane per instance
-        const char *lenv = std::getenv("TINYMPC_HIP_STREAM_LANES");
-        const bool cones = cones_active();
-        if (!lenv || std::atoi(lenv) == 4) {
-            s2 = find_stream_kernel(nx, nu, 4);
-            if (s2 && (s2->lds_bytes(N, precision) > 150 * 1024 || 4.0 * batch * 16 >= 4.0e9)) s2 = nullptr;
-        }
-        if (!s2) {
-            s2 = find_stream_kernel(nx, nu, 1);
-            if (s2 && s2->lds_bytes(N, precision) > 150 * 1024) s2 = nullptr;
-        }
-        (void)cones;
+        s2 = find_stream_kernel(nx, nu);
+        // 32-bit lane byte offsets into one knot's rows; LDS image of coefficients + bounds
+        if (s2 && 16.0 * batch * std::max(nx, nu) >= 4.0e9) s2 = nullptr;
+        if (s2 && s2->lds_bytes(N, precision) > 150 * 1024) s2 = nullptr;
     }
     if (hetero && !s2) {
         set_error("per-instance families need a stream-kernel instantiation for (nx, nu) (nx in {2,3,4,6,8,10,12}, nu <= 4)");
