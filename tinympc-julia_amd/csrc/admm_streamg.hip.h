@@ -389,6 +389,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
         if (active && !conv) {
             const bool check = ct > 0 && (i + 1) % ct == 0;  // lanes still iterating have it == i: wave-uniform
             const bool need_res = check && (can_converge || i + 1 == last_check_it);
+            // OS: vnew / znew themselves are only read back as "previous" values by a residual check and as the
+            // solution, so they are stored when this iteration may be a lane's last or the next one checks
+            const bool check_next = ct > 0 && (i + 2) % ct == 0;
+            const bool keep_w = !OS || need_res || i + 1 == P.max_iter ||
+                                (check_next && (can_converge || i + 2 == last_check_it));
             // ================= fused forward sweep (admm.cpp:25-69 + :93-96) =================
             RT x[RX];
 #pragma unroll
@@ -456,12 +461,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
                 }
                 if (x_owner) {
                     stx(Sg, k, gn);
-                    stx(Sw, k, vn);
+                    if (keep_w) stx(Sw, k, vn);
                     if constexpr (OS) stx(Ss, k, sx);
                     if constexpr (EXT)
                         if (soc_x) {
                             stx(Sgc, k, gcn);
-                            stx(Swc, k, wc);
+                            if (keep_w) stx(Swc, k, wc);
                         }
                 }
                 if (pf) fetch_x(k + D, f);
@@ -507,12 +512,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
                     }
                     if (u_owner) {
                         stu(Sy, k, yn);
-                        stu(Szw, k, zn);
+                        if (keep_w) stu(Szw, k, zn);
                         if constexpr (OS) stu(Ssu, k, su);
                         if constexpr (EXT)
                             if (soc_u) {
                                 stu(Syc, k, ycn);
-                                stu(Szwc, k, zc2);
+                                if (keep_w) stu(Szwc, k, zc2);
                             }
                     }
                     if (pf && k + D < N - 1) fetch_u(k + D, f);
