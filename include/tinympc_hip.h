@@ -76,11 +76,12 @@ int set_cache_terms(double *Kinf_data, int Kinf_rows, int Kinf_cols, double *Pin
                     int verbose);
 /* replaces bindings.cpp:228-259 */
 int print_problem_data(int verbose);
-/* replace bindings.cpp:413-490.  set_linear_constraints is accepted only when every block is empty
- * (otherwise -1).  set_cone_constraints: per-knot second-order cones, inputs first; cone i covers rows
+/* replace bindings.cpp:413-490.  set_linear_constraints: Alin_x x <= blin_x and Alin_u u <= blin_u at every knot
+ * (README.md:115-116), column-major (rows x nx) / (rows x nu), at most 8 rows per side (an equality is two rows,
+ * TinyMPC.jl:258-267); enables the non-empty halves.  set_cone_constraints: per-knot second-order cones, inputs first; cone i covers rows
  * [Ac[i], Ac[i]+qc[i]) of each knot, the LAST row is the axis: ||head|| <= c[i] * axis
  * (rocket_landing_constraints.jl:51-57,132); at most 8 cones per side; enables the non-empty halves.
- * Cone and fdyn arithmetic lives only in the absent submodule — parity UNPINNED. */
+ * Cone, linear-inequality and fdyn arithmetic lives only in the absent submodule — parity UNPINNED. */
 int set_linear_constraints(double *Alin_x_data, int Alin_x_rows, int Alin_x_cols,
                            double *blin_x_data, int blin_x_len, double *Alin_u_data,
                            int Alin_u_rows, int Alin_u_cols, double *blin_u_data, int blin_u_len,
@@ -132,6 +133,9 @@ int tinympc_set_cone_constraints(tinympc_solver *s, const int *Acu, const int *q
                                  int n_input_cones, const int *Acx, const int *qcx, const double *cx,
                                  int n_state_cones);
 int tinympc_enable_cones(tinympc_solver *s, int en_state_soc, int en_input_soc);
+int tinympc_set_linear_constraints(tinympc_solver *s, const double *Alin_x, int rows_x, const double *blin_x,
+                                   const double *Alin_u, int rows_u, const double *blin_u);
+int tinympc_enable_linear(tinympc_solver *s, int en_state_linear, int en_input_linear);
 int tinympc_get_cache_terms(tinympc_solver *s, double *Kinf, double *Pinf, double *Quu_inv,
                             double *AmBKt);
 int tinympc_set_x0(tinympc_solver *s, const double *x0, int cols);       /* cols: 1 | batch */

@@ -120,6 +120,16 @@ class CpuSolver:
         self._call("set_cone_constraints", ia[0].ctypes.data_as(_c_ip), ia[1].ctypes.data_as(_c_ip), _dp(da[0]),
                    len(da[0]), ia[2].ctypes.data_as(_c_ip), ia[3].ctypes.data_as(_c_ip), _dp(da[1]), len(da[1]))
 
+    def set_linear_constraints(self, Alin_x, blin_x, Alin_u, blin_u):
+        """UNPINNED extension; Alin_x x <= blin_x, Alin_u u <= blin_u at every knot (bindings.cpp:413-450)"""
+        assert self.kind != "ref", "the vendored snapshot has no linear constraints"
+        Ax = np.asfortranarray(np.asarray(Alin_x, dtype=np.float64).reshape(-1, self.nx))
+        Au = np.asfortranarray(np.asarray(Alin_u, dtype=np.float64).reshape(-1, self.nu))
+        bx = np.ascontiguousarray(np.asarray(blin_x, dtype=np.float64))
+        bu = np.ascontiguousarray(np.asarray(blin_u, dtype=np.float64))
+        assert Ax.shape[0] == len(bx) and Au.shape[0] == len(bu)
+        self._call("set_linear_constraints", _dp(Ax), Ax.shape[0], _dp(bx), _dp(Au), Au.shape[0], _dp(bu))
+
     def set_cache_terms(self, Kinf, Pinf, Quu_inv, AmBKt):
         a = [_f(m) for m in (Kinf, Pinf, Quu_inv, AmBKt)]
         self._call("set_cache_terms", *[_dp(m) for m in a])
@@ -165,6 +175,16 @@ def project_soc(block, mu, kind="orc64"):
     b = np.ascontiguousarray(np.asarray(block, dtype=np.float64)).copy()
     getattr(lib, kind + "_project_soc_block")(_dp(b), len(b), ctypes.c_double(mu))
     return b
+
+
+def project_halfspaces(z, A, b, kind="orc64"):
+    """The oracle's sequential half-space projection of one vector — for property tests."""
+    lib = _load(kind)
+    z = np.ascontiguousarray(np.asarray(z, dtype=np.float64)).copy()
+    A = np.ascontiguousarray(np.asarray(A, dtype=np.float64).reshape(-1, len(z)))
+    b = np.ascontiguousarray(np.asarray(b, dtype=np.float64))
+    getattr(lib, kind + "_project_halfspaces_block")(_dp(z), len(z), _dp(A), _dp(b), len(b))
+    return z
 
 
 def solve_batch(kind, prob, x0, xref=None, uref=None, abs_pri_tol=1e-3, abs_dua_tol=1e-3,

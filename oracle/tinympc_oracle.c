@@ -16,6 +16,7 @@
 #include "tinympc_oracle.h"
 
 #define ORC_MAX_DIM 64
+#define ORC_MAX_LIN 8 /* rows of linear inequalities per side */
 
 /* ---------- small dense fp64 helpers, column-major ---------- */
 

@@ -37,6 +37,10 @@ extern "C" {
     void P##set_cone_constraints(void *h, const int *Acu, const int *qcu, const double *cu,   \
                                  int ncu, const int *Acx, const int *qcx, const double *cx,   \
                                  int ncx);                                                    \
+    void P##set_linear_constraints(void *h, const double *Alin_x, int mx, const double *blin_x, \
+                                   const double *Alin_u, int mu, const double *blin_u);       \
+    void P##project_halfspaces_block(double *z, int n, const double *A_rowmajor,              \
+                                     const double *b, int m);                                 \
     void P##set_cache_terms(void *h, const double *Kinf, const double *Pinf,                  \
                             const double *Quu_inv, const double *AmBKt);                      \
     void P##reset(void *h);                                                                    \

@@ -107,3 +107,67 @@ def test_fdyn_changes_the_answer_and_cones_bind(oracle_built):
     viol = np.linalg.norm(outs["fdyn"]["u"][:2], axis=0) - 0.25 * np.abs(outs["fdyn"]["u"][2])
     assert viol.max() > 1e-3, "test problem must violate the cone without the constraint"
     assert np.abs(outs["both"]["u"] - outs["fdyn"]["u"]).max() > 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------------
+# linear inequalities Alin_x x <= blin_x, Alin_u u <= blin_u (README.md:115-116, bindings.cpp:413-450; UNPINNED)
+# ---------------------------------------------------------------------------------------------------------
+def test_halfspace_projection_properties(oracle_built):
+    rng = np.random.default_rng(17)
+    for n in (1, 2, 3, 6, 12):
+        for _ in range(200):
+            a = rng.standard_normal(n)
+            bnd = float(rng.standard_normal())
+            z = rng.standard_normal(n) * rng.choice([0.1, 1.0, 10.0])
+            p = oracle_built.project_halfspaces(z, a[None, :], [bnd])
+            # one row: the exact Euclidean projection onto {a.z <= b}
+            viol = a @ z - bnd
+            ref = z - max(viol, 0.0) / (a @ a) * a
+            assert np.allclose(p, ref, rtol=1e-12, atol=1e-13)
+            assert a @ p <= bnd + 1e-12 * max(1.0, abs(bnd))
+            assert np.allclose(oracle_built.project_halfspaces(p, a[None, :], [bnd]), p, rtol=1e-12, atol=1e-13)
+            if viol <= 0:
+                assert np.array_equal(p, z)
+    # several rows are applied in order (not the projection onto the intersection): last row always holds,
+    # and orthogonal rows (a box) give the exact projection
+    z = np.array([2.0, -3.0, 0.5])
+    A = np.vstack([np.eye(3), -np.eye(3)])
+    p = oracle_built.project_halfspaces(z, A, np.full(6, 1.0))
+    assert np.array_equal(p, np.clip(z, -1.0, 1.0))
+
+
+def _cartpole_lin(N=10):
+    p = t.problems.cartpole(N, u_bound=5.0)
+    Ax = np.array([[1.0, 0.0, 0.0, 0.0], [0.0, 0.0, 1.0, 1.0]])   # cart position, and pole angle + rate
+    bx = np.array([0.6, 0.12])
+    Au = np.array([[1.0], [-1.0]])                                 # |u| <= 0.8 as two rows
+    bu = np.array([0.8, 0.8])
+    return p, Ax, bx, Au, bu
+
+
+def test_linear_constraints_converge_feasible(oracle_built):
+    """At convergence the trajectory satisfies the inequalities (within the tolerance) and still the dynamics;
+    an inactive set leaves the pinned path's answer unchanged."""
+    p, Ax, bx, Au, bu = _cartpole_lin()
+    kw = dict(abs_pri_tol=1e-5, abs_dua_tol=1e-5, max_iter=20000, check_termination=1)
+    o = oracle_built.CpuSolver("orc64", p.A, p.B, p.Q, p.R, p.rho, p.N)
+    o.update_settings(**kw)
+    o.set_linear_constraints(Ax, bx, Au, bu)
+    o.set_x0([0.5, 0.0, 0.0, 0.0])
+    assert o.solve() == 0
+    r = o.get_solution()
+    assert (Ax @ r["x"] <= bx[:, None] + 1e-4).all() and (Au @ r["u"] <= bu[:, None] + 1e-4).all()
+    assert np.abs(r["u"]).max() > 0.79                     # the input rows bind
+    x = r["x"]
+    assert np.abs(x[:, 1:] - (p.A @ x[:, :-1] + p.B @ r["u"])).max() < 1e-4
+
+
+def test_equality_as_two_inequalities(oracle_built):
+    """TinyMPC.jl:261-270 states an equality as two opposite inequality rows: the iterates are squeezed onto it."""
+    p = t.problems.cartpole(10, u_bound=5.0)
+    o = oracle_built.CpuSolver("orc64", p.A, p.B, p.Q, p.R, p.rho, p.N)
+    o.update_settings(abs_pri_tol=1e-6, abs_dua_tol=1e-6, max_iter=20000, check_termination=1)
+    o.set_linear_constraints(np.zeros((0, 4)), [], [[1.0], [-1.0]], [0.3, -0.3])
+    o.set_x0([0.2, 0.0, 0.0, 0.0])
+    assert o.solve() == 0
+    assert np.abs(o.get_solution()["u"] - 0.3).max() < 1e-5

@@ -725,8 +725,129 @@ def test_rocket_example_through_dropin_api(hip_lib, oracle_built):
     assert nrel(sol["states"], X[:, :, 0]) <= FP32_TOL and nrel(sol["controls"], U[:, :, 0]) <= FP32_TOL
     with pytest.raises(t.TinyMPCError):
         t.set_cone_constraints(s, [2], [3], [0.25], [], [], [])      # rows 2..4 of a 3-row input: out of range
+    t.cleanup()
+
+
+def _lin_case(case):
+    """(problem, x0, refs, fdyn?, cones?, Alin_x, blin_x, Alin_u, blin_u) of the linear-inequality parity cases"""
+    B = 24
+    if case == "cartpole":
+        prob = t.problems.cartpole(15, u_bound=5.0)
+        x0 = t.problems.cartpole_x0(B, seed=6)
+        Ax = np.array([[1.0, 0.0, 0.0, 0.0], [0.0, 0.0, 1.0, 1.0]])
+        return prob, x0, None, False, False, Ax, np.array([0.6, 0.12]), np.array([[1.0], [-1.0]]), np.array([0.8, 0.8])
+    prob = t.problems.rocket(20)
+    x0 = t.problems.rocket_x0(B, seed=3)
+    # descent-rate row on the state, a thrust budget and a floor on the vertical thrust on the input
+    Ax = np.array([[0.0, 0.0, 0.0, 0.0, 0.0, -1.0]])
+    Au = np.array([[0.3, 0.3, 1.0], [0.0, 0.0, -1.0]])
+    return prob, x0, t.problems.rocket_refs(20), True, True, Ax, np.array([2.5]), Au, np.array([11.0, -2.0])
+
+
+@pytest.mark.parametrize("case,kernel", [("cartpole", "stream4<4,1>"), ("rocket", "stream4<6,3>"),
+                                         ("cartpole", "generic"), ("rocket", "generic")])
+def test_linear_constraints_vs_oracle(hip_lib, oracle_built, monkeypatch, case, kernel):
+    """SURVEY.md §8(f)-2, third ingredient: linear inequalities (bindings.cpp:413-450) as a third slack/dual pair,
+    alone (cartpole) and together with the affine term and both cone sets (rocket), on the stream and generic
+    kernels against the fp64 restatement of the same construction.  Parity with the reference is UNPINNED (no
+    source here); tests/test_extensions_cpu.py pins the oracle by properties."""
+    if kernel == "generic":
+        monkeypatch.setenv("TINYMPC_HIP_NO_STREAM", "1")
+    prob, x0, refs, fdyn, cones, Ax, bx, Au, bu = _lin_case(case)
+    B = x0.shape[1]
+    kw = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=120, check_termination=1)
+    X, U = np.zeros((prob.nx, prob.N, B)), np.zeros((prob.nu, prob.N - 1, B))
+    it = np.zeros(B, dtype=int)
+    for b in range(B):
+        o = oracle_built.CpuSolver("orc64", prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N)
+        o.update_settings(**kw)
+        o.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        if fdyn:
+            o.set_fdyn(prob.fdyn)
+        if cones:
+            o.set_cone_constraints([0], [3], [0.25], [0], [3], [0.5])
+        o.set_linear_constraints(Ax, bx, Au, bu)
+        if refs is not None:
+            o.set_x_ref(refs[0])
+            o.set_u_ref(refs[1])
+        o.set_x0(x0[:, b])
+        o.solve()
+        r = o.get_solution()
+        X[:, :, b], U[:, :, b], it[b] = r["x"], r["u"], r["iter"]
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+    bs.update_settings(**kw)
+    bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    if fdyn:
+        bs.set_fdyn(prob.fdyn)
+    if cones:
+        bs.set_cone_constraints([0], [3], [0.25], [0], [3], [0.5])
+    bs.set_linear_constraints(Ax, bx, Au, bu)
+    assert bs.kernel_name == kernel
+    if refs is not None:
+        bs.set_x_ref(refs[0])
+        bs.set_u_ref(refs[1])
+    bs.set_x0(x0)
+    bs.solve()
+    sol, st = bs.get_solution(), bs.get_status()
+    same = st["iter"] == it
+    assert same.mean() >= 0.9 and np.all(np.abs(st["iter"] - it) <= 1)
+    assert nrel_batch(sol["states"], X)[same].max() <= FP32_TOL
+    assert nrel_batch(sol["controls"], U)[same].max() <= FP32_TOL
+    assert len(set(it.tolist())) >= 1 and (np.einsum("ij,jkb->ikb", Au, U) - bu[:, None, None]).max() > -0.05  # rows matter
+    # the linear pairs persist too: a warm second solve continues from the stored state
+    bs.solve()
+    st2 = bs.get_status()
+    assert st2["iter"].sum() < st["iter"].sum() or np.all(st2["iter"] <= st["iter"])
+    # one-shot solves (workspace not kept): same answers as the first solve
+    bs.set_warm_start(False)
+    bs.solve()
+    sol1, st1 = bs.get_solution(), bs.get_status()
+    assert np.array_equal(st1["iter"], st["iter"])
+    assert nrel_batch(sol1["states"], X)[same].max() <= FP32_TOL
+    assert nrel_batch(sol1["controls"], U)[same].max() <= FP32_TOL
     with pytest.raises(t.TinyMPCError):
-        t.update_settings(s, en_input_linear=True)                   # linear constraints stay refused
+        bs.set_linear_constraints(np.zeros((1, prob.nx)), [1.0], np.zeros((0, prob.nu)), [])   # an all-zero row
+    with pytest.raises(t.TinyMPCError):
+        bs.set_linear_constraints(np.ones((9, prob.nx)), np.ones(9), np.zeros((0, prob.nu)), [])  # more than 8 rows
+    bs.close()
+
+
+def test_linear_and_equality_constraints_through_dropin_api(hip_lib, oracle_built):
+    """TinyMPC.jl:229-270 on the process-global entry points: set_linear_constraints, then
+    set_equality_constraints (two opposite rows per equality), against the oracle."""
+    prob = t.problems.cartpole(10, u_bound=5.0)
+    s = t.TinyMPCSolver()
+    t.setup(s, prob.A, prob.B, np.zeros(4), prob.Q, prob.R, prob.rho, 4, 1, 10, max_iter=150, abs_pri_tol=1e-4,
+            abs_dua_tol=1e-4)
+    x0 = np.array([0.3, 0.0, 0.05, 0.0])
+    for eq in (False, True):
+        o = oracle_built.CpuSolver("orc64", prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N)
+        o.update_settings(abs_pri_tol=1e-4, abs_dua_tol=1e-4, max_iter=150, check_termination=1)
+        if eq:
+            t.set_equality_constraints(s, np.zeros((0, 4)), [], [[1.0]], [0.25])
+            o.set_linear_constraints(np.zeros((0, 4)), [], [[1.0], [-1.0]], [0.25, -0.25])
+        else:
+            Ax, bx, Au, bu = [[1.0, 0.0, 0.0, 0.0]], [0.35], [[1.0], [-1.0]], [0.6, 0.6]
+            t.set_linear_constraints(s, Ax, bx, Au, bu)
+            o.set_linear_constraints(Ax, bx, Au, bu)
+        o.set_x0(x0)
+        o.solve()
+        r = o.get_solution()
+        t.reset_workspace(s)
+        t.set_x0(s, x0)
+        status = t.solve(s)
+        sol, st = t.get_solution(s), t.get_status(s)
+        assert status == 1 - r["solved"] and int(st["iter"][0]) == r["iter"]
+        assert nrel(sol["states"], r["x"]) <= FP32_TOL and nrel(sol["controls"], r["u"]) <= FP32_TOL
+    t.update_settings(s, max_iter=150, abs_pri_tol=1e-4, abs_dua_tol=1e-4)     # resets every en_* flag to off
+    t.reset_workspace(s)
+    t.set_x0(s, x0)
+    t.solve(s)
+    free = oracle_built.CpuSolver("orc64", prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N)
+    free.update_settings(abs_pri_tol=1e-4, abs_dua_tol=1e-4, max_iter=150, check_termination=1)
+    free.set_x0(x0)
+    free.solve()
+    assert nrel(t.get_solution(s)["controls"], free.get_solution()["u"]) <= FP32_TOL
     t.cleanup()
 
 

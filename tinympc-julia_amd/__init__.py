@@ -47,6 +47,7 @@ from .tinympc import (  # noqa: E402,F401
     set_bound_constraints,
     set_cache_terms,
     set_cone_constraints,
+    set_equality_constraints,
     set_linear_constraints,
     set_u_ref,
     set_x0,

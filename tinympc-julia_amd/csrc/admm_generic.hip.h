@@ -32,7 +32,7 @@ struct GenericPack {
 // bounds pack: xmin[N*nx] xmax[N*nx] umin[(N-1)*nu] umax[(N-1)*nu] Qd[nx] Rd[nu]
 // scratch arrays, in units of E_x / E_u blocks of [element][batch]
 //   x q v vnew g  (5 x E_x)   then   u r d z znew y  (6 x E_u); p is a running vector;
-//   with cones: + vc vcnew gc (3 x E_x) and zc zcnew yc (3 x E_u)
+//   with cones: + vc vcnew gc (3 x E_x) and zc zcnew yc (3 x E_u); with linear inequalities: + vl vlnew gl, zl zlnew yl
 
 __device__ __forceinline__ float gfma(float a, float b, float c) { return fmaf(a, b, c); }
 __device__ __forceinline__ double gfma(double a, double b, double c) { return fma(a, b, c); }
@@ -49,7 +49,10 @@ __global__ __launch_bounds__(256) void admm_generic_kernel(const AdmmParams P) {
     const RT *cA = coef + pk.oA, *cB = coef + pk.oB, *cK = coef + pk.oK, *cP = coef + pk.oP,
              *cQi = coef + pk.oQi, *cAt = coef + pk.oAt, *cF = coef + pk.oF, *cAPf = coef + pk.oAPf,
              *cBPf = coef + pk.oBPf;
-    const bool soc_x = P.ncx > 0, soc_u = P.ncu > 0;
+    const bool soc_x = P.ncx > 0, soc_u = P.ncu > 0, lin_x = P.mlx > 0, lin_u = P.mlu > 0;
+    // linear-inequality pack: rows, right-hand sides, squared row norms, states then inputs
+    const float *lAx = P.lin, *lbx = lAx + P.mlx * nx, *ln2x = lbx + P.mlx;
+    const float *lAu = ln2x + P.mlx, *lbu = lAu + P.mlu * nu, *ln2u = lbu + P.mlu;
     const float *xmin = P.bounds, *xmax = P.bounds + EX, *umin = P.bounds + 2 * EX,
                 *umax = P.bounds + 2 * EX + EU, *cQd = P.bounds + 2 * EX + 2 * EU,
                 *cRd = P.bounds + 2 * EX + 2 * EU + nx;
@@ -58,6 +61,8 @@ __global__ __launch_bounds__(256) void admm_generic_kernel(const AdmmParams P) {
           *sz = sd + (long)EU * B, *szn = sz + (long)EU * B, *sy = szn + (long)EU * B;
     float *svc = sy + (long)EU * B, *svcn = svc + (long)EX * B, *sgc = svcn + (long)EX * B;
     float *szc = sgc + (long)EX * B, *szcn = szc + (long)EU * B, *syc = szcn + (long)EU * B;
+    float *svl = syc + (long)EU * B, *svln = svl + (long)EX * B, *sgl = svln + (long)EX * B;
+    float *szl = sgl + (long)EX * B, *szln = szl + (long)EU * B, *syl = szln + (long)EU * B;
 #define AT(arr, e) arr[(long)(e)*B]
     const float rho = P.rho;
     const bool warm = !P.cold_start;
@@ -72,6 +77,11 @@ __global__ __launch_bounds__(256) void admm_generic_kernel(const AdmmParams P) {
             AT(sgc, e) = warm ? P.sgc[b * EX + e] : 0.f;
             AT(svcn, e) = 0.f;
         }
+        if (lin_x) {
+            AT(svl, e) = warm ? P.svl[b * EX + e] : 0.f;
+            AT(sgl, e) = warm ? P.sgl[b * EX + e] : 0.f;
+            AT(svln, e) = 0.f;
+        }
     }
     for (int e = 0; e < EU; ++e) {
         AT(su, e) = 0.f;
@@ -84,6 +94,11 @@ __global__ __launch_bounds__(256) void admm_generic_kernel(const AdmmParams P) {
             AT(szc, e) = warm ? P.szc[b * EU + e] : 0.f;
             AT(syc, e) = warm ? P.syc[b * EU + e] : 0.f;
             AT(szcn, e) = 0.f;
+        }
+        if (lin_u) {
+            AT(szl, e) = warm ? P.szl[b * EU + e] : 0.f;
+            AT(syl, e) = warm ? P.syl[b * EU + e] : 0.f;
+            AT(szln, e) = 0.f;
         }
     }
     float res0 = 0.f, res1 = 0.f, res2 = 0.f, res3 = 0.f;
@@ -166,6 +181,28 @@ __global__ __launch_bounds__(256) void admm_generic_kernel(const AdmmParams P) {
                 }
             }
         }
+        if (lin_u) {  // UNPINNED: slack zl = (u + yl) projected row by row onto {a.z <= b}, dual yl, -rho (zl - yl) in r
+            for (int k = 0; k < N - 1; ++k) {
+                for (int a = 0; a < nu; ++a) AT(szln, k * nu + a) = AT(su, k * nu + a) + AT(syl, k * nu + a);
+                for (int c = 0; c < P.mlu; ++c) {
+                    float dot = 0.f;
+                    for (int j = 0; j < nu; ++j) dot = fmaf(lAu[c * nu + j], AT(szln, k * nu + j), dot);
+                    if (dot > lbu[c]) {
+                        const float tt = (dot - lbu[c]) / ln2u[c];
+                        for (int j = 0; j < nu; ++j) AT(szln, k * nu + j) -= tt * lAu[c * nu + j];
+                    }
+                }
+                for (int a = 0; a < nu; ++a) {
+                    const int e = k * nu + a;
+                    const float u = AT(su, e), zl = AT(szln, e);
+                    const float yy = (AT(syl, e) + u) - zl;
+                    AT(syl, e) = yy;
+                    AT(sr, e) -= rho * (zl - yy);
+                    pri_u = fmaxf(pri_u, fabsf(u - zl));
+                    dua_u = fmaxf(dua_u, fabsf(AT(szl, e) - zl));
+                }
+            }
+        }
         for (int e = 0; e < EX; ++e) {
             const int k = e / nx, r = e % nx;
             const float x = AT(sx, e);
@@ -206,12 +243,35 @@ __global__ __launch_bounds__(256) void admm_generic_kernel(const AdmmParams P) {
                 }
             }
         }
+        if (lin_x) {  // UNPINNED: state side, same construction
+            for (int k = 0; k < N; ++k) {
+                for (int r = 0; r < nx; ++r) AT(svln, k * nx + r) = AT(sx, k * nx + r) + AT(sgl, k * nx + r);
+                for (int c = 0; c < P.mlx; ++c) {
+                    float dot = 0.f;
+                    for (int j = 0; j < nx; ++j) dot = fmaf(lAx[c * nx + j], AT(svln, k * nx + j), dot);
+                    if (dot > lbx[c]) {
+                        const float tt = (dot - lbx[c]) / ln2x[c];
+                        for (int j = 0; j < nx; ++j) AT(svln, k * nx + j) -= tt * lAx[c * nx + j];
+                    }
+                }
+                for (int r = 0; r < nx; ++r) {
+                    const int e = k * nx + r;
+                    const float x = AT(sx, e), vl = AT(svln, e);
+                    const float gg = (AT(sgl, e) + x) - vl;
+                    AT(sgl, e) = gg;
+                    AT(sq, e) -= rho * (vl - gg);
+                    pri_x = fmaxf(pri_x, fabsf(x - vl));
+                    dua_x = fmaxf(dua_x, fabsf(AT(svl, e) - vl));
+                }
+            }
+        }
         for (int r = 0; r < nx; ++r) {
             const int e = (N - 1) * nx + r;
             RT acc = 0;
             for (int j = 0; j < nx; ++j) acc = gfma(cP[j + r * nx], (RT)xref(N - 1, j), acc);
             float tail = rho * (AT(svn, e) - AT(sg, e));
             if (soc_x) tail += rho * (AT(svcn, e) - AT(sgc, e));
+            if (lin_x) tail += rho * (AT(svln, e) - AT(sgl, e));
             xn[r] = -acc - (RT)tail;  // p_{N-1}
         }
         it += 1;
@@ -233,6 +293,10 @@ __global__ __launch_bounds__(256) void admm_generic_kernel(const AdmmParams P) {
             for (int e = 0; e < EX; ++e) AT(svc, e) = AT(svcn, e);
         if (soc_u)
             for (int e = 0; e < EU; ++e) AT(szc, e) = AT(szcn, e);
+        if (lin_x)
+            for (int e = 0; e < EX; ++e) AT(svl, e) = AT(svln, e);
+        if (lin_u)
+            for (int e = 0; e < EU; ++e) AT(szl, e) = AT(szln, e);
         // backward_pass_grad — admm.cpp:13-20
         for (int j = 0; j < nx; ++j) xv[j] = xn[j];  // running p, kept in RT
         for (int k = N - 2; k >= 0; --k) {
@@ -283,6 +347,16 @@ __global__ __launch_bounds__(256) void admm_generic_kernel(const AdmmParams P) {
             for (int e = 0; e < EU; ++e) {
                 P.syc[b * EU + e] = AT(syc, e);
                 P.szc[b * EU + e] = AT(szc, e);
+            }
+        if (lin_x)
+            for (int e = 0; e < EX; ++e) {
+                P.sgl[b * EX + e] = AT(sgl, e);
+                P.svl[b * EX + e] = AT(svl, e);
+            }
+        if (lin_u)
+            for (int e = 0; e < EU; ++e) {
+                P.syl[b * EU + e] = AT(syl, e);
+                P.szl[b * EU + e] = AT(szl, e);
             }
     }
     atomicMax(&P.gstat[0], __float_as_uint(res0));

@@ -19,7 +19,7 @@ enum RefMode : int {
 enum { GSTAT_WORDS = 8 };
 
 // generic (runtime-shape) kernel limits
-constexpr int GEN_MAX_NX = 64;
+constexpr int LIN_MAX_ROWS = 8, GEN_MAX_NX = 64;
 constexpr int GEN_MAX_NU = 32;
 
 struct AdmmParams {
@@ -61,6 +61,10 @@ struct AdmmParams {
     int Acx[8], qcx[8], Acu[8], qcu[8];  // first row and dimension of each cone block
     float cx[8], cu[8];                  // mu of each cone: ||head|| <= mu * (last row)
     float *sgc, *svc, *syc, *szc;        // warm-start state of the cone slack/dual pairs
+    // ---- linear inequalities Alin_x x <= blin_x, Alin_u u <= blin_u at every knot (parity UNPINNED) ----
+    int mlx, mlu;                        // rows per side (0: disabled), at most LIN_MAX_ROWS each
+    const float *lin;                    // [mlx][nx] rows | b[mlx] | |a|^2[mlx] | [mlu][nu] rows | b[mlu] | |a|^2[mlu]
+    float *sgl, *svl, *syl, *szl;        // warm-start state of the linear-inequality slack/dual pairs
     // ---- stream kernel only: one problem family PER INSTANCE ----
     const float *het_aux;                // [nx + nu + 1][batch]: diag(Q)+rho, diag(R)+rho, rho of each instance
 };

@@ -152,6 +152,25 @@ __device__ __forceinline__ void project_soc_group(float (&blk)[R], unsigned head
     }
 }
 
+// z <- projection onto {a_k . z <= b_k}, one row after the other; a lane holds its R local entries of each row
+// (rows + k * stride), the dot product is summed over the group, so the branch is uniform within it
+template <int G, int R>
+__device__ __forceinline__ void project_halfspaces_group(float (&z)[R], const float *rows, int stride, int m,
+                                                         const float *b, const float *n2) {
+    for (int k = 0; k < m; ++k) {
+        const float *a = rows + k * stride;
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < R; ++j) dot = fmaf(a[j], z[j], dot);
+        dot = group_sum<G>(dot);
+        if (dot > b[k]) {
+            const float t = (dot - b[k]) / n2[k];
+#pragma unroll
+            for (int j = 0; j < R; ++j) z[j] -= t * a[j];
+        }
+    }
+}
+
 // wavefronts per SIMD the register allocation is held to, and knots of prefetch, per group size
 template <int G>
 struct StreamTune {
@@ -165,7 +184,7 @@ struct StreamTune {
 #define TMPC_STREAM_WAVES(G) StreamTune<G>::WAVES
 #endif
 
-template <int NX, int NU, int G, class RT, bool EXT, bool HET, bool OS>
+template <int NX, int NU, int G, class RT, int EXT, bool HET, bool OS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM_WAVES(G)))) void admm_streamg_kernel(const AdmmParams P) {
     using PK = StreamPackG<NX, NU, G>;
     using S = typename PK::S;
@@ -177,6 +196,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
     RT *s_coef = reinterpret_cast<RT *>(s_rawg);
     float *s_bnd = reinterpret_cast<float *>(s_rawg + sizeof(RT) * G * PK::CP);
     __shared__ uint4 s_cmask[8 * G];
+    // linear inequalities (EXT == 2): per row and lane role the local entries, then right-hand sides and |a|^2
+    __shared__ float s_lax[EXT == 2 ? LIN_MAX_ROWS * G * RX : 1], s_lau[EXT == 2 ? LIN_MAX_ROWS * G * RU : 1],
+        s_lb[4 * LIN_MAX_ROWS];
 
     const int N = P.N;
     const int tid = threadIdx.x;
@@ -245,6 +267,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
     }
     const uint4 *cm = s_cmask + q;
     const bool soc_x = ncx > 0, soc_u = ncu > 0;
+    const int mlx = EXT == 2 ? P.mlx : 0, mlu = EXT == 2 ? P.mlu : 0;
+    if constexpr (EXT == 2) {
+        const float *gAx = P.lin, *gbx = gAx + mlx * NX, *gn2x = gbx + mlx;
+        const float *gAu = gn2x + mlx, *gbu = gAu + mlu * NU, *gn2u = gbu + mlu;
+        for (int i = tid; i < LIN_MAX_ROWS * G * RX; i += T) {
+            const int k = i / (G * RX), row = i % (G * RX);  // (role, local row) flattened = padded row index
+            s_lax[i] = (k < mlx && row < NX) ? gAx[k * NX + row] : 0.f;
+        }
+        for (int i = tid; i < LIN_MAX_ROWS * G * RU; i += T) {
+            const int k = i / (G * RU), row = i % (G * RU);
+            s_lau[i] = (k < mlu && row < NU) ? gAu[k * NU + row] : 0.f;
+        }
+        if (tid < LIN_MAX_ROWS) {
+            s_lb[tid] = tid < mlx ? gbx[tid] : 0.f;
+            s_lb[LIN_MAX_ROWS + tid] = tid < mlx ? gn2x[tid] : 1.f;
+            s_lb[2 * LIN_MAX_ROWS + tid] = tid < mlu ? gbu[tid] : 0.f;
+            s_lb[3 * LIN_MAX_ROWS + tid] = tid < mlu ? gn2u[tid] : 1.f;
+        }
+        __syncthreads();
+    }
+    const bool lin_x = mlx > 0, lin_u = mlu > 0;
+    const float *lax = s_lax + q * RX, *lau = s_lau + q * RU;
 
     // Scratch: [array][knot][instance][real row].  Addresses are (uniform 64-bit base in SGPRs) + (32-bit byte
     // offset of the lane); the knot index is made opaque per knot (knot_sgpr) so that no per-array 64-bit
@@ -272,6 +316,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
     float *const Sy = Sv + SXN, *const Szw = Sy + SUN, *const Sz = Szw + SUN, *const Sd = Sz + SUN;
     float *const Sgc = Sd + SUN, *const Swc = Sgc + SXN, *const Svc = Swc + SXN;
     float *const Syc = Svc + SXN, *const Szwc = Syc + SUN, *const Szc = Szwc + SUN;
+    float *const Sgl = Szc + SUN, *const Swl = Sgl + SXN, *const Svl = Swl + SXN;
+    float *const Syl = Svl + SXN, *const Szwl = Syl + SUN, *const Szl = Szwl + SUN;
     float *const Ss = Sv, *const Ssu = Sz;  // OS: the fused arrays live where v and z would
 #define SXP(arr, k, m) lane_elem(sgpr_ptr(arr + ((long)(k)*BNX + (XFULL ? (m) : 0))), lxo[XFULL ? 0 : (m)])
 #define SUP(arr, k, m) lane_elem(sgpr_ptr(arr + ((long)(k)*BNU + (UFULL ? (m) : 0))), luo[UFULL ? 0 : (m)])
@@ -334,6 +380,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
                     *SXP(Swc, k, m) = 0.f;
                     if constexpr (!OS) *SXP(Svc, k, m) = warm ? P.svc[b * EX + k * NX + row] : 0.f;
                 }
+                if (lin_x) {
+                    *SXP(Sgl, k, m) = warm ? P.sgl[b * EX + k * NX + row] : 0.f;
+                    *SXP(Swl, k, m) = 0.f;
+                    if constexpr (!OS) *SXP(Svl, k, m) = warm ? P.svl[b * EX + k * NX + row] : 0.f;
+                }
             }
         for (int k = 0; k < N - 1; ++k)
 #pragma unroll
@@ -348,6 +399,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
                     *SUP(Syc, k, m) = warm ? P.syc[b * EU + k * NU + row] : 0.f;
                     *SUP(Szwc, k, m) = 0.f;
                     if constexpr (!OS) *SUP(Szc, k, m) = warm ? P.szc[b * EU + k * NU + row] : 0.f;
+                }
+                if (lin_u) {
+                    *SUP(Syl, k, m) = warm ? P.syl[b * EU + k * NU + row] : 0.f;
+                    *SUP(Szwl, k, m) = 0.f;
+                    if constexpr (!OS) *SUP(Szl, k, m) = warm ? P.szl[b * EU + k * NU + row] : 0.f;
                 }
             }
     }
@@ -375,14 +431,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
     const int last_check_it = ct > 0 ? (P.max_iter / ct) * ct : 0;
     // where the previous iteration's vnew / znew are found (dual residual, admm.cpp:93-96)
     float *const Svold = OS ? Sw : Sv, *const Svcold = OS ? Swc : Svc, *const Szold = OS ? Szw : Sz,
-                 *const Szcold = OS ? Szwc : Szc;
+                 *const Szcold = OS ? Szwc : Szc, *const Svlold = OS ? Swl : Svl, *const Szlold = OS ? Szwl : Szl;
 
     // what one knot of the forward / backward sweep reads from the scratch block, D knots ahead of its use
     struct FwdBuf {
-        float g[RX], v[RX], gc[RX], vc[RX], d[RU], y[RU], z[RU], yc[RU], zc[RU];
+        float g[RX], v[RX], gc[RX], vc[RX], gl[RX], vl[RX], d[RU], y[RU], z[RU], yc[RU], zc[RU], yl[RU], zl[RU];
     };
-    struct BwdBuf {  // OS: the fused arrays in w / zw; else all eight
-        float w[RX], g[RX], wc[RX], gc[RX], zw[RU], y[RU], zwc[RU], yc[RU];
+    struct BwdBuf {  // OS: the fused arrays in w / zw; else all of them
+        float w[RX], g[RX], wc[RX], gc[RX], wl[RX], gl[RX], zw[RU], y[RU], zwc[RU], yc[RU], zwl[RU], yl[RU];
     };
 
     for (int i = 0; i < P.max_iter; ++i) {
@@ -403,9 +459,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
 #pragma unroll
             for (int j = 0; j < D; ++j) {
 #pragma unroll
-                for (int m = 0; m < RX; ++m) fb[j].g[m] = fb[j].v[m] = fb[j].gc[m] = fb[j].vc[m] = 0.f;
+                for (int m = 0; m < RX; ++m)
+                    fb[j].g[m] = fb[j].v[m] = fb[j].gc[m] = fb[j].vc[m] = fb[j].gl[m] = fb[j].vl[m] = 0.f;
 #pragma unroll
-                for (int m = 0; m < RU; ++m) fb[j].d[m] = fb[j].y[m] = fb[j].z[m] = fb[j].yc[m] = fb[j].zc[m] = 0.f;
+                for (int m = 0; m < RU; ++m)
+                    fb[j].d[m] = fb[j].y[m] = fb[j].z[m] = fb[j].yc[m] = fb[j].zc[m] = fb[j].yl[m] = fb[j].zl[m] = 0.f;
             }
             auto fetch_x = [&](int k_, FwdBuf &f) __attribute__((always_inline)) {
                 const int k = knot_sgpr(k_);
@@ -414,6 +472,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
                 if (soc_x) {
                     ldx(Sgc, k, f.gc);
                     if (need_res) ldx(Svcold, k, f.vc);
+                }
+                if (lin_x) {
+                    ldx(Sgl, k, f.gl);
+                    if (need_res) ldx(Svlold, k, f.vl);
                 }
             };
             auto fetch_u = [&](int k_, FwdBuf &f) __attribute__((always_inline)) {
@@ -425,13 +487,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
                     ldu(Syc, k, f.yc);
                     if (need_res) ldu(Szcold, k, f.zc);
                 }
+                if (lin_u) {
+                    ldu(Syl, k, f.yl);
+                    if (need_res) ldu(Szlold, k, f.zl);
+                }
             };
             auto fwd_knot = [&](int k_, FwdBuf &f) __attribute__((always_inline)) {
                 asm volatile("" ::: "memory");  // keep coefficient / bound loads per knot (no hoisting into registers)
                 const int k = knot_sgpr(k_);
                 const bool pf = k + D < N;  // this knot's buffer is refilled for knot k + D once consumed
                 const float *bk = lb + k * G * PK::BW;
-                float xf[RX], vn[RX], gn[RX], wc[RX], gcn[RX], sx[RX];
+                float xf[RX], vn[RX], gn[RX], wc[RX], gcn[RX], wl[RX], gln[RX], sx[RX];
 #pragma unroll
                 for (int m = 0; m < RX; ++m) {
                     const float g_c = mkx(f.g[m], m), v_c = mkx(f.v[m], m);
@@ -459,6 +525,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
                         }
                     }
                 }
+                if constexpr (EXT == 2) {
+                    if (lin_x) {
+#pragma unroll
+                        for (int m = 0; m < RX; ++m) wl[m] = xf[m] + mkx(f.gl[m], m);
+                        project_halfspaces_group<G, RX>(wl, lax, G * RX, mlx, s_lb, s_lb + LIN_MAX_ROWS);
+#pragma unroll
+                        for (int m = 0; m < RX; ++m) {
+                            gln[m] = (mkx(f.gl[m], m) + xf[m]) - wl[m];
+                            pri_x = fmaxf(pri_x, fabsf(xf[m] - wl[m]));
+                            dua_x = fmaxf(dua_x, fabsf(mkx(f.vl[m], m) - wl[m]));
+                            sx[m] += wl[m] - gln[m];
+                        }
+                    }
+                }
                 if (x_owner) {
                     stx(Sg, k, gn);
                     if (keep_w) stx(Sw, k, vn);
@@ -468,11 +548,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
                             stx(Sgc, k, gcn);
                             if (keep_w) stx(Swc, k, wc);
                         }
+                    if constexpr (EXT == 2)
+                        if (lin_x) {
+                            stx(Sgl, k, gln);
+                            if (keep_w) stx(Swl, k, wl);
+                        }
                 }
                 if (pf) fetch_x(k + D, f);
                 if (k < N - 1) {
                     RT u[RU], xn[RX];
-                    float uf[RU], zn[RU], yn[RU], zc2[RU], ycn[RU], su[RU];
+                    float uf[RU], zn[RU], yn[RU], zc2[RU], ycn[RU], zl2[RU], yln[RU], su[RU];
 #pragma unroll
                     for (int m = 0; m < RU; ++m) u[m] = (RT)0;
 #pragma unroll
@@ -510,6 +595,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
                             }
                         }
                     }
+                    if constexpr (EXT == 2) {
+                        if (lin_u) {
+#pragma unroll
+                            for (int m = 0; m < RU; ++m) zl2[m] = uf[m] + mku(f.yl[m], m);
+                            project_halfspaces_group<G, RU>(zl2, lau, G * RU, mlu, s_lb + 2 * LIN_MAX_ROWS,
+                                                            s_lb + 3 * LIN_MAX_ROWS);
+#pragma unroll
+                            for (int m = 0; m < RU; ++m) {
+                                yln[m] = (mku(f.yl[m], m) + uf[m]) - zl2[m];
+                                pri_u = fmaxf(pri_u, fabsf(uf[m] - zl2[m]));
+                                dua_u = fmaxf(dua_u, fabsf(mku(f.zl[m], m) - zl2[m]));
+                                su[m] += zl2[m] - yln[m];
+                            }
+                        }
+                    }
                     if (u_owner) {
                         stu(Sy, k, yn);
                         if (keep_w) stu(Szw, k, zn);
@@ -518,6 +618,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
                             if (soc_u) {
                                 stu(Syc, k, ycn);
                                 if (keep_w) stu(Szwc, k, zc2);
+                            }
+                        if constexpr (EXT == 2)
+                            if (lin_u) {
+                                stu(Syl, k, yln);
+                                if (keep_w) stu(Szwl, k, zl2);
                             }
                     }
                     if (pf && k + D < N - 1) fetch_u(k + D, f);
@@ -563,6 +668,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
                             ldx(Swc, k, f.wc);
                             ldx(Sgc, k, f.gc);
                         }
+                        if (lin_x) {
+                            ldx(Swl, k, f.wl);
+                            ldx(Sgl, k, f.gl);
+                        }
                     }
                 };
                 auto fetchb_u = [&](int k_, BwdBuf &f) __attribute__((always_inline)) {
@@ -576,6 +685,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
                             ldu(Szwc, k, f.zwc);
                             ldu(Syc, k, f.yc);
                         }
+                        if (lin_u) {
+                            ldu(Szwl, k, f.zwl);
+                            ldu(Syl, k, f.yl);
+                        }
                     }
                 };
                 // consume the state-shaped part of a buffer: returns rho-less (vnew - g [+ cone set]) per row
@@ -588,10 +701,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
                         for (int m = 0; m < RX; ++m) {
                             sx[m] = mkx(f.w[m] - f.g[m], m);
                             if (soc_x) sx[m] += mkx(f.wc[m] - f.gc[m], m);
+                            if (lin_x) sx[m] += mkx(f.wl[m] - f.gl[m], m);
                         }
                         if (x_owner) {
                             stx(Sv, k, f.w);
                             if (soc_x) stx(Svc, k, f.wc);
+                            if (lin_x) stx(Svl, k, f.wl);
                         }
                     }
                 };
@@ -604,10 +719,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
                         for (int m = 0; m < RU; ++m) {
                             su[m] = mku(f.zw[m] - f.y[m], m);
                             if (soc_u) su[m] += mku(f.zwc[m] - f.yc[m], m);
+                            if (lin_u) su[m] += mku(f.zwl[m] - f.yl[m], m);
                         }
                         if (u_owner) {
                             stu(Sz, k, f.zw);
                             if (soc_u) stu(Szc, k, f.zwc);
+                            if (lin_u) stu(Szl, k, f.zwl);
                         }
                     }
                 };
@@ -718,6 +835,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
                                 P.sgc[b * EX + k * NX + row] = *SXP(Sgc, k, m);
                                 P.svc[b * EX + k * NX + row] = *SXP(Svc, k, m);
                             }
+                            if (lin_x) {
+                                P.sgl[b * EX + k * NX + row] = *SXP(Sgl, k, m);
+                                P.svl[b * EX + k * NX + row] = *SXP(Svl, k, m);
+                            }
                         }
                     }
                 for (int k = 0; k < N - 1; ++k)
@@ -731,6 +852,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
                             if (soc_u) {
                                 P.syc[b * EU + k * NU + row] = *SUP(Syc, k, m);
                                 P.szc[b * EU + k * NU + row] = *SUP(Szc, k, m);
+                            }
+                            if (lin_u) {
+                                P.syl[b * EU + k * NU + row] = *SUP(Syl, k, m);
+                                P.szl[b * EU + k * NU + row] = *SUP(Szl, k, m);
                             }
                         }
                     }

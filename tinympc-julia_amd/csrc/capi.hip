@@ -125,6 +125,20 @@ int tinympc_set_fdyn(tinympc_solver *s, const double *fdyn) {
     return guarded("set_fdyn", [&] { return s->s.set_fdyn(fdyn); });
 }
 
+int tinympc_enable_linear(tinympc_solver *s, int en_state_linear, int en_input_linear) {
+    if (!s) return -1;
+    s->s.st.en_state_linear = en_state_linear ? 1 : 0;
+    s->s.st.en_input_linear = en_input_linear ? 1 : 0;
+    return 0;
+}
+
+int tinympc_set_linear_constraints(tinympc_solver *s, const double *Alin_x, int rows_x, const double *blin_x,
+                                   const double *Alin_u, int rows_u, const double *blin_u) {
+    if (!s) return -1;
+    return guarded("set_linear_constraints",
+                   [&] { return s->s.set_linear(Alin_x, rows_x, blin_x, Alin_u, rows_u, blin_u); });
+}
+
 int tinympc_set_cone_constraints(tinympc_solver *s, const int *Acu, const int *qcu, const double *cu,
                                  int n_input_cones, const int *Acx, const int *qcx, const double *cx,
                                  int n_state_cones) {
@@ -421,11 +435,8 @@ int update_settings(double abs_pri_tol, double abs_dua_tol, int max_iter, int ch
     (void)adaptive_rho_enable_clipping;
     (void)verbose;
     if (need_global("update_settings")) return -1;
-    if (en_state_linear || en_input_linear) {
-        set_error("update_settings: linear constraints are not supported (submodule-only arithmetic)");
-        return -1;
-    }
     tinympc_enable_cones(g_solver.get(), en_state_soc, en_input_soc);
+    tinympc_enable_linear(g_solver.get(), en_state_linear, en_input_linear);
     if (adaptive_rho) {
         set_error("update_settings: adaptive_rho is not supported (out of scope, SURVEY.md §2 #7)");
         return -1;
@@ -486,14 +497,18 @@ int print_problem_data(int verbose) {
 int set_linear_constraints(double *Alin_x_data, int Alin_x_rows, int Alin_x_cols, double *blin_x_data,
                            int blin_x_len, double *Alin_u_data, int Alin_u_rows, int Alin_u_cols,
                            double *blin_u_data, int blin_u_len, int verbose) {
-    (void)Alin_x_data; (void)Alin_x_cols; (void)blin_x_data; (void)Alin_u_data; (void)Alin_u_cols;
-    (void)blin_u_data; (void)verbose;
+    (void)verbose;
     if (need_global("set_linear_constraints")) return -1;
-    if ((Alin_x_rows > 0 && blin_x_len > 0) || (Alin_u_rows > 0 && blin_u_len > 0)) {
-        set_error("set_linear_constraints: not supported (arithmetic lives only in the absent TinyMPC submodule)");
+    const tmpc::Solver &v = g_solver->s;
+    // an empty side arrives as 0 x n (TinyMPC.jl:264 zeros(0, nu)); a non-empty one must match nx / nu
+    const bool has_x = Alin_x_rows > 0 && blin_x_len > 0, has_u = Alin_u_rows > 0 && blin_u_len > 0;
+    if ((has_x && (Alin_x_cols != v.nx || blin_x_len != Alin_x_rows)) ||
+        (has_u && (Alin_u_cols != v.nu || blin_u_len != Alin_u_rows))) {
+        set_error("set_linear_constraints: Alin_x must be (m x nx) with m entries in blin_x, Alin_u (m x nu) likewise");
         return -1;
     }
-    return 0;
+    return tinympc_set_linear_constraints(g_solver.get(), Alin_x_data, has_x ? Alin_x_rows : 0, blin_x_data,
+                                          Alin_u_data, has_u ? Alin_u_rows : 0, blin_u_data);
 }
 
 int set_cone_constraints(int *Acu_data, int Acu_len, int *qcu_data, int qcu_len, double *cu_data,

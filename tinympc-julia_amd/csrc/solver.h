@@ -34,8 +34,8 @@ struct StreamEntry {
     void (*build_coef)(const Solver &, std::vector<unsigned char> &);
     void (*build_bounds)(const Solver &, std::vector<float> &);
     size_t (*lds_bytes)(int N, int precision);
-    size_t (*scratch_floats)(int N, bool cones);  // per instance
-    hipError_t (*launch)(const AdmmParams &, int precision, bool ext, bool het, hipStream_t);
+    size_t (*scratch_floats)(int N, int sets);  // per instance; sets: 1 box, 2 + cones, 3 + linear
+    hipError_t (*launch)(const AdmmParams &, int precision, int ext, bool het, hipStream_t);  // ext: 0 | 1 fdyn, cones | 2 + linear
 };
 const StreamEntry *find_stream_kernel(int nx, int nu);
 hipError_t launch_generic(const AdmmParams &, int precision, hipStream_t);
@@ -48,6 +48,7 @@ struct Settings {
     int check_termination = 1;                       // TinyMPC.jl:59,202
     int en_state_bound = 0, en_input_bound = 0;      // TinyMPC.jl:94-95
     int en_state_soc = 0, en_input_soc = 0;          // TinyMPC.jl:96-97 (parity unpinned)
+    int en_state_linear = 0, en_input_linear = 0;    // TinyMPC.jl:98-99 (parity unpinned)
 };
 
 struct Solver {
@@ -67,6 +68,15 @@ struct Solver {
     double cx[8] = {0}, cu[8] = {0};
     float *d_sgc = nullptr, *d_svc = nullptr, *d_syc = nullptr, *d_szc = nullptr;
     bool cones_active() const { return (st.en_state_soc && ncx > 0) || (st.en_input_soc && ncu > 0); }
+    // linear inequalities Alin_x x <= blin_x, Alin_u u <= blin_u at every knot (bindings.cpp:413-450; UNPINNED):
+    // rows row-major fp64, at most LIN_MAX_ROWS per side
+    int mlx = 0, mlu = 0;
+    std::vector<double> lin_Ax, lin_bx, lin_Au, lin_bu;
+    float *d_lin = nullptr, *d_sgl = nullptr, *d_svl = nullptr, *d_syl = nullptr, *d_szl = nullptr;
+    bool lin_dirty = false;
+    bool lin_active() const { return (st.en_state_linear && mlx > 0) || (st.en_input_linear && mlu > 0); }
+    // constraint sets whose arrays the stream / generic scratch lays out: box | + cones | + linear
+    int constraint_sets() const { return lin_active() ? 3 : (cones_active() ? 2 : 1); }
     // one problem family PER INSTANCE: per-instance A, B (column-major, concatenated),
     // Riccati caches and diag/rho scalars; runs on the stream kernel with per-lane coefficient columns
     bool hetero = false;
@@ -124,6 +134,7 @@ struct Solver {
     int set_fdyn(const double *f);
     int set_cones(const int *Acu_, const int *qcu_, const double *cu_, int ncu_, const int *Acx_, const int *qcx_,
                   const double *cx_, int ncx_);
+    int set_linear(const double *Ax, int mx, const double *bx, const double *Au, int mu, const double *bu);
     int ensure_extension_buffers();
     int reset();
     int solve_async(hipStream_t stream, int mpc_steps = 0);

@@ -104,6 +104,11 @@ void Solver::free_batch() {
     dev_free(d_svc);
     dev_free(d_syc);
     dev_free(d_szc);
+    dev_free(d_lin);
+    dev_free(d_sgl);
+    dev_free(d_svl);
+    dev_free(d_syl);
+    dev_free(d_szl);
     dev_free(d_mpc_x);
     dev_free(d_mpc_u);
     dev_free(d_mpc_iter);
@@ -193,7 +198,7 @@ int Solver::select_kernel() {
     const char *genv = std::getenv("TINYMPC_HIP_GROUP");
     const KernelEntry *k = genv ? find_quad_kernel(nx, nu, N, std::atoi(genv)) : nullptr;
     if (!k) k = select_quad_kernel(nx, nu, N, batch);
-    if (has_fdyn || cones_active() || hetero) k = nullptr;  // extensions run on the stream / generic kernels
+    if (has_fdyn || cones_active() || lin_active() || hetero) k = nullptr;  // extensions run on the stream / generic kernels
     if (std::getenv("TINYMPC_HIP_NO_QUAD")) k = nullptr;    // tuning aid: time the fallback kernels on any shape
     if (!k && (nx > GEN_MAX_NX || nu > GEN_MAX_NU)) {
         set_error("problem shape exceeds the generic kernel limits (nx <= 64, nu <= 32)");
@@ -273,6 +278,12 @@ int Solver::reset() {
         HIP_TRY(hipMemset(d_svc, 0, Bn * EX * sizeof(float)));
         HIP_TRY(hipMemset(d_syc, 0, Bn * EU * sizeof(float)));
         HIP_TRY(hipMemset(d_szc, 0, Bn * EU * sizeof(float)));
+    }
+    if (d_sgl) {
+        HIP_TRY(hipMemset(d_sgl, 0, Bn * EX * sizeof(float)));
+        HIP_TRY(hipMemset(d_svl, 0, Bn * EX * sizeof(float)));
+        HIP_TRY(hipMemset(d_syl, 0, Bn * EU * sizeof(float)));
+        HIP_TRY(hipMemset(d_szl, 0, Bn * EU * sizeof(float)));
     }
     return 0;
 }
@@ -436,13 +447,55 @@ int Solver::set_cones(const int *Acu_, const int *qcu_, const double *cu_, int n
     return select_kernel() || ensure_extension_buffers();
 }
 
-// Scratch and cone warm-start buffers of the generic kernel, sized for the current batch / options.
+// UNPINNED (bindings.cpp:413-450): Alin_x (mx x nx), Alin_u (mu x nu) column-major; enables the non-empty halves
+int Solver::set_linear(const double *Ax, int mx, const double *bx, const double *Au, int mu, const double *bu) {
+    if (mx < 0 || mu < 0 || mx > LIN_MAX_ROWS || mu > LIN_MAX_ROWS) {
+        set_error("set_linear_constraints: at most 8 rows per side");
+        return -1;
+    }
+    if ((mx > 0 && (!Ax || !bx)) || (mu > 0 && (!Au || !bu))) {
+        set_error("set_linear_constraints: null matrix or right-hand side");
+        return -1;
+    }
+    auto take = [&](const double *A, const double *b, int m, int n, std::vector<double> &Ar, std::vector<double> &br) {
+        Ar.assign((size_t)m * n, 0.0);
+        br.assign((size_t)m, 0.0);
+        for (int k = 0; k < m; ++k) {
+            double n2 = 0.0;
+            for (int j = 0; j < n; ++j) {
+                Ar[(size_t)k * n + j] = A[k + (size_t)j * m];
+                n2 += A[k + (size_t)j * m] * A[k + (size_t)j * m];
+            }
+            if (!(n2 > 0.0)) return false;
+            br[k] = b[k];
+        }
+        return true;
+    };
+    std::vector<double> ax, bxv, au, buv;
+    if (!take(Ax, bx, mx, nx, ax, bxv) || !take(Au, bu, mu, nu, au, buv)) {
+        set_error("set_linear_constraints: a constraint row is all zero");
+        return -1;
+    }
+    mlx = mx;
+    mlu = mu;
+    lin_Ax.swap(ax);
+    lin_bx.swap(bxv);
+    lin_Au.swap(au);
+    lin_bu.swap(buv);
+    lin_dirty = true;
+    if (mlx > 0) st.en_state_linear = 1;  // bindings.cpp:438-443: only the non-empty halves are enabled
+    if (mlu > 0) st.en_input_linear = 1;
+    return select_kernel() || ensure_extension_buffers();
+}
+
+// Scratch and cone / linear warm-start buffers of the stream and generic kernels, sized for the current batch / options.
 int Solver::ensure_extension_buffers() {
     if (ke) return 0;
     HIP_TRY(hipSetDevice(device));
     const size_t Bn = (size_t)batch, EX = (size_t)ex(), EU = (size_t)eu();
-    size_t need = Bn * (cones_active() ? (8 * EX + 9 * EU) : (5 * EX + 6 * EU));
-    if (se) need = std::max(need, Bn * se->scratch_floats(N, cones_active()));
+    const size_t sets = (size_t)constraint_sets();
+    size_t need = Bn * ((2 + 3 * sets) * EX + (3 + 3 * sets) * EU);  // generic kernel: admm_generic.hip.h
+    if (se) need = std::max(need, Bn * se->scratch_floats(N, (int)sets));
     if (scratch_cap < need) {
         if (dev_alloc(d_scratch, need)) return -1;
         scratch_cap = need;
@@ -455,6 +508,34 @@ int Solver::ensure_extension_buffers() {
         HIP_TRY(hipMemset(d_svc, 0, Bn * EX * sizeof(float)));
         HIP_TRY(hipMemset(d_syc, 0, Bn * EU * sizeof(float)));
         HIP_TRY(hipMemset(d_szc, 0, Bn * EU * sizeof(float)));
+    }
+    if (lin_active() && !d_sgl) {
+        if (dev_alloc(d_sgl, Bn * EX) || dev_alloc(d_svl, Bn * EX) || dev_alloc(d_syl, Bn * EU) ||
+            dev_alloc(d_szl, Bn * EU))
+            return -1;
+        HIP_TRY(hipMemset(d_sgl, 0, Bn * EX * sizeof(float)));
+        HIP_TRY(hipMemset(d_svl, 0, Bn * EX * sizeof(float)));
+        HIP_TRY(hipMemset(d_syl, 0, Bn * EU * sizeof(float)));
+        HIP_TRY(hipMemset(d_szl, 0, Bn * EU * sizeof(float)));
+    }
+    if (lin_dirty || (lin_active() && !d_lin)) {
+        // [mlx][nx] rows | b | |a|^2 | [mlu][nu] rows | b | |a|^2   (fp32)
+        std::vector<float> pk;
+        auto put = [&](const std::vector<double> &A, const std::vector<double> &b, int m, int n) {
+            for (size_t i = 0; i < (size_t)m * n; ++i) pk.push_back((float)A[i]);
+            for (int k = 0; k < m; ++k) pk.push_back((float)b[k]);
+            for (int k = 0; k < m; ++k) {
+                double n2 = 0.0;
+                for (int j = 0; j < n; ++j) n2 += A[(size_t)k * n + j] * A[(size_t)k * n + j];
+                pk.push_back((float)n2);
+            }
+        };
+        put(lin_Ax, lin_bx, mlx, nx);
+        put(lin_Au, lin_bu, mlu, nu);
+        if (pk.empty()) pk.push_back(0.f);
+        if (dev_alloc(d_lin, pk.size())) return -1;
+        HIP_TRY(hipMemcpy(d_lin, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+        lin_dirty = false;
     }
     return 0;
 }
@@ -532,6 +613,13 @@ int Solver::solve_async(hipStream_t stream, int mpc_steps) {
     P.svc = d_svc;
     P.syc = d_syc;
     P.szc = d_szc;
+    P.mlx = st.en_state_linear ? mlx : 0;
+    P.mlu = st.en_input_linear ? mlu : 0;
+    P.lin = d_lin;
+    P.sgl = d_sgl;
+    P.svl = d_svl;
+    P.syl = d_syl;
+    P.szl = d_szl;
     HIP_TRY(hipMemsetAsync(d_gstat, 0, GSTAT_WORDS * sizeof(uint32_t), stream));
     if (profiling) {
         if (!ev0) HIP_TRY(hipEventCreate(&ev0));
@@ -539,7 +627,7 @@ int Solver::solve_async(hipStream_t stream, int mpc_steps) {
         HIP_TRY(hipEventRecord(ev0, stream));
     }
     HIP_TRY(ke ? ke->launch(P, precision, state_bounds_active, stream)
-               : (se ? se->launch(P, precision, has_fdyn || cones_active(), hetero, stream)
+               : (se ? se->launch(P, precision, lin_active() ? 2 : ((has_fdyn || cones_active()) ? 1 : 0), hetero, stream)
                      : launch_generic(P, precision, stream)));
     if (profiling) HIP_TRY(hipEventRecord(ev1, stream));
     HIP_TRY(hipMemcpyAsync(h_gstat, d_gstat, GSTAT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));

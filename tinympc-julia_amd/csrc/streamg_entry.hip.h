@@ -124,39 +124,43 @@ size_t streamg_lds_bytes(int N, int precision) {
     return rt * G * PK::CP + 4 * ((size_t)N * G * PK::BW + G * PK::DW);
 }
 
-// floats of scratch per instance: 3 (6 with cones) state-shaped + 4 (7) input-shaped arrays of real rows
+// floats of scratch per instance: 3 state-shaped and 3 input-shaped arrays per constraint set (box | + cones |
+// + linear inequalities), + d
 template <int NX, int NU>
-size_t streamg_scratch_floats(int N, bool cones) {
-    return (size_t)NX * N * (cones ? 6 : 3) + (size_t)NU * (N - 1) * (cones ? 7 : 4);
+size_t streamg_scratch_floats(int N, int sets) {
+    return (size_t)NX * N * (3 * sets) + (size_t)NU * (N - 1) * (3 * sets + 1);
 }
 
 template <int NX, int NU, int G>
-hipError_t launch_streamg(const AdmmParams &P, int precision, bool ext, bool het, hipStream_t stream) {
+hipError_t launch_streamg(const AdmmParams &P, int precision, int ext, bool het, hipStream_t stream) {
     const int grid = (P.batch + 256 / G - 1) / (256 / G);
     const size_t lds = streamg_lds_bytes<NX, NU, G>(P.N, precision);
     const bool oneshot = P.cold_start && !P.save_state;  // nothing of the workspace outlives the launch
-#define TMPC_LAUNCH(RT_, EXT_, HET_, OS_)                                                                       \
-    do {                                                                                                        \
-        if (lds > 48 * 1024)                                                                                    \
+#define TMPC_LAUNCH(RT_, EXT_, HET_, OS_)                                                                          \
+    do {                                                                                                           \
+        if (lds > 48 * 1024)                                                                                       \
             (void)hipFuncSetAttribute((const void *)admm_streamg_kernel<NX, NU, G, RT_, EXT_, HET_, OS_>,          \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
         hipLaunchKernelGGL((admm_streamg_kernel<NX, NU, G, RT_, EXT_, HET_, OS_>), dim3(grid), dim3(256), lds, stream, \
-                           P);                                                                                  \
+                           P);                                                                                     \
     } while (0)
-#define TMPC_LAUNCH_OS(RT_, EXT_, HET_)                                          \
-    do {                                                                         \
+#define TMPC_LAUNCH_OS(RT_, EXT_, HET_)                                                            \
+    do {                                                                                           \
         if (oneshot) TMPC_LAUNCH(RT_, EXT_, HET_, true); else TMPC_LAUNCH(RT_, EXT_, HET_, false); \
     } while (0)
-#define TMPC_LAUNCH_RT(RT_)                                                                    \
-    do {                                                                                       \
-        if (het) {                                                                             \
-            if (ext) TMPC_LAUNCH_OS(RT_, true, true); else TMPC_LAUNCH_OS(RT_, false, true);   \
-        } else {                                                                               \
-            if (ext) TMPC_LAUNCH_OS(RT_, true, false); else TMPC_LAUNCH_OS(RT_, false, false); \
-        }                                                                                      \
+#define TMPC_LAUNCH_EXT(RT_, HET_)                       \
+    do {                                                 \
+        if (ext == 2) TMPC_LAUNCH_OS(RT_, 2, HET_);      \
+        else if (ext == 1) TMPC_LAUNCH_OS(RT_, 1, HET_); \
+        else TMPC_LAUNCH_OS(RT_, 0, HET_);               \
+    } while (0)
+#define TMPC_LAUNCH_RT(RT_)                                                        \
+    do {                                                                           \
+        if (het) TMPC_LAUNCH_EXT(RT_, true); else TMPC_LAUNCH_EXT(RT_, false);     \
     } while (0)
     if (precision == 0) TMPC_LAUNCH_RT(double); else TMPC_LAUNCH_RT(float);
 #undef TMPC_LAUNCH_RT
+#undef TMPC_LAUNCH_EXT
 #undef TMPC_LAUNCH_OS
 #undef TMPC_LAUNCH
     return hipGetLastError();

@@ -20,7 +20,7 @@ module TinyMPC
 # makes the reference's own src/TinyMPC.jl use this library without adopting this module.
 
 export TinyMPCSolver, setup, solve, get_solution, get_status, set_x0, set_x_ref, set_u_ref,
-       set_bound_constraints, set_linear_constraints, set_cone_constraints, update_settings,
+       set_bound_constraints, set_linear_constraints, set_equality_constraints, set_cone_constraints, update_settings,
        set_cache_terms, set_batch_size, reset_workspace, print_problem_data
 
 using LinearAlgebra, Libdl, Printf
@@ -182,7 +182,8 @@ function set_bound_constraints(solver::TinyMPCSolver, x_min::Matrix{Float64}, x_
         "Failed to set bound constraints")
 end
 
-# Linear constraints: only empty blocks are accepted.  Cones: per-knot second-order cones, inputs first,
+# Linear inequalities Alin_x x <= blin_x, Alin_u u <= blin_u at every knot (at most 8 rows per side); equalities as
+# two opposite rows each.  Cones: per-knot second-order cones, inputs first,
 # 0-based first row `Ac`, dimension `qc`, slope `c` (last row of the block is the axis); parity unpinned.
 function set_linear_constraints(solver::TinyMPCSolver, Alin_x::Matrix{Float64}, blin_x::Vector{Float64},
                                 Alin_u::Matrix{Float64}, blin_u::Vector{Float64}; verbose::Bool=false)
@@ -191,6 +192,11 @@ function set_linear_constraints(solver::TinyMPCSolver, Alin_x::Matrix{Float64}, 
               Alin_x, size(Alin_x, 1), size(Alin_x, 2), blin_x, length(blin_x),
               Alin_u, size(Alin_u, 1), size(Alin_u, 2), blin_u, length(blin_u), _flag(verbose)),
         "Failed to set linear constraints")
+end
+
+function set_equality_constraints(solver::TinyMPCSolver, Aeq_x::Matrix{Float64}, beq_x::Vector{Float64};
+                                  Aeq_u::Matrix{Float64}=zeros(0, solver.nu), beq_u::Vector{Float64}=zeros(Float64, 0))
+    return set_linear_constraints(solver, vcat(Aeq_x, -Aeq_x), vcat(beq_x, -beq_x), vcat(Aeq_u, -Aeq_u), vcat(beq_u, -beq_u))
 end
 
 function set_cone_constraints(solver::TinyMPCSolver, Acu::Vector{Int32}, qcu::Vector{Int32}, cu::Vector{Float64},

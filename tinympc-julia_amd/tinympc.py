@@ -75,6 +75,8 @@ SIGNATURES = {
     "tinympc_set_fdyn": (c_int, [c_vp, c_dp]),
     "tinympc_set_cone_constraints": (c_int, [c_vp, c_ip, c_ip, c_dp, c_int, c_ip, c_ip, c_dp, c_int]),
     "tinympc_enable_cones": (c_int, [c_vp, c_int, c_int]),
+    "tinympc_set_linear_constraints": (c_int, [c_vp, c_dp, c_int, c_dp, c_dp, c_int, c_dp]),
+    "tinympc_enable_linear": (c_int, [c_vp, c_int, c_int]),
     "tinympc_set_x0": (c_int, [c_vp, c_dp, c_int]),
     "tinympc_set_x_ref": (c_int, [c_vp, c_dp, c_int]),
     "tinympc_set_u_ref": (c_int, [c_vp, c_dp, c_int]),
@@ -309,17 +311,34 @@ def set_bound_constraints(solver, x_min, x_max, u_min, u_max, *, verbose=False):
     return status
 
 
+def _lin_block(A, b, n):
+    b = np.ascontiguousarray(np.asarray(b, dtype=np.float64).reshape(-1))
+    A = np.asarray(A, dtype=np.float64)
+    A = _mat(A.reshape(len(b), n) if len(b) else np.zeros((0, n)))
+    return A, b
+
+
 def set_linear_constraints(solver, Alin_x, blin_x, Alin_u, blin_u, *, verbose=False):
-    """TinyMPC.jl:229-243.  Only empty blocks are accepted (parity unpinned)."""
-    Ax, Au = _mat(np.asarray(Alin_x, dtype=np.float64).reshape(len(blin_x), -1)), _mat(
-        np.asarray(Alin_u, dtype=np.float64).reshape(len(blin_u), -1))
-    bx, bu = np.asarray(blin_x, dtype=np.float64), np.asarray(blin_u, dtype=np.float64)
+    """TinyMPC.jl:229-243: Alin_x x <= blin_x, Alin_u u <= blin_u at every knot; parity unpinned."""
+    _need_setup(solver)
+    Ax, bx = _lin_block(Alin_x, blin_x, solver.nx)
+    Au, bu = _lin_block(Alin_u, blin_u, solver.nu)
     status = load_library().set_linear_constraints(_dp(Ax), Ax.shape[0], Ax.shape[1], _dp(bx), len(bx),
                                                    _dp(Au), Au.shape[0], Au.shape[1], _dp(bu), len(bu),
                                                    1 if verbose else 0)
     if status != 0:
         raise TinyMPCError(f"Failed to set linear constraints ({_err()})")
     return status
+
+
+def set_equality_constraints(solver, Aeq_x, beq_x, Aeq_u=None, beq_u=None):
+    """TinyMPC.jl:261-270: equalities as two inequalities each"""
+    _need_setup(solver)
+    Ax, bx = _lin_block(Aeq_x, beq_x, solver.nx)
+    Au, bu = _lin_block(np.zeros((0, solver.nu)) if Aeq_u is None else Aeq_u, [] if beq_u is None else beq_u,
+                        solver.nu)
+    return set_linear_constraints(solver, np.vstack([Ax, -Ax]), np.concatenate([bx, -bx]),
+                                  np.vstack([Au, -Au]), np.concatenate([bu, -bu]))
 
 
 def set_cone_constraints(solver, Acu, qcu, cu, Acx, qcx, cx, *, verbose=False):
@@ -447,6 +466,20 @@ class BatchSolver:
         self._chk(self.lib.tinympc_set_cone_constraints(
             self.h, ia[0].ctypes.data_as(c_ip), ia[1].ctypes.data_as(c_ip), _dp(da[0]), len(da[0]),
             ia[2].ctypes.data_as(c_ip), ia[3].ctypes.data_as(c_ip), _dp(da[1]), len(da[1])), "set_cone_constraints")
+
+    def set_linear_constraints(self, Alin_x, blin_x, Alin_u, blin_u):
+        """Alin_x x <= blin_x, Alin_u u <= blin_u at every knot (TinyMPC.jl:229-243); parity unpinned"""
+        Ax, bx = _lin_block(Alin_x, blin_x, self.nx)
+        Au, bu = _lin_block(Alin_u, blin_u, self.nu)
+        self._chk(self.lib.tinympc_set_linear_constraints(self.h, _dp(Ax), Ax.shape[0], _dp(bx), _dp(Au), Au.shape[0],
+                                                          _dp(bu)), "set_linear_constraints")
+
+    def set_equality_constraints(self, Aeq_x, beq_x, Aeq_u=None, beq_u=None):
+        """equalities as two inequalities each (TinyMPC.jl:261-270)"""
+        Ax, bx = _lin_block(Aeq_x, beq_x, self.nx)
+        Au, bu = _lin_block(np.zeros((0, self.nu)) if Aeq_u is None else Aeq_u, [] if beq_u is None else beq_u, self.nu)
+        self.set_linear_constraints(np.vstack([Ax, -Ax]), np.concatenate([bx, -bx]), np.vstack([Au, -Au]),
+                                    np.concatenate([bu, -bu]))
 
     def get_cache_terms(self):
         nx, nu = self.nx, self.nu
