@@ -119,6 +119,17 @@ def measured_traffic(family, precision, batch, kernel):
     return None
 
 
+def measured_valu_issue(family, batch, kernel):
+    """Fraction of the VALU issue cycles the kernel used, from the committed rocprofv3 SQ counter passes
+    (profiles/*_sq_counters.json: SQ_INSTS_VALU x 4 cycles / (busy cycles x 1 024 SIMDs)); None if not measured."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{family}_sq_counters.json"))):
+        e = json.load(open(path))
+        if (e.get("kernel"), e.get("batch")) == (kernel, batch):
+            return e.get("derived_valu_issue_utilisation")
+    return None
+
+
 def run_mpc_mode(args, t, bs, prob, x0, dev, stream, torch):
     """Extra (not the headline): the closed-loop regime of SURVEY 8(f) — warm-started solves, max_iter 10,
     tol 1e-3 — as K launches of one step (workspace round-trips through HBM every step) and as one fused
@@ -243,7 +254,8 @@ def main():
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "compute-bound path (SURVEY 8d): ~430 FLOP/B; see valu"},
             "valu": {"achieved_tflops": ach_tf, "peak_tflops": FP32_PEAK_TFLOPS,
-                     "frac": ach_tf / FP32_PEAK_TFLOPS, "algorithmic_flops_per_launch": alg_flops},
+                     "frac": ach_tf / FP32_PEAK_TFLOPS, "algorithmic_flops_per_launch": alg_flops,
+                     "issue_utilisation": measured_valu_issue(args.config, batch, bs.kernel_name) if args.precision == 0 else None},
         }
         if bs.kernel_name.startswith("stream"):
             # the state lives in HBM by design on this kernel: its roofline is that stream, not the I/O bytes

@@ -4,7 +4,7 @@ import csv, glob, json, os, shutil, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 traffic = []
-for cfg in ("cartpole", "quadrotor"):
+for cfg in ("cartpole", "quadrotor", "rocket_soc"):
     ks = sorted(glob.glob(f"{root}/gpurun_out/prof_{tag}_{cfg}/*/*_kernel_stats.csv"), key=os.path.getmtime)
     if not ks:
         continue
@@ -20,9 +20,30 @@ for cfg in ("cartpole", "quadrotor"):
             w.writerow(["Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "Counter_Name", "Counter_Value"])
             for r in rows:
                 w.writerow([r[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "Counter_Name", "Counter_Value")])
+    # SQ counters: one row per dispatch and counter; average over the dispatches of the ADMM kernel
+    sq = {}
+    for d in sorted(glob.glob(f"{root}/gpurun_out/pmcS_{tag}_{cfg}_*")):
+        fs = sorted(glob.glob(f"{d}/*/*_counter_collection.csv"), key=os.path.getmtime)
+        if not fs:
+            continue
+        acc = {}
+        for r in csv.DictReader(open(fs[-1])):
+            if "admm" in r["Kernel_Name"]:
+                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            sq[k] = sum(v) / len(v)
+    if sq:
+        if "SQ_INSTS_VALU" in sq and "SQ_BUSY_CYCLES" in sq and "SQ_WAVES" in sq:
+            # SQ_BUSY_CYCLES is summed over the 32 shader engines' SQs; a wave64 VALU instruction holds its SIMD 4 cycles
+            busy = sq["SQ_BUSY_CYCLES"] / 32.0
+            sq["derived_valu_issue_utilisation"] = sq["SQ_INSTS_VALU"] * 4.0 / (busy * 1024.0)
+            sq["derived_note"] = "SQ_INSTS_VALU x 4 cycles / (kernel busy cycles x 1024 SIMDs)"
     log = open(f"{root}/gpurun_out/prof_{tag}_{cfg}.log").read()
     line = [l for l in log.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
+    if sq:
+        sq["family"], sq["kernel"], sq["batch"] = cfg, d["config"]["kernel"], d["config"]["batch_per_gpu"]
+        json.dump(sq, open(f"{root}/profiles/{tag}_{cfg}_sq_counters.json", "w"), indent=1)
     traffic.append({"family": cfg, "precision": 0, "batch": d["config"]["batch_per_gpu"], "kernel": d["config"]["kernel"],
                     "FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"],
                     "hbm_bytes_per_launch": (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
