@@ -369,13 +369,16 @@ def test_full_size_properties(hip_lib, oracle_built, family):
     bs.close()
 
 
-def test_edge_cases(hip_lib, oracle_built):
-    prob = t.problems.cartpole(20, u_bound=0.5)
+@pytest.mark.parametrize("N,kernel", [(20, "quad<4,1,20"), (19, "stream4<4,1>"), (3, "stream4<4,1>")])
+def test_edge_cases(hip_lib, oracle_built, N, kernel):
+    """on the unrolled kernel and on the run-time-horizon one (incl. a 3-knot horizon)"""
+    prob = t.problems.cartpole(N, u_bound=0.5)
     # batch = 1, 3 (less than a quad row of a wavefront), 17 (one instance into the 2nd wavefront), 65
     for B in (1, 3, 17, 65):
         x0 = t.problems.cartpole_x0(B, seed=9)
         ref = _oracle_batch(oracle_built, prob, x0, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=30)
         bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+        assert bs.kernel_name.startswith(kernel)
         bs.update_settings(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=30, check_termination=1)
         bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
         bs.set_x0(x0)
