@@ -194,13 +194,20 @@ def main():
     stream = torch.cuda.current_stream(dev)
     gstat = sharding.device_tensor(bs.device_buffers()["gstat"], (8,), torch.int32, dev)
 
+    pending = []
+
     def step():
         bs.solve_async(stream.cuda_stream)
         if world > 1:
-            # the path's only exchange: global max residuals / unsolved count (16 + 4 bytes)
-            sharding.allreduce_status(gstat)
+            # the path's only exchange: global max residuals / unsolved count (16 + 4 bytes).  It is started on a
+            # snapshot of the status block and awaited at the fence, so it overlaps the next solve.
+            pending.append(sharding.allreduce_status_async(gstat))
 
     def fence():
+        for _, work in pending:
+            if work is not None:
+                work.wait()
+        del pending[:-1]          # the last one carries the global status of the last solve
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -226,6 +233,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     status = bs.solve_status()
+    if world > 1 and pending:
+        status = max(status, sharding.decode_status(pending[-1][0].cpu().numpy())[0])
     st = bs.get_status()
     assert int(st["iter"].min()) == args.iters and int(st["iter"].max()) == args.iters, "work skipped"
 

@@ -86,6 +86,18 @@ def _worker(rank, world, port, total, tol, out_dir):
 
     ss = ShardedSolver(lambda n, lo, hi: OracleLocal(n, lo, hi), total)
     status, res = ss.solve()
+    # pipelined form (bench.py): back-to-back solves, each status exchange started on a snapshot and awaited later,
+    # while the live block is already being overwritten by the next solve
+    from tinympc_julia_amd.sharding import allreduce_status_async, decode_status
+    pend = []
+    for _ in range(3):
+        ss.local.solve_async()
+        pend.append(allreduce_status_async(ss.local.status_tensor()))
+        ss.local.st.zero_()                      # what the next solve does to the live block
+    for _, work in pend:
+        work.wait()
+    pipe = [decode_status(snap.numpy()) for snap, _ in pend]
+    assert all(p[0] == status and np.array_equal(p[1], res) for p in pipe)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), status=status, res=res, lo=ss.lo, hi=ss.hi,
              iters=ss.local.result["iter"], u=ss.local.result["u"])
     dist.barrier()
