@@ -181,10 +181,12 @@ int tinympc_solve_status(tinympc_solver *s);
 int tinympc_mpc_rollout(tinympc_solver *s, int steps, void *hip_stream);
 int tinympc_get_mpc_log(tinympc_solver *s, double *x, double *u, int *iter);
 /* Kernel timing: when enabled, every solve records HIP events immediately around the ADMM kernel
- * launch on the launch stream; tinympc_kernel_elapsed_ms returns the last kernel's duration
+ * launch on the launch stream; tinympc_kernel_elapsed_ms returns the last kernel's duration,
+ * tinympc_kernel_elapsed_mean_ms the mean over the last `last_n` launches (at most 256)
  * (call after the stream has been synchronised; < 0 if unavailable). */
 int tinympc_set_profiling(tinympc_solver *s, int enable);
 double tinympc_kernel_elapsed_ms(tinympc_solver *s);
+double tinympc_kernel_elapsed_mean_ms(tinympc_solver *s, int last_n);
 /* Arithmetic of the two serial recurrences (rollout, Riccati gradient): 0 = fp64 accumulation
  * with fp64 coefficients (default; ADMM state and elementwise steps stay fp32), 1 = all fp32. */
 int tinympc_set_precision(tinympc_solver *s, int precision);

@@ -281,6 +281,9 @@ int tinympc_set_profiling(tinympc_solver *s, int enable) {
     return 0;
 }
 double tinympc_kernel_elapsed_ms(tinympc_solver *s) { return s ? s->s.kernel_elapsed_ms() : -1.0; }
+double tinympc_kernel_elapsed_mean_ms(tinympc_solver *s, int last_n) {
+    return s ? s->s.kernel_elapsed_mean_ms(last_n) : -1.0;
+}
 int tinympc_set_precision(tinympc_solver *s, int precision) {
     if (!s || precision < 0 || precision > 1) return -1;
     if (s->s.precision != precision) s->s.packs_dirty = true;

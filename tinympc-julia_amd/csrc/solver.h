@@ -112,7 +112,9 @@ struct Solver {
     size_t scratch_cap = 0;
     bool solved_once = false;
     bool profiling = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    static constexpr int EV_RING = 256;  // event pairs around the most recent launches (profiling mode)
+    std::vector<hipEvent_t> ev_ring;     // [2 * EV_RING], created on first use
+    long launches = 0;                   // launches recorded since profiling was switched on
     int precision = 0;  // 0: fp64 recurrences (default), 1: all fp32
 
     int ex() const { return nx * N; }
@@ -141,6 +143,7 @@ struct Solver {
     int get_mpc_log(double *x, double *u, int *iter);
     int solve_status();
     double kernel_elapsed_ms();
+    double kernel_elapsed_mean_ms(int last_n);
     int get_traj(bool states, double *buf);
     int get_status(int *iter, int *solved, double *res4);
     int get_workspace(double *d, double *y, double *g, double *v, double *z);

@@ -80,8 +80,8 @@ Solver::~Solver() {
     dev_free(d_gstat);
     if (h_gstat) (void)hipHostFree(h_gstat);
     h_gstat = nullptr;
-    if (ev0) (void)hipEventDestroy(ev0);
-    if (ev1) (void)hipEventDestroy(ev1);
+    for (hipEvent_t e : ev_ring)
+        if (e) (void)hipEventDestroy(e);
 }
 
 void Solver::free_batch() {
@@ -621,16 +621,25 @@ int Solver::solve_async(hipStream_t stream, int mpc_steps) {
     P.syl = d_syl;
     P.szl = d_szl;
     HIP_TRY(hipMemsetAsync(d_gstat, 0, GSTAT_WORDS * sizeof(uint32_t), stream));
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (profiling) {
-        if (!ev0) HIP_TRY(hipEventCreate(&ev0));
-        if (!ev1) HIP_TRY(hipEventCreate(&ev1));
+        if (ev_ring.empty()) {
+            ev_ring.assign(2 * EV_RING, nullptr);
+            for (hipEvent_t &e : ev_ring) HIP_TRY(hipEventCreate(&e));
+        }
+        ev0 = ev_ring[2 * (launches % EV_RING)];
+        ev1 = ev_ring[2 * (launches % EV_RING) + 1];
         HIP_TRY(hipEventRecord(ev0, stream));
     }
     HIP_TRY(ke ? ke->launch(P, precision, state_bounds_active, stream)
                : (se ? se->launch(P, precision, lin_active() ? 2 : ((has_fdyn || cones_active()) ? 1 : 0), hetero, stream)
                      : launch_generic(P, precision, stream)));
-    if (profiling) HIP_TRY(hipEventRecord(ev1, stream));
-    HIP_TRY(hipMemcpyAsync(h_gstat, d_gstat, GSTAT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    if (profiling) {
+        HIP_TRY(hipEventRecord(ev1, stream));
+        launches += 1;
+    }
+    // the status block stays on the device; solve_status() fetches it when asked (nothing but the kernel and the
+    // 32-byte clear is enqueued per solve)
     solved_once = true;
     return 0;
 }
@@ -640,6 +649,8 @@ int Solver::solve_status() {
         set_error("solve_status before any solve");
         return -1;
     }
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemcpy(h_gstat, d_gstat, GSTAT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return h_gstat[4] == 0 ? 0 : 1;  // admm.cpp:192 / :206 folded over the batch
 }
 
@@ -665,11 +676,19 @@ int Solver::get_mpc_log(double *x, double *u, int *iter) {
     return 0;
 }
 
-double Solver::kernel_elapsed_ms() {
-    if (!profiling || !ev0 || !ev1) return -1.0;
-    float ms = -1.f;
-    if (hipEventElapsedTime(&ms, ev0, ev1) != hipSuccess) return -1.0;
-    return (double)ms;
+double Solver::kernel_elapsed_ms() { return kernel_elapsed_mean_ms(1); }
+
+// mean duration of the last `last_n` launches (at most EV_RING), from the event pairs recorded around each
+double Solver::kernel_elapsed_mean_ms(int last_n) {
+    if (!profiling || ev_ring.empty() || launches == 0 || last_n <= 0) return -1.0;
+    const long n = std::min<long>(std::min<long>(last_n, EV_RING), launches);
+    double sum = 0.0;
+    for (long i = launches - n; i < launches; ++i) {
+        float ms = -1.f;
+        if (hipEventElapsedTime(&ms, ev_ring[2 * (i % EV_RING)], ev_ring[2 * (i % EV_RING) + 1]) != hipSuccess) return -1.0;
+        sum += ms;
+    }
+    return sum / (double)n;
 }
 
 int Solver::get_traj(bool states, double *buf) {

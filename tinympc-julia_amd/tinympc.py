@@ -96,6 +96,7 @@ SIGNATURES = {
     "tinympc_get_mpc_log": (c_int, [c_vp, c_dp, c_dp, c_ip]),
     "tinympc_set_profiling": (c_int, [c_vp, c_int]),
     "tinympc_kernel_elapsed_ms": (c_dbl, [c_vp]),
+    "tinympc_kernel_elapsed_mean_ms": (c_dbl, [c_vp, c_int]),
     "tinympc_set_precision": (c_int, [c_vp, c_int]),
     "tinympc_kernel_name": (ctypes.c_char_p, [c_vp]),
     "tinympc_algorithmic_bytes": (c_dbl, [c_vp]),
@@ -567,8 +568,11 @@ class BatchSolver:
     def set_profiling(self, on):
         self._chk(self.lib.tinympc_set_profiling(self.h, 1 if on else 0), "set_profiling")
 
-    def kernel_elapsed_ms(self):
-        return float(self.lib.tinympc_kernel_elapsed_ms(self.h))
+    def kernel_elapsed_ms(self, last_n=1):
+        """duration of the last launch, or the mean over the last `last_n` launches (profiling mode)"""
+        if last_n == 1:
+            return float(self.lib.tinympc_kernel_elapsed_ms(self.h))
+        return float(self.lib.tinympc_kernel_elapsed_mean_ms(self.h, int(last_n)))
 
     def set_precision(self, precision):
         """0: fp64 recurrences (default), 1: all fp32"""
