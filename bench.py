@@ -8,9 +8,10 @@
 A "step" is one batched solve of the workload on every rank: BASELINE.json configs[1] —
 cartpole nx=4 nu=1 N=20, u in [-0.5, 0.5], batch 65 536 per GPU, cold start, exactly 100 ADMM
 iterations per instance (tolerances 0).  Inputs are resident in HBM before the timed region.
-One process per GPU; the batch shards with no data-path collective; each step ends with the
-path's only exchange: an all-reduce(MAX) over RCCL of the 5-word status block (4 residual
-maxima + unsolved count) that decides the global solve status.  scaling = weak (per-GPU batch
+One process per GPU; the batch shards with no data-path collective.  The path's only exchange is an
+all-reduce(MAX) over RCCL of the 5-word status block (4 residual maxima + unsolved count) that decides the
+global solve status: the fixed-iteration workload needs it once, after the last solve (SURVEY 8e);
+--status-every-step does it after every solve, overlapped with the next one.  scaling = weak (per-GPU batch
 fixed).  Rank 0 prints ONE JSON line.  Before the W warm-up steps the GPU clocks are ramped with 150 ms of untimed
 solves (set-up, like building the solver); the timed region is exactly K steps.
 """
@@ -43,6 +44,9 @@ def parse():
                     help="solve: BASELINE configs[1] (default).  mpc: warm-started closed loop (SURVEY 8f), extra")
     ap.add_argument("--mpc-steps", type=int, default=50)
     ap.add_argument("--mpc-max-iter", type=int, default=10)
+    ap.add_argument("--status-every-step", action="store_true",
+                    help="N > 1: all-reduce the status block after every solve (tolerance-terminated use); the default "
+                         "fixed-iteration workload needs no collective (SURVEY 8e) and folds the status once at the end")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -170,9 +174,26 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # TINYMPC_BENCH_FORCE_DIST=1: take the multi-rank code path (process group, status all-reduce) on one rank too —
+    # a rehearsal of the N > 1 run on a one-GPU box
+    dist_on = world > 1 or bool(os.environ.get("TINYMPC_BENCH_FORCE_DIST"))
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL on ROCm
+        os.environ.setdefault("MASTER_PORT", "29577")
+        # RCCL prints a version banner on stdout when its communicator comes up; stdout is reserved for the one JSON
+        # line, so the banner is sent to stderr
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)  # RCCL on ROCm
+            probe = torch.zeros(8, dtype=torch.int32, device=dev)
+            dist.all_reduce(probe, op=dist.ReduceOp.MAX)      # brings the communicator up
+            torch.cuda.synchronize(dev)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     import tinympc_julia_amd as t
     from tinympc_julia_amd import sharding
@@ -199,10 +220,10 @@ def main():
 
     def step():
         bs.solve_async(stream.cuda_stream)
-        if world > 1:
-            # the path's only exchange: global max residuals / unsolved count (16 + 4 bytes).  It is started on a
-            # snapshot of the status block and awaited at the fence, so it overlaps the next solve.
-            pending.append(sharding.allreduce_status_async(gstat))
+        if dist_on and args.status_every_step:
+            # global max residuals / unsolved count (16 + 4 bytes) after every solve: started on a snapshot of the
+            # status block and awaited at the fence, so it overlaps the next solve
+            pending.append(sharding.allreduce_status_async(gstat, force=True))
 
     def fence():
         for _, work in pending:
@@ -210,7 +231,7 @@ def main():
                 work.wait()
         del pending[:-1]          # the last one carries the global status of the last solve
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -230,12 +251,16 @@ def main():
     elapsed = time.perf_counter() - t0
     # per-launch kernel duration: HIP events the library records on the launch stream immediately around each kernel
     kernel_ms.append(bs.kernel_elapsed_ms(args.steps))  # mean over the timed launches, events immediately around the kernel
-    if world > 1:
+    if dist_on:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     status = bs.solve_status()
-    if world > 1 and pending:
+    if dist_on and not pending:
+        # the path's only exchange in the fixed-iteration workload: one fold of the last solve's status block
+        pending.append(sharding.allreduce_status_async(gstat, force=True))
+        fence()
+    if dist_on and pending:
         status = max(status, sharding.decode_status(pending[-1][0].cpu().numpy())[0])
     st = bs.get_status()
     assert int(st["iter"].min()) == args.iters and int(st["iter"].max()) == args.iters, "work skipped"
@@ -256,7 +281,7 @@ def main():
             "dtype": "f32" if args.precision == 1 else "f32 (f64 recurrences)", "data": "synthetic",
             "config": {"workload": label, "family": args.config, "batch_per_gpu": batch,
                        "admm_iters_per_solve": args.iters, "kernel": bs.kernel_name,
-                       "sharding": f"batch-sharded x{world}, status all-reduce only"},
+                       "sharding": f"batch-sharded x{world}, no data-path collective; status all-reduce " + ("every step" if args.status_every_step else "once")},
             "admm_iters_per_sec": value * args.iters,
             "solve_status": status,
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -280,7 +305,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(prob, x0, refs, args.iters, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     bs.close()
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

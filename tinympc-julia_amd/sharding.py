@@ -49,7 +49,7 @@ def allreduce_status(status, group=None):
     return status
 
 
-def allreduce_status_async(status, group=None):
+def allreduce_status_async(status, group=None, force=False):
     """Pipelined form for back-to-back solves: snapshots the status block (stream-ordered after the solve that
     produced it) and starts the all-reduce(MAX) of the snapshot without making the launch stream wait for it, so
     the exchange overlaps the next solve (which zeroes and rewrites the live block).  Returns (snapshot, work);
@@ -57,7 +57,7 @@ def allreduce_status_async(status, group=None):
     import torch.distributed as dist
     snap = status.clone()
     work = None
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (force or dist.get_world_size(group) > 1):
         work = dist.all_reduce(snap, op=dist.ReduceOp.MAX, group=group, async_op=True)
     return snap, work
 
