@@ -34,7 +34,7 @@ extern "C" {
 
 /* replaces bindings.cpp:21-73 setup_solver.  A non-zero fdyn (affine dynamics x+ = A x + B u + f)
  * is honoured, but its arithmetic lives only in the un-vendored TinyMPC submodule (SURVEY.md §0
- * fact 2): parity for it is UNPINNED, and such problems run on the generic kernel.
+ * fact 2): parity for it is UNPINNED, and such problems run on the stream (or generic) kernel.
  * Batch starts at 1; see set_batch_size. */
 int setup_solver(double *A_data, int A_rows, int A_cols, double *B_data, int B_rows, int B_cols,
                  double *fdyn_data, int fdyn_rows, int fdyn_cols, double *Q_data, int Q_rows,

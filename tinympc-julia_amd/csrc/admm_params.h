@@ -39,7 +39,7 @@ struct AdmmParams {
     // warm-start state, persists between solves: d,y,z [B][N-1][nu]; g,v [B][N][nx]
     float *sd, *sy, *sz, *sg, *sv;
     uint32_t *gstat;  // [GSTAT_WORDS]
-    // generic kernel only: per-instance scratch in HBM
+    // stream / generic kernels: per-instance scratch in HBM
     float *scratch;
     int batch;
     int max_iter;
@@ -48,14 +48,14 @@ struct AdmmParams {
     int cold_start;  // 1: start from the zero workspace, do not read sd..sv
     int save_state;  // 1: write sd..sv back at exit
     float abs_pri_tol, abs_dua_tol, rho;
-    int nx, nu, N;  // generic kernel only
+    int nx, nu, N;  // run-time shape (stream kernel: N; generic kernel: all three)
     // fused closed loop (0 = plain solve): steps per launch and per-step logs
     int mpc_steps;
     float *mpc_x;    // [B][steps][nx]  plant state after each step
     float *mpc_u;    // [B][steps][nu]  control applied at each step
     int *mpc_iter;   // [B][steps]      ADMM iterations of each step, negative if it hit max_iter
     float *x0_out;   // [B][nx]         plant state after the last step (aliases x0)
-    // ---- generic kernel only: affine dynamics + second-order cones (parity UNPINNED) ----
+    // ---- stream / generic kernels: affine dynamics + second-order cones (parity UNPINNED) ----
     int has_fdyn;            // coef pack carries fdyn, APf, BPf behind the matrices
     int ncx, ncu;            // number of state / input cones per knot (0: disabled), at most 8 each
     int Acx[8], qcx[8], Acu[8], qcu[8];  // first row and dimension of each cone block

@@ -60,7 +60,7 @@ struct Solver {
     // per-knot bounds, column-major fp64 (nx x N, nu x (N-1)); +-1e17 until set
     std::vector<double> x_min, x_max, u_min, u_max;
     // affine dynamics term and cone constraints (parity UNPINNED: they exist only in the absent
-    // TinyMPC submodule; run on the generic kernel)
+    // TinyMPC submodule; run on the stream kernel, or the generic one for shapes outside its grid)
     std::vector<double> fdyn;  // nx, all zero by default
     bool has_fdyn = false;
     int ncx = 0, ncu = 0;

@@ -456,7 +456,7 @@ class BatchSolver:
         self._chk(self.lib.tinympc_set_cache_terms(self.h, *[_dp(m) for m in ms]), "set_cache_terms")
 
     def set_fdyn(self, fdyn):
-        """affine dynamics term x+ = A x + B u + f (parity unpinned; generic kernel)"""
+        """affine dynamics term x+ = A x + B u + f (parity unpinned; stream / generic kernels)"""
         f = np.ascontiguousarray(np.asarray(fdyn, dtype=np.float64).reshape(-1))
         self._chk(self.lib.tinympc_set_fdyn(self.h, _dp(f)), "set_fdyn")
 
