@@ -38,7 +38,8 @@ struct AdmmParams {
     float *res;    // [B][4] pri_x, dua_x, pri_u, dua_u
     // warm-start state, persists between solves: d,y,z [B][N-1][nu]; g,v [B][N][nx]
     float *sd, *sy, *sz, *sg, *sv;
-    uint32_t *gstat;  // [GSTAT_WORDS]
+    uint32_t *gstat;  // [GSTAT_WORDS] status block of the launch: max residual bits [0..3], unsolved count [4]
+    uint32_t *gacc;   // [GSTAT_WORDS] accumulator behind it (fold_status); zero between launches
     // stream / generic kernels: per-instance scratch in HBM
     float *scratch;
     int batch;
@@ -68,5 +69,31 @@ struct AdmmParams {
     // ---- stream kernel only: one problem family PER INSTANCE ----
     const float *het_aux;                // [nx + nu + 1][batch]: diag(Q)+rho, diag(R)+rho, rho of each instance
 };
+
+#ifdef __HIPCC__
+// Folds one wavefront's residual maxima / unsolved count into the launch's status block without a host-side clear:
+// wavefronts accumulate in P.gacc; the last workgroup to finish (ticket in gacc[7]) publishes the totals to P.gstat
+// and hands the accumulator back zeroed to the next launch.  Every thread of the workgroup must call it.
+__device__ __forceinline__ void fold_status(const AdmmParams &P, float m0, float m1, float m2, float m3,
+                                            int unsolved_in_wave, int tid) {
+    if ((tid & 63) == 0) {
+        atomicMax(&P.gacc[0], __float_as_uint(m0));
+        atomicMax(&P.gacc[1], __float_as_uint(m1));
+        atomicMax(&P.gacc[2], __float_as_uint(m2));
+        atomicMax(&P.gacc[3], __float_as_uint(m3));
+        if (unsolved_in_wave) atomicAdd(&P.gacc[4], (uint32_t)unsolved_in_wave);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();  // this workgroup's contributions before its ticket
+        if (atomicAdd(&P.gacc[7], 1u) == gridDim.x - 1) {
+            __threadfence();
+#pragma unroll
+            for (int i = 0; i < 5; ++i) P.gstat[i] = atomicExch(&P.gacc[i], 0u);
+            atomicExch(&P.gacc[7], 0u);
+        }
+    }
+}
+#endif
 
 }  // namespace tmpc

@@ -854,14 +854,7 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
             m3 = fmaxf(m3, __shfl_xor(m3, off, 64));
         }
         const unsigned long long unsolved = __builtin_amdgcn_ballot_w64(active && !conv && q == 0);
-        if ((tid & 63) == 0) {
-            atomicMax(&P.gstat[0], __float_as_uint(m0));
-            atomicMax(&P.gstat[1], __float_as_uint(m1));
-            atomicMax(&P.gstat[2], __float_as_uint(m2));
-            atomicMax(&P.gstat[3], __float_as_uint(m3));
-            const int n = __popcll(unsolved);
-            if (n) atomicAdd(&P.gstat[4], (uint32_t)n);
-        }
+        fold_status(P, m0, m1, m2, m3, __popcll(unsolved), tid);
     }
 }
 

@@ -103,7 +103,7 @@ struct Solver {
     float *d_xout = nullptr, *d_uout = nullptr, *d_res = nullptr;
     int *d_iter = nullptr, *d_solved = nullptr;
     float *d_sd = nullptr, *d_sy = nullptr, *d_sz = nullptr, *d_sg = nullptr, *d_sv = nullptr;
-    uint32_t *d_gstat = nullptr;
+    uint32_t *d_gstat = nullptr;  // [2 * GSTAT_WORDS]: the public status block, then the kernels' accumulator
     uint32_t *h_gstat = nullptr;  // pinned
     float *d_scratch = nullptr;
     float *d_mpc_x = nullptr, *d_mpc_u = nullptr;  // fused closed-loop logs

@@ -152,7 +152,8 @@ int Solver::init(const double *A_, const double *B_, const double *Q_, const dou
     u_max.assign((size_t)eu(), 1e17);
     batch = batch_;
     if (select_kernel()) return -1;
-    if (dev_alloc(d_gstat, (size_t)GSTAT_WORDS)) return -1;
+    if (dev_alloc(d_gstat, (size_t)2 * GSTAT_WORDS)) return -1;
+    HIP_TRY(hipMemset(d_gstat, 0, 2 * GSTAT_WORDS * sizeof(uint32_t)));
     HIP_TRY(hipHostMalloc((void **)&h_gstat, GSTAT_WORDS * sizeof(uint32_t), hipHostMallocDefault));
     std::memset(h_gstat, 0, GSTAT_WORDS * sizeof(uint32_t));
     packs_dirty = true;
@@ -579,6 +580,7 @@ int Solver::solve_async(hipStream_t stream, int mpc_steps) {
     P.sg = d_sg;
     P.sv = d_sv;
     P.gstat = d_gstat;
+    P.gacc = d_gstat + GSTAT_WORDS;
     P.scratch = d_scratch;
     P.batch = batch;
     P.max_iter = st.max_iter;
@@ -620,7 +622,9 @@ int Solver::solve_async(hipStream_t stream, int mpc_steps) {
     P.svl = d_svl;
     P.syl = d_syl;
     P.szl = d_szl;
-    HIP_TRY(hipMemsetAsync(d_gstat, 0, GSTAT_WORDS * sizeof(uint32_t), stream));
+    // the quad and stream kernels keep the status block clean themselves (fold_status); the generic kernel
+    // accumulates straight into it
+    if (!ke && !se) HIP_TRY(hipMemsetAsync(d_gstat, 0, GSTAT_WORDS * sizeof(uint32_t), stream));
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (profiling) {
         if (ev_ring.empty()) {
