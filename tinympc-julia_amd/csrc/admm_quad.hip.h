@@ -44,6 +44,11 @@
 #define TMPC_COEF_LDS_THRESHOLD_G1 100000
 #endif
 
+// LDS state arrays: 0 = [element][thread] (one bank per lane and element), 1 = [knot][thread][rows of the knot]
+// (a lane's rows contiguous: one ds_read/write_b64/b128 per knot instead of one b32 per row)
+#ifndef TMPC_LDS_ROWS
+#define TMPC_LDS_ROWS 1
+#endif
 #ifndef TMPC_FENCE_LDS_MATVEC
 #define TMPC_FENCE_LDS_MATVEC 0
 #endif
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
     __shared__ float s_bnd[S::BOUNDS_LEN];
     __shared__ float s_ref[REFS == REF_SHARED ? S::REFS_LEN : 1];
     __shared__ RT s_coef[COEF_LDS ? G * S::CP : 1];
-    __shared__ float s_state[STATE_LEN];
+    __shared__ __align__(16) float s_state[STATE_LEN];
     static_assert(sizeof(float) * (S::BOUNDS_LEN + (REFS == REF_SHARED ? S::REFS_LEN : 1) + STATE_LEN) +
                           sizeof(RT) * (COEF_LDS ? G * S::CP : 1) <=
                       160 * 1024,
@@ -374,14 +379,17 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
     // the LDS state block, as the placement says.
 #define TMPC_STATE_ARRAY(name, ID, KN, RW_)                                                      \
     float name##_reg[PL.lds[S::ID] ? 1 : (KN)][PL.lds[S::ID] ? 1 : (RW_)];                      \
-    float *const name##_lds = s_state + PL.off[S::ID] * T + tid;                                \
+    float *const name##_lds = s_state + PL.off[S::ID] * T + (TMPC_LDS_ROWS ? tid * (RW_) : tid); \
     auto name##_get = [&](int k, int m) -> float {                                              \
-        if constexpr (PL.lds[S::ID]) return name##_lds[(k * (RW_) + m) * T];                    \
+        if constexpr (PL.lds[S::ID])                                                            \
+            return TMPC_LDS_ROWS ? name##_lds[k * T * (RW_) + m] : name##_lds[(k * (RW_) + m) * T]; \
         else return name##_reg[k][m];                                                           \
     };                                                                                          \
     auto name##_set = [&](int k, int m, float val) {                                            \
-        if constexpr (PL.lds[S::ID]) name##_lds[(k * (RW_) + m) * T] = val;                     \
-        else name##_reg[k][m] = val;                                                            \
+        if constexpr (PL.lds[S::ID]) {                                                          \
+            if (TMPC_LDS_ROWS) name##_lds[k * T * (RW_) + m] = val;                             \
+            else name##_lds[(k * (RW_) + m) * T] = val;                                         \
+        } else name##_reg[k][m] = val;                                                          \
     };
     TMPC_STATE_ARRAY(g, A_G, N, RX)        // state dual
     TMPC_STATE_ARRAY(v, A_V, N, RX)        // v (previous slack)
