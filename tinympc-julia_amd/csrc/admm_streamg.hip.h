@@ -1,18 +1,20 @@
 // Fused ADMM kernel with a run-time horizon, G = 1, 2 or 4 lanes per instance: "stream<G>".
 //
 // For shapes / options without an unrolled quad-kernel instantiation (admm_quad.hip.h): any horizon, the
-// affine dynamics term, second-order cones, one problem family per instance.  The knot loops are rolled and the
+// affine dynamics term, second-order cones, linear inequalities, one problem family per instance.  The knot loops are rolled and the
 // per-instance trajectories are streamed through a scratch block in HBM / Infinity Cache, D knots ahead of
 // their use; the lane mapping is the quad kernel's (lane q of a group owns state rows [q*RX,(q+1)*RX) and
 // input rows [q*RU,(q+1)*RU), mat-vec operands fetched with DPP quad_perm broadcasts).
 //   * G trades instruction efficiency against parallelism: one lane per instance executes the fewest
 //     instructions per instance but fills the chip only from ~65 536 instances up; four lanes put 4x the
-//     wavefronts in flight at ~2x the instructions.  The host picks G from the batch size.
+//     wavefronts in flight at ~2x the instructions.  G = 4 is what is instantiated (kernels.hip): measured, 1 and 2
+//     lanes are no faster at any batch size, because from ~32 768 instances up all three are bound by the state stream.
 //   * scratch layout [array][knot][instance][row] with the real nx / nu rows only: a lane's rows are one
 //     contiguous (vector) access, a wavefront's instances one contiguous span, no padding rows travel;
 //   * one-shot solves (cold start, workspace not kept: OS) update vnew / znew in place and hand the backward
 //     sweep one fused array (vnew - g [+ the cone set's]) instead of four: 10 instead of 14 state-shaped and
-//     12 instead of 16 input-shaped float transfers per knot and iteration;
+//     12 instead of 16 input-shaped float transfers per knot and iteration (6 and 8 when no residual check
+//     reads vnew / znew back);
 //   * one family for the batch: coefficient rows per lane role in LDS (conflict-free image, as in the
 //     quad kernel); one family per instance (HET): the same rows as per-lane columns in HBM;
 //   * second-order cones may straddle lanes: squared head norms and the axis value are summed over
@@ -171,7 +173,8 @@ __device__ __forceinline__ void project_halfspaces_group(float (&z)[R], const fl
     }
 }
 
-// wavefronts per SIMD the register allocation is held to, and knots of prefetch, per group size
+// wavefronts per SIMD the register allocation is held to, and knots of prefetch, per group size (MI355X, rocket
+// N=50 with cones: 2..4 wavefronts and depth 1..3 are within 5 % of each other for G = 4; scripts/stream_tune.sh)
 template <int G>
 struct StreamTune {
     static constexpr int WAVES = G == 4 ? 3 : (G == 2 ? 2 : 1);
