@@ -913,7 +913,7 @@ def test_config5_shard_tolerance_terminated(hip_lib, oracle_built):
 def test_kernel_selection_by_batch(hip_lib):
     """Lanes per instance follow the batch size; shapes outside the unrolled table use the stream kernel."""
     prob = t.problems.cartpole(20, u_bound=0.5)
-    for batch, tag in ((100, "g4>"), (30000, "g2>"), (65536, "g1>")):
+    for batch, tag in ((100, "g4>"), (16384, "g4>"), (30000, "g1>"), (65536, "g1>")):
         bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=batch)
         assert bs.kernel_name.startswith("quad<4,1,20") and bs.kernel_name.endswith(tag), bs.kernel_name
         bs.close()

@@ -29,12 +29,14 @@ const KernelEntry *find_quad_kernel(int nx, int nu, int N, int group) {
     return nullptr;
 }
 
-// Lanes per instance for a batch size: fewer lanes per instance means fewer cross-lane moves and no
-// redundant work, but also fewer wavefronts, so it only pays once the batch fills the 1024 SIMDs
-// (measured on cartpole N=20, batch 65 536, MI355X: 1 lane 0.44 ms, 2 lanes 0.55 ms, 4 lanes 0.79 ms).
+// Lanes per instance for a batch size.  Fewer lanes per instance means fewer cross-lane moves and no redundant
+// work, but also fewer wavefronts.  A launch with at most one wavefront per SIMD takes about the same time
+// whatever the batch (the instances' serial chains run side by side), so one lane per instance wins as soon as four
+// lanes would need more than 1 024 wavefronts.  Measured on cartpole N=20, MI355X (scripts/group_sweep.sh), kernel ms
+// for 1 / 2 / 4 lanes: batch 16 384: 0.326 / 0.331 / 0.272; 24 576: 0.331 / 0.348 / 0.383; 65 536: 0.370 / 0.512 / 0.748.
 const KernelEntry *select_quad_kernel(int nx, int nu, int N, int batch) {
-    const int pref[3][3] = {{1, 2, 4}, {2, 4, 1}, {4, 2, 1}};
-    const int *order = batch >= 49152 ? pref[0] : (batch >= 24576 ? pref[1] : pref[2]);
+    const int pref[2][3] = {{1, 2, 4}, {4, 2, 1}};
+    const int *order = batch >= 20480 ? pref[0] : pref[1];
     for (int i = 0; i < 3; ++i)
         if (const KernelEntry *e = find_quad_kernel(nx, nu, N, order[i])) return e;
     return nullptr;
