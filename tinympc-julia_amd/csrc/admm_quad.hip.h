@@ -125,36 +125,38 @@ struct QuadShape {
         int off[A_COUNT];  // float offset of the array inside the LDS state block, per thread-stride
         int lds_floats;    // floats per lane in LDS
     };
-    static constexpr int arr_size(int a, bool oneshot) {
+    static constexpr int arr_size(int a, bool oneshot, bool nog = false) {
         if (oneshot && (a == A_W || a == A_ZW)) return 0;  // vnew / znew overwrite v / z in place
+        if (nog && a == A_G) return 0;                     // the state dual is identically zero
         return (a == A_V || a == A_W || a == A_G) ? RX * N : RU * (N - 1);
     }
-    template <class RT, int REFS, bool OS>
+    template <class RT, int REFS, bool OS, bool NOG = false>
     static constexpr Placement place() {
         Placement p{};
         const int fixed = ((coef_in_lds<RT, REFS>() || G == 1) ? 0 : coef_regs<RT, REFS>()) +  // G = 1: SGPRs
                          
                           (G == 1 ? 150 : (sizeof(RT) == 8 ? 60 : 45)) +  // working registers of a knot
                           (REFS == REF_PER_INSTANCE ? RX * N + RU * (N - 1) : 0);
-        const int total = (OS ? 2 : 3) * RX * N + (OS ? 3 : 4) * RU * (N - 1);
+        const int total = (OS ? 2 : 3) * RX * N + (OS ? 3 : 4) * RU * (N - 1) - (NOG ? RX * N : 0);
         // (register budget, LDS floats per lane) for 2 waves/SIMD, then 1 wave/SIMD
         const int budget[2] = {250 - fixed, (sizeof(RT) == 8 ? BUD64_ : BUD32_) - fixed};
         const int cap[2] = {78, 150};
-        for (int pass = 0; pass < 2; ++pass) {
+        // one lane per instance is picked for batches of about one wavefront per SIMD: only the second target applies
+        for (int pass = (G == 1 ? 1 : 0); pass < 2; ++pass) {
             int regs = total, lds = 0;
             bool sel[A_COUNT] = {};
             for (int a = 0; a < A_COUNT && regs > budget[pass]; ++a) {
-                if (arr_size(a, OS) == 0 || lds + arr_size(a, OS) > cap[pass]) continue;
+                if (arr_size(a, OS, NOG) == 0 || lds + arr_size(a, OS, NOG) > cap[pass]) continue;
                 sel[a] = true;
-                regs -= arr_size(a, OS);
-                lds += arr_size(a, OS);
+                regs -= arr_size(a, OS, NOG);
+                lds += arr_size(a, OS, NOG);
             }
             if (regs <= budget[pass] || pass == 1) {
                 int o = 0;
                 for (int a = 0; a < A_COUNT; ++a) {
                     p.lds[a] = sel[a];
                     p.off[a] = o;
-                    if (sel[a]) o += arr_size(a, OS);
+                    if (sel[a]) o += arr_size(a, OS, NOG);
                 }
                 p.lds_floats = lds;
                 return p;
@@ -307,7 +309,11 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
     constexpr int NXL = S::NXL, NUL = S::NUL;
     constexpr int EX = NX * N, EU = NU * (N - 1);
     constexpr bool COEF_LDS = S::template coef_in_lds<RT, REFS>();
-    constexpr auto PL = S::template place<RT, REFS, OS>();
+    // One-shot solve without an active state bound: vnew = x + g is never clamped, so g += x - vnew leaves the
+    // state dual at its cold-start value, zero, for the whole solve — it is neither stored nor computed (the
+    // results are bit-identical: x + 0 and (0 + x) - x are exact).
+    constexpr bool NOG = OS && !XB;
+    constexpr auto PL = S::template place<RT, REFS, OS, NOG>();
     constexpr int STATE_LEN = PL.lds_floats > 0 ? PL.lds_floats * S::THREADS : 1;
     constexpr int T = S::THREADS;
     constexpr bool UREP = S::UREP;
@@ -393,7 +399,14 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
             else name##_lds[(k * (RW_) + m) * T] = val;                                         \
         } else name##_reg[k][m] = val;                                                          \
     };
-    TMPC_STATE_ARRAY(g, A_G, N, RX)        // state dual
+    TMPC_STATE_ARRAY(gx, A_G, NOG ? 1 : N, RX)   // state dual (no storage when NOG)
+    auto g_get = [&](int k, int m) -> float {
+        if constexpr (NOG) return 0.f;
+        else return gx_get(k, m);
+    };
+    auto g_set = [&](int k, int m, float val) {
+        if constexpr (!NOG) gx_set(k, m, val);
+    };
     TMPC_STATE_ARRAY(v, A_V, N, RX)        // v (previous slack)
     TMPC_STATE_ARRAY(y, A_Y, N - 1, RU)    // input dual
     TMPC_STATE_ARRAY(z, A_Z, N - 1, RU)    // z (previous slack)
