@@ -57,6 +57,7 @@ struct AdmmParams {
     int *mpc_iter;   // [B][steps]      ADMM iterations of each step, negative if it hit max_iter
     float *x0_out;   // [B][nx]         plant state after the last step (aliases x0)
     // ---- stream / generic kernels: affine dynamics + second-order cones (parity UNPINNED) ----
+    int xb_active;           // some enabled state bound is finite (else vnew = x + g is never clamped)
     int has_fdyn;            // coef pack carries fdyn, APf, BPf behind the matrices
     int ncx, ncu;            // number of state / input cones per knot (0: disabled), at most 8 each
     int Acx[8], qcx[8], Acu[8], qcu[8];  // first row and dimension of each cone block

@@ -364,6 +364,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
     auto mkx = [&](float v, int m) __attribute__((always_inline)) { return OKX(m) ? v : 0.f; };
     auto mku = [&](float v, int m) __attribute__((always_inline)) { return OKU(m) ? v : 0.f; };
     const bool x_owner = ALLX || !XFULL || xl, u_owner = ALLU || !UFULL || ul;
+    // One-shot solve without a finite state bound: vnew = x + g is never clamped, so the state dual stays at its
+    // cold-start value, zero — it is neither streamed nor computed (bit-identical results).  Plain kernels only: with
+    // the extensions compiled in, the extra run-time case costs config 4 (which has finite state bounds) 3 %.
+    const bool nog = EXT == 0 && OS && !P.xb_active;
 
     RT x0[RX];
 #pragma unroll
@@ -470,7 +474,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
             }
             auto fetch_x = [&](int k_, FwdBuf &f) __attribute__((always_inline)) {
                 const int k = knot_sgpr(k_);
-                ldx(Sg, k, f.g);
+                if (!nog) ldx(Sg, k, f.g);
                 if (need_res) ldx(Svold, k, f.v);
                 if (soc_x) {
                     ldx(Sgc, k, f.gc);
@@ -503,7 +507,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
                 float xf[RX], vn[RX], gn[RX], wc[RX], gcn[RX], wl[RX], gln[RX], sx[RX];
 #pragma unroll
                 for (int m = 0; m < RX; ++m) {
-                    const float g_c = mkx(f.g[m], m), v_c = mkx(f.v[m], m);
+                    const float g_c = nog ? 0.f : mkx(f.g[m], m), v_c = mkx(f.v[m], m);
                     xf[m] = (float)x[m];
                     vn[m] = fminf(bk[RX + m], fmaxf(bk[m], xf[m] + g_c));
                     gn[m] = (g_c + xf[m]) - vn[m];
@@ -543,7 +547,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
                     }
                 }
                 if (x_owner) {
-                    stx(Sg, k, gn);
+                    if (!nog) stx(Sg, k, gn);
                     if (keep_w) stx(Sw, k, vn);
                     if constexpr (OS) stx(Ss, k, sx);
                     if constexpr (EXT)

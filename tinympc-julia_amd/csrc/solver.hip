@@ -599,6 +599,7 @@ int Solver::solve_async(hipStream_t stream, int mpc_steps) {
     P.mpc_u = d_mpc_u;
     P.mpc_iter = d_mpc_iter;
     P.x0_out = d_x0;
+    P.xb_active = state_bounds_active ? 1 : 0;
     P.has_fdyn = has_fdyn ? 1 : 0;
     P.ncx = st.en_state_soc ? ncx : 0;
     P.ncu = st.en_input_soc ? ncu : 0;
