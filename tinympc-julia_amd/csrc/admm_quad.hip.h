@@ -265,7 +265,8 @@ __device__ __forceinline__ double tfma(double a, double b, double c) { return fm
 // acc[m] += sum_{s < SL} sum_{k < SK} C[m*CW + s*SK + k] * (src[k] of quad lane s)
 // Dot products longer than 6 terms are accumulated in two independent chains (source lanes 0,1 and
 // 2,3) that are added at the end: the dependent-FMA chain is what a lone wavefront waits on.
-template <int G, int ROWS, int SL, int SK, int CW, class RT, class CP>
+// acc += C src (NEG: acc -= C src, the sign folded into the FMAs)
+template <int G, int ROWS, int SL, int SK, int CW, bool NEG = false, class RT, class CP>
 __device__ __forceinline__ void quad_matvec(RT (&acc)[ROWS], const CP C, const RT (&src)[SK]) {
     constexpr bool SPLIT = (SL * SK > 6) && SL >= 3;
     RT acc2[ROWS];
@@ -278,10 +279,11 @@ __device__ __forceinline__ void quad_matvec(RT (&acc)[ROWS], const CP C, const R
             const RT xv = gbcast<G, S>(src[k]);
 #pragma unroll
             for (int m = 0; m < ROWS; ++m) {
+                const RT c = NEG ? -(RT)C[m * CW + S * SK + k] : (RT)C[m * CW + S * SK + k];
                 if constexpr (SPLIT && S >= 2)
-                    acc2[m] = tfma((RT)C[m * CW + S * SK + k], xv, acc2[m]);
+                    acc2[m] = tfma(c, xv, acc2[m]);
                 else
-                    acc[m] = tfma((RT)C[m * CW + S * SK + k], xv, acc[m]);
+                    acc[m] = tfma(c, xv, acc[m]);
             }
         }
         if constexpr (!std::is_pointer<CP>::value && TMPC_FENCE_LDS_MATVEC == 2) __builtin_amdgcn_sched_barrier(0);
@@ -319,6 +321,10 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
     constexpr bool UREP = S::UREP;
     // two copies of the forward sweep (with / without the residual maxima) only where the code stays small
     constexpr bool DUAL_FWD = (RX + RU) * N <= 64;
+    // -d and -Kinf^T r folded into the accumulators' starting values and FMA signs: fewer instructions where the
+    // state is in registers (one lane per instance: cartpole 0.358 -> 0.352 ms); with LDS-resident state the earlier
+    // operand loads cost more than they save (quadrotor 11.7 -> 12.0 ms), so quads keep the separate form
+    constexpr bool FOLD = G == 1;
 
     __shared__ float s_bnd[S::BOUNDS_LEN];
     __shared__ float s_ref[REFS == REF_SHARED ? S::REFS_LEN : 1];
@@ -572,14 +578,14 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
             if (k < N - 1) {
                 RT u[RU], xn[RX];
 #pragma unroll
-                for (int m = 0; m < RU; ++m) u[m] = (RT)0;
+                for (int m = 0; m < RU; ++m) u[m] = FOLD ? -(RT)d_get(k, m) : (RT)0;
 #pragma unroll
                 for (int m = 0; m < RX; ++m) xn[m] = (RT)0;
-                quad_matvec<G, RU, NXL, RX, NXP>(u, cK, x);                        // Kinf x
+                quad_matvec<G, RU, NXL, RX, NXP, FOLD>(u, cK, x);                  // Kinf x  (FOLD: u = -d - Kinf x)
                 quad_matvec<G, RX, NXL, RX, NXP>(xn, cA, x);                       // A x
 #pragma unroll
                 for (int m = 0; m < RU; ++m) {
-                    u[m] = -u[m] - (RT)d_get(k, m);                             // u = -Kinf x - d
+                    if constexpr (!FOLD) u[m] = -u[m] - (RT)d_get(k, m);        // u = -Kinf x - d
                     const float uf = (float)u[m];
                     const float yk = y_get(k, m);
                     float zn = uf + yk;                                         // znew = u + y
@@ -672,20 +678,36 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
                 }
 #pragma unroll
                 for (int m = 0; m < RU; ++m) d_set(k, m, (float)dn[m]);
-                RT ap[RX], kr[RX];
+                // p_k = q_k + AmBKt p_{k+1} - Kinf^T r_k (admm.cpp:18)
+                RT ap[RX];
+                if constexpr (FOLD) {  // the part that does not wait for p_{k+1} first, its sign folded into the FMAs
+                    if constexpr (UREP) {
 #pragma unroll
-                for (int m = 0; m < RX; ++m) ap[m] = qk[m];
-                quad_matvec<G, RX, NXL, RX, NXP>(ap, cAT, p);                  // q_k + AmBKt p_{k+1}
-                if constexpr (UREP) {
+                        for (int m = 0; m < RX; ++m) ap[m] = tfma(-(RT)cKT[m * NUP], r[0], qk[m]);
+                    } else {
 #pragma unroll
-                    for (int m = 0; m < RX; ++m) kr[m] = (RT)cKT[m * NUP] * r[0];  // Kinf^T r_k
+                        for (int m = 0; m < RX; ++m) ap[m] = qk[m];
+                        quad_matvec<G, RX, NUL, RU, NUP, true>(ap, cKT, r);
+                    }
+                    quad_matvec<G, RX, NXL, RX, NXP>(ap, cAT, p);
+#pragma unroll
+                    for (int m = 0; m < RX; ++m) p[m] = ap[m];
                 } else {
+                    RT kr[RX];
 #pragma unroll
-                    for (int m = 0; m < RX; ++m) kr[m] = (RT)0;
-                    quad_matvec<G, RX, NUL, RU, NUP>(kr, cKT, r);
+                    for (int m = 0; m < RX; ++m) ap[m] = qk[m];
+                    quad_matvec<G, RX, NXL, RX, NXP>(ap, cAT, p);              // q_k + AmBKt p_{k+1}
+                    if constexpr (UREP) {
+#pragma unroll
+                        for (int m = 0; m < RX; ++m) kr[m] = (RT)cKT[m * NUP] * r[0];  // Kinf^T r_k
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < RX; ++m) kr[m] = (RT)0;
+                        quad_matvec<G, RX, NUL, RU, NUP>(kr, cKT, r);
+                    }
+#pragma unroll
+                    for (int m = 0; m < RX; ++m) p[m] = ap[m] - kr[m];
                 }
-#pragma unroll
-                for (int m = 0; m < RX; ++m) p[m] = ap[m] - kr[m];          // admm.cpp:18
             });
     };
     auto backward_sweep = [&]() {

@@ -566,18 +566,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
                     RT u[RU], xn[RX];
                     float uf[RU], zn[RU], yn[RU], zc2[RU], ycn[RU], zl2[RU], yln[RU], su[RU];
 #pragma unroll
-                    for (int m = 0; m < RU; ++m) u[m] = (RT)0;
+                    for (int m = 0; m < RU; ++m) u[m] = -(RT)mku(f.d[m], m);
 #pragma unroll
                     for (int m = 0; m < RX; ++m) xn[m] = EXT ? (RT)cF[m] : (RT)0;
                     asm volatile("" ::: "memory");  // (and between products: each one's coefficient loads stay next to their use)
-                    quad_matvec<G, RU, NXL, RX, NXP>(u, cK, x);    // Kinf x
+                    quad_matvec<G, RU, NXL, RX, NXP, true>(u, cK, x);    // u = -d - Kinf x
                     asm volatile("" ::: "memory");
                     quad_matvec<G, RX, NXL, RX, NXP>(xn, cA, x);   // A x (+ fdyn)
                     asm volatile("" ::: "memory");
 #pragma unroll
                     for (int m = 0; m < RU; ++m) {
                         const float y_c = mku(f.y[m], m);
-                        u[m] = -u[m] - (RT)mku(f.d[m], m);
                         uf[m] = (float)u[m];
                         zn[m] = fminf(bk[2 * RX + RU + m], fmaxf(bk[2 * RX + m], uf[m] + y_c));
                         yn[m] = (y_c + uf[m]) - zn[m];
@@ -776,7 +775,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
                         fetchb_x(k - D, f);
                         fetchb_u(k - D, f);
                     }
-                    RT tt[RU], dn[RU], ap[RX], kr[RX];
+                    RT tt[RU], dn[RU], ap[RX];
                     float dnf[RU];
 #pragma unroll
                     for (int m = 0; m < RU; ++m) {
@@ -791,16 +790,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
                     for (int m = 0; m < RU; ++m) dnf[m] = (float)dn[m];
                     if (u_owner) stu(Sd, k, dnf);
 #pragma unroll
-                    for (int m = 0; m < RX; ++m) {
-                        ap[m] = qk[m] + (EXT ? (RT)cAPF[m] : (RT)0);
-                        kr[m] = (RT)0;
-                    }
+                    for (int m = 0; m < RX; ++m) ap[m] = qk[m] + (EXT ? (RT)cAPF[m] : (RT)0);
                     asm volatile("" ::: "memory");
-                    quad_matvec<G, RX, NXL, RX, NXP>(ap, cAT, p);   // q + AmBKt p (+ APf)
+                    quad_matvec<G, RX, NUL, RU, NUP, true>(ap, cKT, r);   // q (+ APf) - Kinf^T r: does not wait for p
                     asm volatile("" ::: "memory");
-                    quad_matvec<G, RX, NUL, RU, NUP>(kr, cKT, r);   // Kinf^T r
+                    quad_matvec<G, RX, NXL, RX, NXP>(ap, cAT, p);         // + AmBKt p
 #pragma unroll
-                    for (int m = 0; m < RX; ++m) p[m] = ap[m] - kr[m];
+                    for (int m = 0; m < RX; ++m) p[m] = ap[m];
                 };
                 for (int t0 = 0; t0 < N - 1; t0 += D)
                     sfor<0, D>([&](auto J) {
