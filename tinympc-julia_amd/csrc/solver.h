@@ -105,6 +105,13 @@ struct Solver {
     float *d_sd = nullptr, *d_sy = nullptr, *d_sz = nullptr, *d_sg = nullptr, *d_sv = nullptr;
     uint32_t *d_gstat = nullptr;  // [2 * GSTAT_WORDS]: the public status block, then the kernels' accumulator
     uint32_t *h_gstat = nullptr;  // pinned
+    // host round trips (fp64 caller buffers <-> fp32 device buffers): pinned staging, copy stream, two chunk slots
+    float *h_stage = nullptr;
+    size_t stage_cap = 0;  // floats
+    hipStream_t s_copy = nullptr;
+    hipEvent_t ev_copy[2] = {nullptr, nullptr};
+    int d2h_double(const float *d, double *out, size_t n);
+    int h2d_float(float *d, const double *in, size_t n);
     float *d_scratch = nullptr;
     float *d_mpc_x = nullptr, *d_mpc_u = nullptr;  // fused closed-loop logs
     int *d_mpc_iter = nullptr;

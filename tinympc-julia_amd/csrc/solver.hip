@@ -5,6 +5,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <cstring>
 #include <thread>
 
@@ -29,6 +32,71 @@ bool hip_ok(hipError_t e, const char *what) {
 
 // fp32 <-> fp64 conversion of the host-side staging buffers, spread over a few threads: at batch 65 536
 // a solution is 6.5 M elements and a single-threaded loop costs more than the kernel that produced it.
+// The workers are started once and parked on a condition variable: spawning 16 threads per call costs ~0.5 ms,
+// more than the copy they help with.
+class HostPool {
+public:
+    static HostPool &get() {
+        static HostPool pool;
+        return pool;
+    }
+    // runs f(lo, hi) over [0, n) in `parts` contiguous ranges, part 0 on the calling thread
+    void run(size_t n, size_t parts, const std::function<void(size_t, size_t)> &f) {
+        std::unique_lock<std::mutex> outer(call_);  // one parallel region at a time
+        parts = std::min(parts, workers_.size() + 1);
+        const size_t chunk = (n + parts - 1) / parts;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            fn_ = &f;
+            n_ = n;
+            chunk_ = chunk;
+            next_ = 1;
+            parts_ = parts;
+            pending_ = parts - 1;
+        }
+        cv_.notify_all();
+        f(0, std::min(n, chunk));
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [&] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    HostPool() {
+        const unsigned hw = std::thread::hardware_concurrency();
+        const unsigned nt = std::min<unsigned>(hw ? hw : 1, 16);
+        for (unsigned i = 1; i < nt; ++i) workers_.emplace_back([this] { loop(); });
+    }
+    ~HostPool() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+    void loop() {
+        for (;;) {
+            std::unique_lock<std::mutex> lk(m_);
+            cv_.wait(lk, [&] { return stop_ || next_ < parts_; });  // parked until a region has an unclaimed part
+            if (stop_) return;
+            const size_t part = next_++;
+            const auto *f = fn_;
+            const size_t lo = part * chunk_, hi = std::min(n_, lo + chunk_);
+            lk.unlock();
+            if (lo < hi) (*f)(lo, hi);
+            lk.lock();
+            if (--pending_ == 0) done_.notify_one();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_, call_;
+    std::condition_variable cv_, done_;
+    const std::function<void(size_t, size_t)> *fn_ = nullptr;
+    size_t n_ = 0, chunk_ = 0, next_ = 0, parts_ = 0, pending_ = 0;
+    bool stop_ = false;
+};
+
 template <class F>
 static void parallel_chunks(size_t n, F &&f, size_t min_parallel = (size_t)1 << 16) {
     const unsigned hw = std::thread::hardware_concurrency();
@@ -37,14 +105,7 @@ static void parallel_chunks(size_t n, F &&f, size_t min_parallel = (size_t)1 << 
         f((size_t)0, n);
         return;
     }
-    std::vector<std::thread> th;
-    const size_t chunk = (n + nt - 1) / nt;
-    for (size_t t = 1; t < nt; ++t) {
-        const size_t lo = t * chunk, hi = std::min(n, lo + chunk);
-        if (lo < hi) th.emplace_back([=, &f] { f(lo, hi); });
-    }
-    f((size_t)0, std::min(n, chunk));
-    for (auto &x : th) x.join();
+    HostPool::get().run(n, nt, std::function<void(size_t, size_t)>(f));
 }
 static void widen(const float *src, double *dst, size_t n) {
     parallel_chunks(n, [=](size_t lo, size_t hi) {
@@ -82,6 +143,10 @@ Solver::~Solver() {
     h_gstat = nullptr;
     for (hipEvent_t e : ev_ring)
         if (e) (void)hipEventDestroy(e);
+    if (h_stage) (void)hipHostFree(h_stage);
+    for (hipEvent_t e : ev_copy)
+        if (e) (void)hipEventDestroy(e);
+    if (s_copy) (void)hipStreamDestroy(s_copy);
 }
 
 void Solver::free_batch() {
@@ -698,11 +763,7 @@ double Solver::kernel_elapsed_mean_ms(int last_n) {
 
 int Solver::get_traj(bool states, double *buf) {
     HIP_TRY(hipSetDevice(device));
-    const size_t n = (size_t)batch * (states ? ex() : eu());
-    std::vector<float> h(n);
-    HIP_TRY(hipMemcpy(h.data(), states ? d_xout : d_uout, n * sizeof(float), hipMemcpyDeviceToHost));
-    widen(h.data(), buf, n);
-    return 0;
+    return d2h_double(states ? d_xout : d_uout, buf, (size_t)batch * (states ? ex() : eu()));
 }
 
 int Solver::get_status(int *iter, int *solved, double *res4) {
@@ -718,14 +779,38 @@ int Solver::get_status(int *iter, int *solved, double *res4) {
     return 0;
 }
 
-static int d2h_double(const float *d, double *out, size_t n) {
-    if (!out) return 0;
-    std::vector<float> h(n);
-    HIP_TRY(hipMemcpy(h.data(), d, n * sizeof(float), hipMemcpyDeviceToHost));
-    widen(h.data(), out, n);
+// fp32 device buffer -> fp64 caller buffer.  Chunks travel into pinned staging on a copy stream while the previous
+// chunk is widened by the host threads, so the round trip costs about max(PCIe, widening) instead of their sum plus
+// a pageable-memory bounce.
+int Solver::d2h_double(const float *d, double *out, size_t n) {
+    if (!out || n == 0) return 0;
+    constexpr size_t CHUNK = (size_t)1 << 21;  // floats per slot (8 MB)
+    if (!s_copy) {
+        HIP_TRY(hipStreamCreate(&s_copy));  // a blocking stream: ordered after work on the default stream, like hipMemcpy
+        for (hipEvent_t &e : ev_copy) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    if (stage_cap < 2 * CHUNK) {
+        if (h_stage) (void)hipHostFree(h_stage);
+        h_stage = nullptr;
+        HIP_TRY(hipHostMalloc((void **)&h_stage, 2 * CHUNK * sizeof(float), hipHostMallocDefault));
+        stage_cap = 2 * CHUNK;
+    }
+    const size_t nchunks = (n + CHUNK - 1) / CHUNK;
+    for (size_t c = 0; c <= nchunks; ++c) {
+        if (c < nchunks) {
+            const size_t off = c * CHUNK, len = std::min(CHUNK, n - off);
+            HIP_TRY(hipMemcpyAsync(h_stage + (c & 1) * CHUNK, d + off, len * sizeof(float), hipMemcpyDeviceToHost, s_copy));
+            HIP_TRY(hipEventRecord(ev_copy[c & 1], s_copy));
+        }
+        if (c > 0) {
+            const size_t pc = c - 1, off = pc * CHUNK, len = std::min(CHUNK, n - off);
+            HIP_TRY(hipEventSynchronize(ev_copy[pc & 1]));
+            widen(h_stage + (pc & 1) * CHUNK, out + off, len);
+        }
+    }
     return 0;
 }
-static int h2d_float(float *d, const double *in, size_t n) {
+int Solver::h2d_float(float *d, const double *in, size_t n) {
     if (!in) return 0;
     std::vector<float> h(n);
     narrow(in, h.data(), n);
