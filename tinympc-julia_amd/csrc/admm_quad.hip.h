@@ -61,7 +61,8 @@ namespace tmpc {
 // BUD64 / BUD32: register budget per lane (fp64 / fp32 recurrences) the placement aims at when only one
 // wavefront per SIMD fits; tuned per shape on MI355X ("Where state lives").
 // LOOPV: which cheaper loop variants are built and used for one-shot solves of this shape (bit 0: vnew/znew
-// in place, bit 1: additionally no per-lane guard when nobody can converge); measured per shape.
+// in place, bit 1: additionally no per-lane guard when nobody can converge, bit 2: folded signs in the fp64
+// recurrences, see FOLD); measured per shape.
 template <int NX_, int NU_, int N_, int G_ = 4, int BUD64_ = 380, int BUD32_ = 380, int LOOPV_ = 0>
 struct QuadShape {
     static constexpr int LOOPV = LOOPV_;
@@ -323,8 +324,9 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
     constexpr bool DUAL_FWD = (RX + RU) * N <= 64;
     // -d and -Kinf^T r folded into the accumulators' starting values and FMA signs: fewer instructions where the
     // state is in registers (one lane per instance: cartpole 0.358 -> 0.352 ms); with LDS-resident state the earlier
-    // operand loads cost more than they save (quadrotor 11.7 -> 12.0 ms), so quads keep the separate form
-    constexpr bool FOLD = G == 1;
+    // operand loads cost more than they save (quadrotor 11.7 -> 12.0 ms), so quads keep the separate form unless the
+    // shape asks for it (QuadShape::LOOPV bit 2: rocket N=50 with fp64 recurrences 5.88 -> 5.54 ms)
+    constexpr bool FOLD = G == 1 || ((S::LOOPV & 4) != 0 && sizeof(RT) == 8);
 
     __shared__ float s_bnd[S::BOUNDS_LEN];
     __shared__ float s_ref[REFS == REF_SHARED ? S::REFS_LEN : 1];

@@ -1,5 +1,5 @@
 // part 0 of inst_6_3_50_g4: the (double, state bounds true) kernels
 #include "quad_entry.hip.h"
 namespace tmpc {
-TMPC_QUAD_PART(double, true, 6, 3, 50, 4, 470, 470, 3)
+TMPC_QUAD_PART(double, true, 6, 3, 50, 4, 470, 470, 7)
 }

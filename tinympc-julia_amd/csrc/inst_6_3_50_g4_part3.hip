@@ -1,5 +1,5 @@
 // part 3 of inst_6_3_50_g4: the (float, state bounds false) kernels
 #include "quad_entry.hip.h"
 namespace tmpc {
-TMPC_QUAD_PART(float, false, 6, 3, 50, 4, 470, 470, 3)
+TMPC_QUAD_PART(float, false, 6, 3, 50, 4, 470, 470, 7)
 }
