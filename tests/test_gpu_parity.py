@@ -333,6 +333,71 @@ def test_fallback_kernels_vs_oracle(hip_lib, oracle_built, monkeypatch, shape, k
     bs.close()
 
 
+def _random_problem(rng, nx, nu, N, bounded):
+    """a random controllable-ish family with per-knot bounds that bind for some instances"""
+    A = np.eye(nx) + 0.15 * rng.standard_normal((nx, nx)) / np.sqrt(nx)
+    A *= 0.97 / np.abs(np.linalg.eigvals(A)).max()       # stable: an unstable 12-state / 1-input draw loses 2 digits even in the fp32 CPU loop
+    Bm = rng.standard_normal((nx, nu)) * 0.5
+    prob = t.problems.Problem("rand", A, Bm, np.diag(rng.uniform(0.5, 5.0, nx)), np.diag(rng.uniform(0.5, 3.0, nu)),
+                              float(rng.uniform(0.5, 4.0)), N)
+    if bounded:
+        prob.x_min = -rng.uniform(0.8, 2.0, (nx, 1)) * np.ones((1, N))
+        prob.x_max = rng.uniform(0.8, 2.0, (nx, 1)) * np.ones((1, N))
+        prob.x_min[:, N // 2:] -= 0.3                    # per-knot, not constant
+    else:
+        prob.x_min, prob.x_max = np.full((nx, N), -1e17), np.full((nx, N), 1e17)
+    prob.u_min = -rng.uniform(0.2, 0.6, (nu, 1)) * np.ones((1, N - 1))
+    prob.u_max = rng.uniform(0.2, 0.6, (nu, 1)) * np.ones((1, N - 1))
+    return prob
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_stream_kernel_random_sweep(hip_lib, oracle_built, seed):
+    """Every (nx, nu) of the run-time-horizon kernel's grid (25 shapes over the 6 seeds), random horizon, batch,
+    family, bounds (finite state bounds or none), reference mode and check interval, against the oracle; then a
+    same problem as a one-shot solve (the in-place loop).  Tolerance 5e-5 norm-relative, written here: random
+    families are worse conditioned than the reference's examples, whose bar stays 1e-5; the sweep is there to catch
+    indexing / masking errors, which show up at 1e-2 and above."""
+    SWEEP_TOL = 5e-5
+    rng = np.random.default_rng(1000 + seed)
+    grid = [(nx, nu) for nx in (2, 3, 4, 6, 8, 10, 12) for nu in (1, 2, 3, 4) if nu <= nx]
+    for nx, nu in grid[seed::6]:
+        N = int(rng.integers(2, 36))
+        if (nx, nu, N) in ((4, 1, 2), (4, 1, 10), (4, 1, 20), (12, 4, 20), (12, 4, 30), (6, 3, 10)):
+            N += 1                                        # keep off the unrolled kernels' horizons
+        B = int(rng.integers(1, 150))
+        prob = _random_problem(rng, nx, nu, N, bounded=bool(rng.integers(0, 2)))
+        x0 = np.asfortranarray(rng.uniform(-1.0, 1.0, (nx, B)))
+        mode = int(rng.integers(0, 3))
+        xref = uref = None
+        if mode == 1:
+            xref, uref = 0.2 * rng.standard_normal((nx, N)), 0.1 * rng.standard_normal((nu, N - 1))
+        elif mode == 2:
+            xref, uref = 0.2 * rng.standard_normal((nx, N, B)), 0.1 * rng.standard_normal((nu, N - 1, B))
+        ct = int(rng.choice([1, 1, 3]))
+        kw = dict(abs_pri_tol=1e-4, abs_dua_tol=1e-4, max_iter=60, check_termination=ct)
+        ref = _oracle_batch(oracle_built, prob, x0, xref=xref, uref=uref, **kw)
+        bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+        assert bs.kernel_name == f"stream4<{nx},{nu}>", (bs.kernel_name, N)
+        bs.update_settings(**kw)
+        bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        bs.set_x0(x0)
+        if xref is not None:
+            bs.set_x_ref(xref)
+            bs.set_u_ref(uref)
+        for warm in (True, False):                        # workspace kept (reference semantics), then one-shot
+            bs.set_warm_start(warm)
+            bs.reset()
+            bs.solve()
+            sol, st = bs.get_solution(), bs.get_status()
+            same = st["iter"] == ref["iter"]
+            tag = (nx, nu, N, B, mode, ct, warm)
+            assert same.mean() >= 0.9 and np.all(np.abs(st["iter"] - ref["iter"]) <= ct), tag
+            assert nrel_batch(sol["states"], ref["x"])[same].max() <= SWEEP_TOL, tag
+            assert nrel_batch(sol["controls"], ref["u"])[same].max() <= SWEEP_TOL, tag
+        bs.close()
+
+
 @pytest.mark.parametrize("family", ["cartpole", "quadrotor"])
 def test_full_size_properties(hip_lib, oracle_built, family):
     """BASELINE.json sizes (batch 65 536): size-independent properties.
