@@ -880,6 +880,109 @@ def test_linear_constraints_vs_oracle(hip_lib, oracle_built, monkeypatch, case, 
     bs.close()
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_stream_extensions_random_sweep(hip_lib, oracle_built, seed):
+    """Cones that start anywhere and straddle lane boundaries (up to two per side, dimensions 2..4), dense linear
+    rows, an affine term, on shapes whose rows split unevenly over the four lanes — against the fp64 restatement
+    (UNPINNED with respect to the reference, like every cone / linear / fdyn test).  Tolerance as in
+    test_stream_kernel_random_sweep."""
+    SWEEP_TOL = 5e-5
+    rng = np.random.default_rng(7000 + seed)
+    nx, nu = [(8, 3), (10, 4), (6, 2), (12, 4)][seed]
+    N, B = int(rng.integers(4, 18)), int(rng.integers(3, 40))
+    prob = _random_problem(rng, nx, nu, N, bounded=bool(seed % 2))
+    fd = 0.02 * rng.standard_normal(nx)
+    # cones: (first row, dimension, mu); the second one only where the rows allow it
+    cx = [(1, 3, 0.6)] + ([(5, 4, 0.9)] if nx >= 9 else [(4, 2, 1.2)])
+    cu = [(0, nu if nu <= 3 else 3, 0.5)] + ([(2, 2, 0.8)] if nu == 4 else [])
+    if nu == 4:
+        cu[0] = (0, 2, 0.5)
+    Ax, bx = rng.standard_normal((3, nx)), rng.uniform(0.5, 1.5, 3)
+    Au, bu = rng.standard_normal((2, nu)), rng.uniform(0.2, 0.5, 2)
+    x0 = np.asfortranarray(rng.uniform(-0.5, 0.5, (nx, B)))
+    kw = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=50, check_termination=1)
+    X, U = np.zeros((nx, N, B)), np.zeros((nu, N - 1, B))
+    it = np.zeros(B, dtype=int)
+    for b in range(B):
+        o = oracle_built.CpuSolver("orc64", prob.A, prob.B, prob.Q, prob.R, prob.rho, N)
+        o.update_settings(**kw)
+        o.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        o.set_fdyn(fd)
+        o.set_cone_constraints([c[0] for c in cu], [c[1] for c in cu], [c[2] for c in cu],
+                               [c[0] for c in cx], [c[1] for c in cx], [c[2] for c in cx])
+        o.set_linear_constraints(Ax, bx, Au, bu)
+        o.set_x0(x0[:, b])
+        o.solve()
+        r = o.get_solution()
+        X[:, :, b], U[:, :, b], it[b] = r["x"], r["u"], r["iter"]
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, N, batch=B)
+    bs.update_settings(**kw)
+    bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    bs.set_fdyn(fd)
+    bs.set_cone_constraints([c[0] for c in cu], [c[1] for c in cu], [c[2] for c in cu],
+                            [c[0] for c in cx], [c[1] for c in cx], [c[2] for c in cx])
+    bs.set_linear_constraints(Ax, bx, Au, bu)
+    assert bs.kernel_name == f"stream4<{nx},{nu}>"
+    bs.set_x0(x0)
+    for warm in (True, False):
+        bs.set_warm_start(warm)
+        bs.reset()
+        bs.solve()
+        sol, st = bs.get_solution(), bs.get_status()
+        same = st["iter"] == it
+        assert same.mean() >= 0.9 and np.all(np.abs(st["iter"] - it) <= 1), (nx, nu, N, B, warm)
+        assert nrel_batch(sol["states"], X)[same].max() <= SWEEP_TOL, (nx, nu, N, B, warm)
+        assert nrel_batch(sol["controls"], U)[same].max() <= SWEEP_TOL, (nx, nu, N, B, warm)
+    bs.close()
+
+
+def test_families_with_cones_linear_and_fdyn(hip_lib, oracle_built):
+    """One (A, B, Q, R, rho) per instance together with the affine term, a cone per side and linear rows (shared by
+    the batch): each instance against the oracle set up for its own family."""
+    rng = np.random.default_rng(77)
+    nx, nu, N, B = 6, 3, 12, 21
+    base = _random_problem(rng, nx, nu, N, bounded=True)
+    A = np.repeat(base.A[:, :, None], B, axis=2) * (1.0 + 0.03 * rng.standard_normal((nx, nx, B)))
+    Bm = np.repeat(base.B[:, :, None], B, axis=2) * (1.0 + 0.05 * rng.standard_normal((nx, nu, B)))
+    Q = np.stack([np.diag(rng.uniform(0.5, 4.0, nx)) for _ in range(B)], axis=2)
+    R = np.stack([np.diag(rng.uniform(0.5, 2.0, nu)) for _ in range(B)], axis=2)
+    rho = rng.uniform(0.8, 3.0, B)
+    fd = 0.02 * rng.standard_normal(nx)
+    Ax, bx, Au, bu = rng.standard_normal((2, nx)), rng.uniform(0.5, 1.5, 2), rng.standard_normal((2, nu)), rng.uniform(0.2, 0.5, 2)
+    x0 = np.asfortranarray(rng.uniform(-0.5, 0.5, (nx, B)))
+    kw = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=50, check_termination=1)
+    X, U = np.zeros((nx, N, B)), np.zeros((nu, N - 1, B))
+    it = np.zeros(B, dtype=int)
+    for b in range(B):
+        o = oracle_built.CpuSolver("orc64", A[:, :, b], Bm[:, :, b], Q[:, :, b], R[:, :, b], float(rho[b]), N)
+        o.update_settings(**kw)
+        o.set_bound_constraints(base.x_min, base.x_max, base.u_min, base.u_max)
+        o.set_fdyn(fd)
+        o.set_cone_constraints([0], [3], [0.5], [2], [3], [0.7])
+        o.set_linear_constraints(Ax, bx, Au, bu)
+        o.set_x0(x0[:, b])
+        o.solve()
+        r = o.get_solution()
+        X[:, :, b], U[:, :, b], it[b] = r["x"], r["u"], r["iter"]
+    bs = t.BatchSolver.from_families(A, Bm, Q, R, rho, N)
+    bs.update_settings(**kw)
+    bs.set_bound_constraints(base.x_min, base.x_max, base.u_min, base.u_max)
+    bs.set_fdyn(fd)
+    bs.set_cone_constraints([0], [3], [0.5], [2], [3], [0.7])
+    bs.set_linear_constraints(Ax, bx, Au, bu)
+    assert bs.kernel_name == "stream4<6,3>"
+    bs.set_x0(x0)
+    for warm in (True, False):
+        bs.set_warm_start(warm)
+        bs.reset()
+        bs.solve()
+        sol, st = bs.get_solution(), bs.get_status()
+        same = st["iter"] == it
+        assert same.mean() >= 0.9 and np.all(np.abs(st["iter"] - it) <= 1), warm
+        assert nrel_batch(sol["states"], X)[same].max() <= 5e-5 and nrel_batch(sol["controls"], U)[same].max() <= 5e-5, warm
+    bs.close()
+
+
 def test_linear_and_equality_constraints_through_dropin_api(hip_lib, oracle_built):
     """TinyMPC.jl:229-270 on the process-global entry points: set_linear_constraints, then
     set_equality_constraints (two opposite rows per equality), against the oracle."""
