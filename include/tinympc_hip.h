@@ -180,6 +180,12 @@ int tinympc_solve_status(tinympc_solver *s);
  * negated when the step hit max_iter).  Any log pointer may be NULL. */
 int tinympc_mpc_rollout(tinympc_solver *s, int steps, void *hip_stream);
 int tinympc_get_mpc_log(tinympc_solver *s, double *x, double *u, int *iter);
+/* Tolerance-terminated solves of big batches: with chunk_iters > 0 (rounded up to a multiple of check_termination)
+ * a solve runs in chunks of that many iterations and, between chunks, gathers the instances still iterating into
+ * a dense list, so that wavefronts do not idle behind their slowest instance.  Iterates, iteration counts and
+ * residuals are those of the single-launch solve.  The solve then synchronises its stream.  Ignored for
+ * fixed-iteration settings (a tolerance <= 0), per-instance families, closed-loop rollouts.  0 = off (default). */
+int tinympc_set_compaction(tinympc_solver *s, int chunk_iters);
 /* Kernel timing: when enabled, every solve records HIP events immediately around the ADMM kernel
  * launch on the launch stream; tinympc_kernel_elapsed_ms returns the last kernel's duration,
  * tinympc_kernel_elapsed_mean_ms the mean over the last `last_n` launches (at most 256)

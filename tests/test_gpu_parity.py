@@ -1078,6 +1078,47 @@ def test_config5_shard_tolerance_terminated(hip_lib, oracle_built):
     bs.close()
 
 
+@pytest.mark.parametrize("family,kernel", [("cartpole", "quad<4,1,20"), ("quadrotor", "quad<12,4,30"),
+                                           ("cartpole19", "stream4<4,1>")])
+def test_chunked_solve_with_compaction_is_the_same_solve(hip_lib, oracle_built, family, kernel):
+    """tinympc_set_compaction: chunks of iterations with the unconverged instances gathered in between give bit for
+    bit the single-launch result (iterates, iteration counts, solved flags, residuals, global status), cold and
+    warm-started; and the oracle agrees."""
+    B = 3000
+    if family == "quadrotor":
+        prob, x0 = t.problems.quadrotor(30), t.problems.quadrotor_x0(B, seed=3)
+    else:
+        prob, x0 = t.problems.cartpole(20 if family == "cartpole" else 19, u_bound=0.5), t.problems.cartpole_x0(B, seed=8)
+    kw = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=5)
+    out = []
+    for chunk in (0, 12):                                 # 12 -> chunks of 15 iterations (multiple of 5)
+        bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+        assert bs.kernel_name.startswith(kernel)
+        bs.update_settings(**kw)
+        bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        bs.set_compaction(chunk)
+        bs.set_x0(x0)
+        status1 = bs.solve()
+        sol1, st1 = bs.get_solution(), bs.get_status()
+        bs.set_x0(np.asfortranarray(0.9 * x0))            # warm-started second solve from the kept workspace
+        status2 = bs.solve()
+        sol2, st2 = bs.get_solution(), bs.get_status()
+        out.append((status1, sol1, st1, status2, sol2, st2))
+        bs.close()
+    a, c = out
+    for i in (0, 3):
+        assert a[i] == c[i]
+    for i in (1, 4):
+        assert np.array_equal(a[i]["states"], c[i]["states"]) and np.array_equal(a[i]["controls"], c[i]["controls"])
+    for i in (2, 5):
+        for k in ("iter", "solved", "residuals"):
+            assert np.array_equal(a[i][k], c[i][k]), k
+    assert len(set(a[2]["iter"].tolist())) > 3            # the instances really stop at different iterations
+    ref = _oracle_batch(oracle_built, prob, x0, **kw)
+    same = a[2]["iter"] == ref["iter"]
+    assert same.mean() >= 0.97 and nrel_batch(c[1]["controls"], ref["u"])[same].max() <= FP32_TOL
+
+
 def test_kernel_selection_by_batch(hip_lib):
     """Lanes per instance follow the batch size; shapes outside the unrolled table use the stream kernel."""
     prob = t.problems.cartpole(20, u_bound=0.5)

@@ -42,6 +42,10 @@ struct AdmmParams {
     uint32_t *gacc;   // [GSTAT_WORDS] accumulator behind it (fold_status); zero between launches
     // stream / generic kernels: per-instance scratch in HBM
     float *scratch;
+    // chunked solves with compaction (Solver::solve_chunked): launch slot j works on instance idx[j] (NULL: j) and
+    // reports iter_offset + its own iteration count; `batch` is then the number of slots of this launch
+    const int *idx;
+    int iter_offset;
     int batch;
     int max_iter;
     int check_termination;  // <= 0: never check (the reference divides by it, admm.cpp:91)

@@ -361,8 +361,9 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
     __syncthreads();
 
     const int q = tid & (G - 1);
-    const long b = (long)blockIdx.x * S::INST_PER_BLOCK + tid / G;
-    const bool active = b < P.batch;
+    const long slot = (long)blockIdx.x * S::INST_PER_BLOCK + tid / G;
+    const bool active = slot < P.batch;
+    const long b = (active && P.idx) ? P.idx[slot] : slot;  // instance this lane group works on
     const float *lb = s_bnd + q * S::BW;
     const float *lr = s_ref + q * S::RW;
     const float *ld = s_bnd + N * G * S::BW + q * S::DW;  // diag(Q)+rho, diag(R)+rho
@@ -856,7 +857,7 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
             }
         }
         if (q == 0) {
-            P.iter[b] = it;
+            P.iter[b] = P.iter_offset + it;
             P.solved[b] = conv;
             P.res[b * 4 + 0] = res0;
             P.res[b * 4 + 1] = res1;

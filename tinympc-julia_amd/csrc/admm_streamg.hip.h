@@ -214,9 +214,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
 
     const int q = tid % G;
     const long B = P.batch, BG = G * B;
-    const long b = (long)blockIdx.x * (T / G) + tid / G;
-    const bool active = b < B;
-    const long bb = active ? b : 0;
+    const long slot = (long)blockIdx.x * (T / G) + tid / G;
+    const bool active = slot < B;
+    const long bb = active ? slot : 0;                      // dense index: scratch columns (and families, HET)
+    const long b = (active && P.idx) ? P.idx[slot] : slot;  // instance this lane group works on
     const long L = G * bb + q;  // this lane's column in the per-instance coefficient matrix (HET)
     const long EX = (long)NX * N, EU = (long)NU * (N - 1);
     const float *lb = s_bnd + q * PK::BW;
@@ -818,7 +819,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
             for (int m = 0; m < RU; ++m)
                 if (q * RU + m < NU) P.uout[b * EU + k * NU + q * RU + m] = *SUP(Szw, k, m);
         if (q == 0) {
-            P.iter[b] = it;
+            P.iter[b] = P.iter_offset + it;
             P.solved[b] = conv;
             P.res[b * 4 + 0] = res0;
             P.res[b * 4 + 1] = res1;

@@ -275,6 +275,11 @@ int tinympc_set_ref_mode(tinympc_solver *s, int ref_mode) {
     });
 }
 
+int tinympc_set_compaction(tinympc_solver *s, int chunk_iters) {
+    if (!s || chunk_iters < 0) return -1;
+    s->s.chunk_iters = chunk_iters;
+    return 0;
+}
 int tinympc_set_profiling(tinympc_solver *s, int enable) {
     if (!s) return -1;
     s->s.profiling = enable != 0;

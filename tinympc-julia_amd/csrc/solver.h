@@ -147,6 +147,16 @@ struct Solver {
     int ensure_extension_buffers();
     int reset();
     int solve_async(hipStream_t stream, int mpc_steps = 0);
+    // one kernel launch over `n_slots` instances (idx: their ids, NULL = 0..n_slots-1) for at most `max_iter_pass`
+    // iterations, the instances having done `iter_offset` already
+    int launch_pass(hipStream_t stream, int mpc_steps, const int *idx, int n_slots, int iter_offset, int max_iter_pass,
+                    bool cold, bool save);
+    // tolerance-terminated solves of big batches in chunks of `chunk_iters` iterations: after each chunk the
+    // instances still iterating are compacted, so wavefronts do not idle behind their slowest instance
+    int solve_chunked(hipStream_t stream);
+    int chunk_iters = 0;  // 0: off
+    int *d_idx[2] = {nullptr, nullptr};
+    int *d_count = nullptr;
     int get_mpc_log(double *x, double *u, int *iter);
     int solve_status();
     double kernel_elapsed_ms();

@@ -169,6 +169,9 @@ void Solver::free_batch() {
     dev_free(d_svc);
     dev_free(d_syc);
     dev_free(d_szc);
+    dev_free(d_idx[0]);
+    dev_free(d_idx[1]);
+    dev_free(d_count);
     dev_free(d_lin);
     dev_free(d_sgl);
     dev_free(d_svl);
@@ -606,9 +609,68 @@ int Solver::ensure_extension_buffers() {
     return 0;
 }
 
+// appends the ids of the instances that have not converged to `out` (order unspecified)
+__global__ void compact_unsolved_kernel(const int *solved, const int *idx_in, int n_in, int *idx_out, int *count) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_in) return;
+    const int b = idx_in ? idx_in[j] : j;
+    if (!solved[b]) idx_out[atomicAdd(count, 1)] = b;
+}
+
 int Solver::solve_async(hipStream_t stream, int mpc_steps) {
     HIP_TRY(hipSetDevice(device));
     if (select_kernel() || ensure_extension_buffers()) return -1;
+    const bool chunkable = chunk_iters > 0 && mpc_steps == 0 && !hetero && (ke || se) && st.check_termination > 0 &&
+                           st.abs_pri_tol > 0.0 && st.abs_dua_tol > 0.0 && st.max_iter > chunk_iters;
+    if (chunkable) return solve_chunked(stream);
+    return launch_pass(stream, mpc_steps, nullptr, batch, 0, st.max_iter, !warm_start, warm_start);
+}
+
+// Chunks of (a multiple of check_termination) iterations; between chunks the unconverged instances are gathered
+// into a dense index list on the device, so the next launch has no idle lanes for the finished ones.  The warm-start
+// workspace carries every instance from chunk to chunk exactly (it is what the kernel holds, fp32), so the iterates,
+// iteration counts and residuals are those of the single-launch solve.  Synchronises the stream between chunks.
+int Solver::solve_chunked(hipStream_t stream) {
+    const int ct = st.check_termination;
+    const int chunk = std::max(ct, (chunk_iters + ct - 1) / ct * ct);
+    if (!d_idx[0]) {
+        if (dev_alloc(d_idx[0], (size_t)batch) || dev_alloc(d_idx[1], (size_t)batch) || dev_alloc(d_count, 1)) return -1;
+    }
+    uint32_t acc[GSTAT_WORDS] = {0};
+    const int *idx = nullptr;
+    int n = batch, offset = 0, cur = 0;
+    for (;;) {
+        const int iters = std::min(chunk, st.max_iter - offset);
+        if (launch_pass(stream, 0, idx, n, offset, iters, offset == 0 && !warm_start, true)) return -1;
+        offset += iters;
+        HIP_TRY(hipMemcpyAsync(h_gstat, d_gstat, GSTAT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        const bool last = offset >= st.max_iter;
+        int count = 0;
+        if (!last) {
+            HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(int), stream));
+            hipLaunchKernelGGL(compact_unsolved_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_solved, idx, n,
+                               d_idx[cur], d_count);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(&count, d_count, sizeof(int), hipMemcpyDeviceToHost, stream));
+        }
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (int i = 0; i < 4; ++i) acc[i] = std::max(acc[i], h_gstat[i]);  // residual maxima over every instance's last check
+        acc[4] = h_gstat[4];                                                // unsolved: what the latest chunk left
+        if (last || count == 0) {
+            if (count == 0 && !last) acc[4] = 0;
+            break;
+        }
+        idx = d_idx[cur];
+        n = count;
+        cur ^= 1;
+    }
+    HIP_TRY(hipMemcpyAsync(d_gstat, acc, GSTAT_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+}
+
+int Solver::launch_pass(hipStream_t stream, int mpc_steps, const int *idx, int n_slots, int iter_offset, int max_iter_pass,
+                        bool cold, bool save) {
     if (mpc_steps > 0) {
         if (!ke) {
             set_error("mpc_rollout: this problem shape has no specialised kernel (generic path does plain solves only)");
@@ -647,12 +709,14 @@ int Solver::solve_async(hipStream_t stream, int mpc_steps) {
     P.gstat = d_gstat;
     P.gacc = d_gstat + GSTAT_WORDS;
     P.scratch = d_scratch;
-    P.batch = batch;
-    P.max_iter = st.max_iter;
+    P.idx = idx;
+    P.iter_offset = iter_offset;
+    P.batch = n_slots;
+    P.max_iter = max_iter_pass;
     P.check_termination = st.check_termination;
     P.ref_mode = ref_mode;
-    P.cold_start = warm_start ? 0 : 1;
-    P.save_state = warm_start ? 1 : 0;
+    P.cold_start = cold ? 1 : 0;
+    P.save_state = save ? 1 : 0;
     P.abs_pri_tol = (float)st.abs_pri_tol;
     P.abs_dua_tol = (float)st.abs_dua_tol;
     P.rho = (float)cache.rho;

@@ -95,6 +95,7 @@ SIGNATURES = {
     "tinympc_mpc_rollout": (c_int, [c_vp, c_int, c_vp]),
     "tinympc_get_mpc_log": (c_int, [c_vp, c_dp, c_dp, c_ip]),
     "tinympc_set_profiling": (c_int, [c_vp, c_int]),
+    "tinympc_set_compaction": (c_int, [c_vp, c_int]),
     "tinympc_kernel_elapsed_ms": (c_dbl, [c_vp]),
     "tinympc_kernel_elapsed_mean_ms": (c_dbl, [c_vp, c_int]),
     "tinympc_set_precision": (c_int, [c_vp, c_int]),
@@ -567,6 +568,11 @@ class BatchSolver:
 
     def set_profiling(self, on):
         self._chk(self.lib.tinympc_set_profiling(self.h, 1 if on else 0), "set_profiling")
+
+    def set_compaction(self, chunk_iters):
+        """tolerance-terminated solves in chunks of `chunk_iters` iterations with the unconverged instances compacted
+        in between (0: off)"""
+        self._chk(self.lib.tinympc_set_compaction(self.h, int(chunk_iters)), "set_compaction")
 
     def kernel_elapsed_ms(self, last_n=1):
         """duration of the last launch, or the mean over the last `last_n` launches (profiling mode)"""
