@@ -1,0 +1,283 @@
+// Fused ADMM kernel on the fp64 matrix cores: "mfma<nx,nu,N>", for one-shot solves of shapes with nx <= 12, nu <= 4.
+//
+// One instance's mat-vecs are too small for a matrix core, but a batch sharing one (A, B, Kinf, ...) is a dense
+// contraction: 16 instances side by side make X (nx x 16), and x+ = A x + B u for all of them is a 16 x nx x 16
+// product.  v_mfma_f64_16x16x4f64 (D = A B + C, A: 16 x 4, B: 4 x 16) has, on gfx950,
+//     A operand: lane l holds A[l % 16][l / 16]          B operand: lane l holds B[l / 16][l % 16]
+//     result   : lane l, register v holds D[4 v + l / 16][l % 16]          (experiments/mfma_probe.hip)
+// so with lane l = 16 g + j working on instance j of its wavefront and owning state rows {g, 4 + g, 8 + g} (registers
+// v = 0, 1, 2) and input row g (register v = 3), a RESULT IS ALREADY LAID OUT AS THE NEXT PRODUCT'S B OPERAND: register
+// s of lane group g is row 4 s + g, i.e. K-slice s.  The whole forward / backward recurrence chains MFMAs without a
+// single cross-lane move:
+//     forward  : c = {0, 0, 0, -d};  c += [A; -Kinf] x (one MFMA per K-slice)  ->  c[0..2] = A x,  c[3] = u = -d - Kinf x
+//                c += [B; 0] u                                                 ->  c[0..2] = x+
+//     backward : c = {q, r};         c += [AmBKt; B^T] p                       ->  c[0..2] = q + AmBKt p,  c[3] = B^T p + r
+//                d = [0; Quu_inv] c[3];   c += [-Kinf^T; 0] r                  ->  c[0..2] = p-
+// with the stacked matrices ([A; -Kinf] is 16 x 12 for the quadrotor: a full tile) spread over the 64 lanes, three
+// doubles per lane and matrix, held in registers for the whole solve: no LDS coefficient traffic, no DPP broadcasts,
+// and the 48 + 48 fp64 FMAs per lane and knot pair of the quad kernel leave the VALU, which does the elementwise
+// slack / dual / cost work while the matrix core runs.
+//
+// Scope: cold-start solves whose workspace is not kept (what the quad kernel's OS / UNI variants serve); other modes
+// stay on the quad kernel.  An instance that converges stores its solution at that iteration and idles (its lanes keep
+// iterating, results discarded) until its wavefront is done.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "admm_params.h"
+
+namespace tmpc {
+
+typedef double mf_d4 __attribute__((ext_vector_type(4)));
+
+template <int NX, int NU, int N>
+struct MfmaShape {
+    static_assert(NX >= 1 && NX <= 12 && NU >= 1 && NU <= 4, "mfma kernel: nx <= 12, nu <= 4");
+    static constexpr int VX = (NX + 3) / 4;             // state rows (registers) per lane
+    static constexpr int NF = 3 * VX + 3;               // operand doubles per lane: Mf[VX] Bf Mb[VX] KTn QI PT[VX]
+    static constexpr int O_MF = 0, O_BF = VX, O_MB = VX + 1, O_KT = 2 * VX + 1, O_QI = 2 * VX + 2, O_PT = 2 * VX + 3;
+    // bounds pack (fp32): xmin[N][NX] xmax[N][NX] umin[N-1][NU] umax[N-1][NU] Qd[NX] Rd[NU]
+    static constexpr int B_XMIN = 0, B_XMAX = N * NX, B_UMIN = 2 * N * NX, B_UMAX = 2 * N * NX + (N - 1) * NU,
+                         B_QD = 2 * N * NX + 2 * (N - 1) * NU, B_RD = B_QD + NX, BOUNDS_LEN = B_RD + NU;
+    static constexpr int REFS_LEN = N * NX + (N - 1) * NU;  // shared references: xref[N][NX] uref[N-1][NU]
+};
+
+template <int I, int E, class F>
+__device__ __forceinline__ void mf_for(F &&f) {
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        mf_for<I + 1, E>(f);
+    }
+}
+
+__device__ __forceinline__ mf_d4 mf_mma(double a, double b, mf_d4 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// max over the four lanes (16 apart) of an instance
+__device__ __forceinline__ float mf_inst_max(float m) {
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    return m;
+}
+
+template <int NX, int NU, int N, int REFS, bool XB>
+__global__ __launch_bounds__(256) void admm_mfma_kernel(const AdmmParams P) {
+    using S = MfmaShape<NX, NU, N>;
+    constexpr int VX = S::VX, T = 256;
+    __shared__ float s_bnd[S::BOUNDS_LEN];
+    __shared__ float s_ref[REFS == REF_SHARED ? S::REFS_LEN : 1];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < S::BOUNDS_LEN; i += T) s_bnd[i] = P.bounds[i];
+    if constexpr (REFS == REF_SHARED)
+        for (int i = tid; i < S::REFS_LEN; i += T) s_ref[i] = i < N * NX ? P.xref[i] : P.uref[i - N * NX];
+    __syncthreads();
+
+    const int l = tid & 63, g = l >> 4, j = l & 15;
+    const long slot = (long)blockIdx.x * 64 + (tid >> 6) * 16 + j;
+    const bool active = slot < P.batch;
+    const long b = (active && P.idx) ? P.idx[slot] : slot;
+    constexpr long EX = (long)NX * N, EU = (long)NU * (N - 1);
+    const bool uok = g < NU;
+    bool xok[VX];
+#pragma unroll
+    for (int v = 0; v < VX; ++v) xok[v] = 4 * v + g < NX;
+
+    // matrix operands of this lane (fp64, [field][64 lanes] in HBM), constant for the solve
+    const double *gc = reinterpret_cast<const double *>(P.coef);
+    double cf[S::NF];
+#pragma unroll
+    for (int f = 0; f < S::NF; ++f) cf[f] = gc[f * 64 + l];
+    float qd[VX], rd = uok ? s_bnd[S::B_RD + g] : 0.f;
+#pragma unroll
+    for (int v = 0; v < VX; ++v) qd[v] = xok[v] ? s_bnd[S::B_QD + 4 * v + g] : 0.f;
+    const float rho = P.rho;
+
+    // per-instance state of this lane: its rows of the state dual, of vnew (in place of v), and its input row's
+    // y, znew (in place of z), d.  No state dual without an active state bound (identically zero in a cold one-shot solve).
+    float sg[XB ? N : 1][VX], sw[N][VX], sy[N - 1], szw[N - 1], sd[N - 1];
+    float xr[REFS == REF_PER_INSTANCE ? N : 1][VX], ur[REFS == REF_PER_INSTANCE ? N - 1 : 1];
+    double x0[VX];
+#pragma unroll
+    for (int v = 0; v < VX; ++v) x0[v] = (active && xok[v]) ? (double)P.x0[b * NX + 4 * v + g] : 0.0;
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+#pragma unroll
+        for (int v = 0; v < VX; ++v) {
+            if constexpr (XB) sg[k][v] = 0.f;
+            sw[k][v] = 0.f;
+            if constexpr (REFS == REF_PER_INSTANCE)
+                xr[k][v] = (active && xok[v]) ? P.xref[b * EX + k * NX + 4 * v + g] : 0.f;
+        }
+#pragma unroll
+    for (int k = 0; k < N - 1; ++k) {
+        sy[k] = szw[k] = sd[k] = 0.f;
+        if constexpr (REFS == REF_PER_INSTANCE) ur[k] = (active && uok) ? P.uref[b * EU + k * NU + g] : 0.f;
+    }
+    auto ref_x = [&](auto kk, int v) -> float {
+        constexpr int K = decltype(kk)::value;
+        if constexpr (REFS == REF_SHARED) return xok[v] ? s_ref[K * NX + 4 * v + g] : 0.f;
+        else if constexpr (REFS == REF_PER_INSTANCE) return xr[K][v];
+        else return 0.f;
+    };
+    auto ref_u = [&](auto kk) -> float {
+        constexpr int K = decltype(kk)::value;
+        if constexpr (REFS == REF_SHARED) return uok ? s_ref[N * NX + K * NU + g] : 0.f;
+        else if constexpr (REFS == REF_PER_INSTANCE) return ur[K];
+        else return 0.f;
+    };
+    constexpr float kInf = __builtin_inff();
+
+    int it = 0, conv = 0;
+    float res0 = 0.f, res1 = 0.f, res2 = 0.f, res3 = 0.f;
+    const int ct = P.check_termination;
+    const bool can_converge = P.abs_pri_tol > 0.f && P.abs_dua_tol > 0.f;
+    const int last_check_it = ct > 0 ? (P.max_iter / ct) * ct : 0;
+
+    auto store_solution = [&]() {  // this instance's solution and status: vnew / znew of the iteration just run
+#pragma unroll
+        for (int v = 0; v < VX; ++v)
+            if (xok[v]) {
+#pragma unroll
+                for (int k = 0; k < N; ++k) P.xout[b * EX + k * NX + 4 * v + g] = sw[k][v];
+            }
+        if (uok) {
+#pragma unroll
+            for (int k = 0; k < N - 1; ++k) P.uout[b * EU + k * NU + g] = szw[k];
+        }
+        if (g == 0) {
+            P.iter[b] = P.iter_offset + it;
+            P.solved[b] = conv;
+            P.res[b * 4 + 0] = res0;
+            P.res[b * 4 + 1] = res1;
+            P.res[b * 4 + 2] = res2;
+            P.res[b * 4 + 3] = res3;
+        }
+    };
+
+    for (int i = 0; i < P.max_iter; ++i) {
+        const bool check = ct > 0 && (i + 1) % ct == 0;                       // every lane's it == i here
+        const bool need_res = check && (can_converge || i + 1 == last_check_it);
+        // ================= fused forward sweep (admm.cpp:25-69, :93-96) =================
+        float pri_x = 0.f, dua_x = 0.f, pri_u = 0.f, dua_u = 0.f;
+        double x[VX];
+#pragma unroll
+        for (int v = 0; v < VX; ++v) x[v] = x0[v];
+        mf_for<0, N>([&](auto kk) {
+            constexpr int k = decltype(kk)::value;
+            asm volatile("" ::: "memory");  // LDS constants (bounds, shared references) are re-read per knot, not hoisted
+            mf_d4 c = {0.0, 0.0, 0.0, 0.0};
+            if constexpr (k < N - 1) {
+                c[3] = -(double)sd[k];
+                mf_for<0, VX>([&](auto ss) {
+                    constexpr int s = decltype(ss)::value;
+                    c = mf_mma(cf[S::O_MF + s], x[s], c);                      // [A; -Kinf] x
+                });
+            }
+            // slack / dual of the state rows at this knot (the matrix core works on the products meanwhile)
+#pragma unroll
+            for (int v = 0; v < VX; ++v) {
+                const float xf = (float)x[v];
+                const float gk = XB ? sg[XB ? k : 0][v] : 0.f;
+                float vn = xf + gk;
+                if constexpr (XB) {
+                    const float lo = xok[v] ? s_bnd[S::B_XMIN + k * NX + 4 * v + g] : -kInf;
+                    const float hi = xok[v] ? s_bnd[S::B_XMAX + k * NX + 4 * v + g] : kInf;
+                    vn = fminf(hi, fmaxf(lo, vn));
+                    sg[XB ? k : 0][v] = (gk + xf) - vn;
+                }
+                if (need_res) {
+                    pri_x = fmaxf(pri_x, fabsf(xf - vn));
+                    dua_x = fmaxf(dua_x, fabsf(sw[k][v] - vn));
+                }
+                sw[k][v] = vn;
+            }
+            if constexpr (k < N - 1) {
+                const double u = c[3];                                         // -d - Kinf x
+                const float uf = (float)u, yk = sy[k];
+                float zn = uf + yk;
+                const float lo = uok ? s_bnd[S::B_UMIN + k * NU + g] : -kInf, hi = uok ? s_bnd[S::B_UMAX + k * NU + g] : kInf;
+                zn = fminf(hi, fmaxf(lo, zn));
+                sy[k] = (yk + uf) - zn;
+                if (need_res) {
+                    pri_u = fmaxf(pri_u, fabsf(uf - zn));
+                    dua_u = fmaxf(dua_u, fabsf(szw[k] - zn));
+                }
+                szw[k] = zn;
+                c[3] = 0.0;
+                c = mf_mma(cf[S::O_BF], u, c);                                 // + [B; 0] u
+#pragma unroll
+                for (int v = 0; v < VX; ++v) x[v] = c[v];
+            }
+        });
+        it += 1;
+        bool newly = false;
+        if (need_res) {
+            const float r0 = mf_inst_max(pri_x), r1 = mf_inst_max(dua_x) * rho, r2 = mf_inst_max(pri_u),
+                        r3 = mf_inst_max(dua_u) * rho;
+            if (!conv) {  // a finished instance keeps the residuals it finished with
+                res0 = r0, res1 = r1, res2 = r2, res3 = r3;
+                if (res0 < P.abs_pri_tol && res2 < P.abs_pri_tol && res1 < P.abs_dua_tol && res3 < P.abs_dua_tol) {
+                    conv = 1;
+                    newly = true;
+                }
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(newly)) {
+            if (newly && active) store_solution();
+        }
+        if (!__builtin_amdgcn_ballot_w64(active && !conv)) break;
+        // ================= fused backward sweep (admm.cpp:75-83, :13-20) =================
+        double p[VX];
+        {
+            mf_d4 c = {0.0, 0.0, 0.0, 0.0};
+            if constexpr (REFS != REF_ZERO) {
+                mf_for<0, VX>([&](auto ss) {
+                    constexpr int s = decltype(ss)::value;
+                    c = mf_mma(cf[S::O_PT + s], (double)ref_x(std::integral_constant<int, N - 1>{}, s), c);  // Pinf^T xref
+                });
+            }
+#pragma unroll
+            for (int v = 0; v < VX; ++v) p[v] = -c[v] - (double)(rho * (sw[N - 1][v] - (XB ? sg[XB ? N - 1 : 0][v] : 0.f)));
+        }
+        mf_for<0, N - 1>([&](auto kk) {
+            constexpr int k = N - 2 - decltype(kk)::value;
+            constexpr std::integral_constant<int, k> kc{};
+            asm volatile("" ::: "memory");
+            const double r = (double)(-(ref_u(kc) * rd) - rho * (szw[k] - sy[k]));
+            mf_d4 c;
+#pragma unroll
+            for (int v = 0; v < 3; ++v)
+                c[v] = v < VX ? (double)(-(ref_x(kc, v < VX ? v : 0) * qd[v < VX ? v : 0]) -
+                                         rho * (sw[k][v < VX ? v : 0] - (XB ? sg[XB ? k : 0][v < VX ? v : 0] : 0.f)))
+                              : 0.0;
+            c[3] = r;
+            mf_for<0, VX>([&](auto ss) {
+                constexpr int s = decltype(ss)::value;
+                c = mf_mma(cf[S::O_MB + s], p[s], c);                          // [AmBKt; B^T] p
+            });
+            mf_d4 dq = {0.0, 0.0, 0.0, 0.0};
+            dq = mf_mma(cf[S::O_QI], c[3], dq);                                // [0; Quu_inv] (B^T p + r)
+            sd[k] = (float)dq[3];
+            c = mf_mma(cf[S::O_KT], r, c);                                     // + [-Kinf^T; 0] r
+#pragma unroll
+            for (int v = 0; v < VX; ++v) p[v] = c[v];
+        });
+    }
+
+    if (active && !conv) store_solution();
+    {
+        float m0 = active ? res0 : 0.f, m1 = active ? res1 : 0.f, m2 = active ? res2 : 0.f, m3 = active ? res3 : 0.f;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {  // over the 16 instances of the wavefront (lanes of a group)
+            m0 = fmaxf(m0, __shfl_xor(m0, off, 64));
+            m1 = fmaxf(m1, __shfl_xor(m1, off, 64));
+            m2 = fmaxf(m2, __shfl_xor(m2, off, 64));
+            m3 = fmaxf(m3, __shfl_xor(m3, off, 64));
+        }
+        const unsigned long long unsolved = __builtin_amdgcn_ballot_w64(active && !conv && g == 0);
+        fold_status(P, m0, m1, m2, m3, __popcll(unsolved), tid);
+    }
+}
+
+}  // namespace tmpc

@@ -29,6 +29,16 @@ const KernelEntry *find_quad_kernel(int nx, int nu, int N, int group) {
     return nullptr;
 }
 
+const KernelEntry *mfma_entry_12_4_30();
+
+// matrix-core kernels (admm_mfma.hip.h): one-shot solves of the shapes instantiated
+const KernelEntry *find_mfma_kernel(int nx, int nu, int N) {
+    static const KernelEntry *const table[] = {mfma_entry_12_4_30()};
+    for (const KernelEntry *e : table)
+        if (e->nx == nx && e->nu == nu && e->N == N) return e;
+    return nullptr;
+}
+
 // Lanes per instance for a batch size.  Fewer lanes per instance means fewer cross-lane moves and no redundant
 // work, but also fewer wavefronts.  A launch with at most one wavefront per SIMD takes about the same time
 // whatever the batch (the instances' serial chains run side by side), so one lane per instance wins as soon as four

@@ -1,0 +1,95 @@
+// Host-side pack builders + launcher for one (nx, nu, N) instantiation of the matrix-core kernel (admm_mfma.hip.h).
+#pragma once
+#include <cstring>
+#include <limits>
+
+#include "admm_mfma.hip.h"
+#include "solver.h"
+
+namespace tmpc {
+
+// operand doubles of every lane: [field][64]; lane l supplies row l % 16, K-column l / 16 of each 16 x 4 operand
+template <int NX, int NU, int N>
+void build_mfma_coef(const Solver &sv, std::vector<unsigned char> &out) {
+    using S = MfmaShape<NX, NU, N>;
+    out.assign((size_t)S::NF * 64 * sizeof(double), 0);
+    double *o = reinterpret_cast<double *>(out.data());
+    const Cache &c = sv.cache;
+    for (int l = 0; l < 64; ++l) {
+        const int i = l % 16, kq = l / 16;          // result row (= 4 v + g), K-column within a slice
+        const bool xrow = i < NX;                   // rows 0..11: state rows
+        const int a = i - 12;                       // rows 12..15: input rows
+        const bool urow = a >= 0 && a < NU;
+        for (int s = 0; s < S::VX; ++s) {
+            const int col = 4 * s + kq;             // state index the slice's column stands for
+            double mf = 0.0, mb = 0.0, pt = 0.0;
+            if (col < NX) {
+                if (xrow) {
+                    mf = sv.A(i, col);
+                    mb = c.AmBKt(i, col);
+                    pt = c.Pinf(col, i);            // (Pinf^T)[i][col]
+                } else if (urow) {
+                    mf = -c.Kinf(a, col);           // u = -d - Kinf x
+                    mb = sv.B(col, a);              // (B^T)[a][col]
+                }
+            }
+            o[(S::O_MF + s) * 64 + l] = mf;
+            o[(S::O_MB + s) * 64 + l] = mb;
+            o[(S::O_PT + s) * 64 + l] = pt;
+        }
+        o[S::O_BF * 64 + l] = (xrow && kq < NU) ? sv.B(i, kq) : 0.0;
+        o[S::O_KT * 64 + l] = (xrow && kq < NU) ? -c.Kinf(kq, i) : 0.0;   // -(Kinf^T)[i][kq]
+        o[S::O_QI * 64 + l] = (urow && kq < NU) ? c.Quu_inv(a, kq) : 0.0;
+    }
+}
+
+template <int NX, int NU, int N>
+void build_mfma_bounds(const Solver &sv, std::vector<float> &out) {
+    using S = MfmaShape<NX, NU, N>;
+    constexpr float kInf = std::numeric_limits<float>::infinity();
+    out.assign((size_t)S::BOUNDS_LEN, 0.f);
+    for (int k = 0; k < N; ++k)
+        for (int r = 0; r < NX; ++r) {
+            out[S::B_XMIN + k * NX + r] = sv.st.en_state_bound ? (float)sv.x_min[r + (size_t)k * NX] : -kInf;
+            out[S::B_XMAX + k * NX + r] = sv.st.en_state_bound ? (float)sv.x_max[r + (size_t)k * NX] : kInf;
+        }
+    for (int k = 0; k < N - 1; ++k)
+        for (int a = 0; a < NU; ++a) {
+            out[S::B_UMIN + k * NU + a] = sv.st.en_input_bound ? (float)sv.u_min[a + (size_t)k * NU] : -kInf;
+            out[S::B_UMAX + k * NU + a] = sv.st.en_input_bound ? (float)sv.u_max[a + (size_t)k * NU] : kInf;
+        }
+    for (int r = 0; r < NX; ++r) out[S::B_QD + r] = (float)sv.cache.Qd[r];
+    for (int a = 0; a < NU; ++a) out[S::B_RD + a] = (float)sv.cache.Rd[a];
+}
+
+template <int NX, int NU, int N, bool XB>
+hipError_t launch_mfma_xb(const AdmmParams &P, hipStream_t stream) {
+    const int grid = (P.batch + 63) / 64;
+    switch (P.ref_mode) {
+        case REF_ZERO:
+            hipLaunchKernelGGL((admm_mfma_kernel<NX, NU, N, REF_ZERO, XB>), dim3(grid), dim3(256), 0, stream, P);
+            break;
+        case REF_SHARED:
+            hipLaunchKernelGGL((admm_mfma_kernel<NX, NU, N, REF_SHARED, XB>), dim3(grid), dim3(256), 0, stream, P);
+            break;
+        default:
+            hipLaunchKernelGGL((admm_mfma_kernel<NX, NU, N, REF_PER_INSTANCE, XB>), dim3(grid), dim3(256), 0, stream, P);
+            break;
+    }
+    return hipGetLastError();
+}
+
+// precision is ignored: the matrix cores run the recurrences in fp64 (the kernel is only selected for precision 0)
+template <int NX, int NU, int N>
+hipError_t launch_mfma(const AdmmParams &P, int /*precision*/, bool state_bounds_active, hipStream_t stream) {
+    return state_bounds_active ? launch_mfma_xb<NX, NU, N, true>(P, stream) : launch_mfma_xb<NX, NU, N, false>(P, stream);
+}
+
+#define TMPC_DEFINE_MFMA_ENTRY(NX, NU, NN)                                                                 \
+    const KernelEntry *mfma_entry_##NX##_##NU##_##NN() {                                                   \
+        static const KernelEntry e = {NX, NU, NN, 16, "mfma<" #NX "," #NU "," #NN ">", &build_mfma_coef<NX, NU, NN>, \
+                                      &build_mfma_bounds<NX, NU, NN>, &launch_mfma<NX, NU, NN>};           \
+        return &e;                                                                                         \
+    }
+
+}  // namespace tmpc

@@ -26,6 +26,8 @@ struct KernelEntry {
 const KernelEntry *find_quad_kernel(int nx, int nu, int N, int group = -1);
 // the variant best suited to `batch` instances (nullptr: no specialised kernel for the shape)
 const KernelEntry *select_quad_kernel(int nx, int nu, int N, int batch);
+// the matrix-core kernel of the shape, for one-shot solves (nullptr: not instantiated)
+const KernelEntry *find_mfma_kernel(int nx, int nu, int N);
 // One (nx, nu) instantiation of the run-time-horizon stream kernel (admm_streamg.hip.h).
 struct StreamEntry {
     int nx, nu;

@@ -269,6 +269,9 @@ int Solver::select_kernel() {
     if (!k) k = select_quad_kernel(nx, nu, N, batch);
     if (has_fdyn || cones_active() || lin_active() || hetero) k = nullptr;  // extensions run on the stream / generic kernels
     if (std::getenv("TINYMPC_HIP_NO_QUAD")) k = nullptr;    // tuning aid: time the fallback kernels on any shape
+    // one-shot solves (cold start, workspace not kept) with fp64 recurrences: the matrix-core kernel of the shape
+    if (k && !warm_start && precision == 0 && chunk_iters == 0 && !genv && !std::getenv("TINYMPC_HIP_NO_MFMA"))
+        if (const KernelEntry *m = find_mfma_kernel(nx, nu, N)) k = m;
     if (!k && (nx > GEN_MAX_NX || nu > GEN_MAX_NU)) {
         set_error("problem shape exceeds the generic kernel limits (nx <= 64, nu <= 32)");
         return -1;
