@@ -1119,6 +1119,73 @@ def test_chunked_solve_with_compaction_is_the_same_solve(hip_lib, oracle_built, 
     assert same.mean() >= 0.97 and nrel_batch(c[1]["controls"], ref["u"])[same].max() <= FP32_TOL
 
 
+@pytest.mark.parametrize("case", ["quadrotor30_fixed", "quadrotor30_tol", "quadrotor20_tol", "quadrotor30_refs_bounds",
+                                  "quadrotor20_per_instance_refs"])
+def test_matrix_core_kernel_vs_oracle(hip_lib, oracle_built, monkeypatch, case):
+    """One-shot solves (cold start, workspace not kept) of the shapes that have a matrix-core instantiation run on it:
+    fixed iterations and tolerance-terminated (an instance's solution is captured at the iteration it converges),
+    finite state bounds, shared and per-instance references, ragged batches — against the oracle."""
+    rng = np.random.default_rng(5)
+    xref = uref = None
+    N = 30 if "30" in case else 20
+    prob, B = t.problems.quadrotor(N), 171
+    x0 = t.problems.quadrotor_x0(B, seed=4)
+    if "bounds" in case:                                  # finite per-knot state bounds that bind + a shared reference
+        prob.x_min, prob.x_max = np.full((12, N), -0.12), np.full((12, N), 0.12)
+        prob.x_min[:, N // 2:] = -0.2
+        xref, uref = 0.05 * rng.standard_normal((12, N)), 0.02 * rng.standard_normal((4, N - 1))
+    if "per_instance" in case:
+        xref, uref = 0.05 * rng.standard_normal((12, N, B)), 0.02 * rng.standard_normal((4, N - 1, B))
+    kw = (dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=60, check_termination=1) if "fixed" in case else
+          dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=3 if "20" in case else 1))
+    if "refs" in case:
+        kw = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=60, check_termination=1)
+    ref = _oracle_batch(oracle_built, prob, x0, xref=xref, uref=uref, **kw)
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+    bs.update_settings(**kw)
+    bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    bs.set_warm_start(False)
+    if xref is not None:
+        bs.set_x_ref(xref)
+        bs.set_u_ref(uref)
+    bs.set_x0(x0)
+    status = bs.solve()
+    assert bs.kernel_name == f"mfma<{prob.nx},{prob.nu},{N}>"
+    sol, st = bs.get_solution(), bs.get_status()
+    same = st["iter"] == ref["iter"]
+    assert same.mean() >= 0.97 and np.all(np.abs(st["iter"] - ref["iter"]) <= kw["check_termination"])
+    assert np.array_equal(st["solved"][same], ref["solved"][same]) and status == int(np.any(st["solved"] == 0))
+    # the synthetic tight state bounds make that case ill-conditioned (the fp32 CPU loop is off by 2e-4 on it): 5e-5 there
+    tol = 5e-5 if "bounds" in case else FP32_TOL
+    assert nrel_batch(sol["states"], ref["x"])[same].max() <= tol
+    assert nrel_batch(sol["controls"], ref["u"])[same].max() <= tol
+    assert np.abs(st["residuals"][same] - ref["res"][same]).max() <= 1e-4 * max(1.0, np.abs(ref["res"]).max())
+    # and the quad kernel, forced onto the same one-shot solve, agrees with it far inside that tolerance
+    monkeypatch.setenv("TINYMPC_HIP_NO_MFMA", "1")
+    bq = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+    bq.update_settings(**kw)
+    bq.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    bq.set_warm_start(False)
+    if xref is not None:
+        bq.set_x_ref(xref)
+        bq.set_u_ref(uref)
+    bq.set_x0(x0)
+    bq.solve()
+    assert bq.kernel_name.startswith("quad<")
+    sq, stq = bq.get_solution(), bq.get_status()
+    assert np.array_equal(stq["iter"], st["iter"])
+    assert nrel_batch(sq["states"], sol["states"]).max() <= 2e-6 and nrel_batch(sq["controls"], sol["controls"]).max() <= 2e-6
+    bq.close()
+    monkeypatch.delenv("TINYMPC_HIP_NO_MFMA")
+    if "tol" in case:
+        assert len(set(st["iter"].tolist())) > 2 or np.all(st["solved"] == 0)   # instances stop at different iterations
+    # warm-started / workspace-keeping solves stay on the quad kernel
+    bs.set_warm_start(True)
+    bs.solve()
+    assert bs.kernel_name.startswith("quad<")
+    bs.close()
+
+
 def test_kernel_selection_by_batch(hip_lib):
     """Lanes per instance follow the batch size; shapes outside the unrolled table use the stream kernel."""
     prob = t.problems.cartpole(20, u_bound=0.5)
