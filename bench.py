@@ -29,6 +29,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector
+FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD MI355X spec: dense fp64 matrix (= fp64 vector) rate
 
 
 def parse():
@@ -133,6 +134,17 @@ def measured_valu_issue(family, batch, kernel):
         e = json.load(open(path))
         if (e.get("kernel"), e.get("batch")) == (kernel, batch):
             return e.get("derived_valu_issue_utilisation")
+    return None
+
+
+def measured_mfma_issue(family, batch, kernel):
+    """Fraction of the matrix cores' issue cycles the kernel used (committed rocprofv3 pass: SQ_INSTS_MFMA x 64 cycles
+    over busy cycles x 1 024 SIMDs); None if not measured."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{family}_sq_counters.json"))):
+        e = json.load(open(path))
+        if (e.get("kernel"), e.get("batch")) == (kernel, batch):
+            return e.get("derived_mfma_issue_utilisation")
     return None
 
 
@@ -294,6 +306,14 @@ def main():
                      "frac": ach_tf / FP32_PEAK_TFLOPS, "algorithmic_flops_per_launch": alg_flops,
                      "issue_utilisation": measured_valu_issue(args.config, batch, bs.kernel_name) if args.precision == 0 else None},
         }
+        if bs.kernel_name.startswith("mfma"):
+            # matrix-core kernel: its roofline is the dense fp64 MFMA rate (AMD MI355X spec 78.6 TFLOP/s = half the F32
+            # MFMA rate of MI355X_MICROARCH.md's table, i.e. 32 FLOP/clk/SIMD; the guide has no fp64 row of its own)
+            out["roofline"].update({"bound": "mfma", "achieved": ach_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": ach_tf / FP64_MFMA_PEAK_TFLOPS,
+                                    "issue_utilisation": measured_mfma_issue(args.config, batch, bs.kernel_name),
+                                    "note": "algorithmic FLOPs (SURVEY 8d) over the fp64 matrix-core peak; tiles are "
+                                            "padded, so the issued MFMA FLOPs are higher (DESIGN.md, mfma kernel)"})
         if bs.kernel_name.startswith("stream"):
             # the state lives in HBM by design on this kernel: its roofline is that stream, not the I/O bytes
             bounded = bool((np.asarray(prob.x_min) > -1e17).any() or (np.asarray(prob.x_max) < 1e17).any())

@@ -38,6 +38,9 @@ for cfg in ("cartpole", "quadrotor", "rocket_soc"):
             busy = sq["SQ_BUSY_CYCLES"] / 32.0
             sq["derived_valu_issue_utilisation"] = sq["SQ_INSTS_VALU"] * 4.0 / (busy * 1024.0)
             sq["derived_note"] = "SQ_INSTS_VALU x 4 cycles / (kernel busy cycles x 1024 SIMDs)"
+        if "SQ_INSTS_MFMA" in sq and "SQ_BUSY_CYCLES" in sq:
+            # v_mfma_f64_16x16x4f64: 2 048 FLOP at 32 FLOP/clk/SIMD = 64 cycles of the SIMD's matrix core each
+            sq["derived_mfma_issue_utilisation"] = sq["SQ_INSTS_MFMA"] * 64.0 / (sq["SQ_BUSY_CYCLES"] / 32.0 * 1024.0)
     log = open(f"{root}/gpurun_out/prof_{tag}_{cfg}.log").read()
     line = [l for l in log.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)

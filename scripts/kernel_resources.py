@@ -2,7 +2,8 @@
 import glob, os, re, subprocess, sys
 from concurrent.futures import ThreadPoolExecutor
 here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tinympc-julia_amd", "csrc")
-srcs = sorted(glob.glob(os.path.join(here, "inst_*.hip"))) + [os.path.join(here, "kernels.hip")]
+srcs = (sorted(glob.glob(os.path.join(here, "inst_*.hip"))) + sorted(glob.glob(os.path.join(here, "minst_*.hip"))) +
+        [os.path.join(here, "sinst_g4_3.hip"), os.path.join(here, "kernels.hip")])  # + the stream kernels of the (6, x) shapes
 def run(src):
     out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-honor-nans",
                           "--cuda-device-only", "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"],
