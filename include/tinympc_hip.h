@@ -55,8 +55,9 @@ int get_states(double *states_buffer, int *rows, int *cols);
 int get_controls(double *controls_buffer, int *rows, int *cols);
 /* replaces bindings.cpp:205-208 */
 void cleanup_solver(void);
-/* replaces bindings.cpp:336-376.  en_*_linear and adaptive_rho must be 0 (non-zero returns -1);
- * en_*_soc switch the cone sets given to set_cone_constraints on and off (parity unpinned).  check_termination <= 0 means "never check"
+/* replaces bindings.cpp:336-376.  en_*_soc / en_*_linear switch the sets given to set_cone_constraints /
+ * set_linear_constraints on and off (parity unpinned).  adaptive_rho != 0 turns on the per-instance rho adaptation of
+ * admm.cpp:147-174 (see tinympc_set_adaptive_rho; runs on the generic kernel).  check_termination <= 0 means "never check"
  * (the reference divides by it, admm.cpp:91). */
 int update_settings(double abs_pri_tol, double abs_dua_tol, int max_iter, int check_termination,
                     int en_state_bound, int en_input_bound, int en_state_soc, int en_input_soc,
@@ -74,6 +75,14 @@ int set_cache_terms(double *Kinf_data, int Kinf_rows, int Kinf_cols, double *Pin
                     int Pinf_rows, int Pinf_cols, double *Quu_inv_data, int Quu_inv_rows,
                     int Quu_inv_cols, double *AmBKt_data, int AmBKt_rows, int AmBKt_cols,
                     int verbose);
+/* The sensitivities the reference takes through codegen_with_sensitivity (bindings.cpp:298-334; TinyMPC.jl:374-394) for
+ * its generated solver, here for the live one: dK (nu x nx), dP (nx x nx); dC1 / dC2 may be NULL (see
+ * tinympc_set_sensitivity).  Optional: update_settings(adaptive_rho = 1) without it computes them on first use. */
+int set_sensitivity(double *dK_data, int dK_rows, int dK_cols, double *dP_data, int dP_rows, int dP_cols,
+                    double *dC1_data, int dC1_rows, int dC1_cols, double *dC2_data, int dC2_rows, int dC2_cols,
+                    int verbose);
+/* rho of every instance after adaptation (the reference's solver->cache->rho, one per instance); *count = batch */
+int get_adaptive_rho(double *rho_buffer, int *count);
 /* replaces bindings.cpp:228-259 */
 int print_problem_data(int verbose);
 /* replace bindings.cpp:413-490.  set_linear_constraints: Alin_x x <= blin_x and Alin_u u <= blin_u at every knot
@@ -138,6 +147,24 @@ int tinympc_set_linear_constraints(tinympc_solver *s, const double *Alin_x, int 
 int tinympc_enable_linear(tinympc_solver *s, int en_state_linear, int en_input_linear);
 int tinympc_get_cache_terms(tinympc_solver *s, double *Kinf, double *Pinf, double *Quu_inv,
                             double *AmBKt);
+/* Adaptive rho — admm.cpp:147-174 + rho_benchmark.cpp, per instance: every 5th ADMM iteration each instance predicts
+ * a new rho from its normalised residuals (clipped to [rho_min, rho_max] if enable_clipping) and moves ITS Kinf, Pinf
+ * by delta_rho * sensitivity.  The adapted (rho, Kinf, Pinf) are solver state and persist between solves, as the
+ * reference's mutated cache does; tinympc_reset / set_cache_terms / toggling the switch return them to the family's
+ * cache.  Settings: bindings.cpp:360-364.  Not available on per-instance-family solvers or in mpc_rollout. */
+int tinympc_set_adaptive_rho(tinympc_solver *s, int enable, double rho_min, double rho_max, int enable_clipping);
+/* dKinf/drho (nu x nx) and dPinf/drho (nx x nx), column-major — what codegen_with_sensitivity receives
+ * (bindings.cpp:298-334) and tiny_setup hard-codes for the 12x4 quadrotor (tiny_api.cpp:269-329).  dC1 / dC2 may be
+ * NULL: the reference applies them to copies the iteration never reads.  If never set, the first adaptive solve
+ * computes them as TinyMPC.jl:301-352 does (tinympc_compute_sensitivity). */
+int tinympc_set_sensitivity(tinympc_solver *s, const double *dKinf, const double *dPinf, const double *dC1,
+                            const double *dC2);
+/* Host-side finite differences (h = 1e-6) of the rho-regularised LQR — TinyMPC.jl:301-352
+ * (compute_sensitivity_autograd / solve_lqr).  Any output may be NULL. */
+int tinympc_compute_sensitivity(tinympc_solver *s, double *dKinf, double *dPinf, double *dC1, double *dC2);
+/* Per-instance adapted values: rho [batch], Kinf [batch][nu*nx], Pinf [batch][nx*nx] (column-major each); any may be
+ * NULL.  Before any adaptive solve: the family's values. */
+int tinympc_get_adaptive_state(tinympc_solver *s, double *rho, double *Kinf, double *Pinf);
 int tinympc_set_x0(tinympc_solver *s, const double *x0, int cols);       /* cols: 1 | batch */
 int tinympc_set_x_ref(tinympc_solver *s, const double *x_ref, int cols); /* cols: N | N*batch */
 int tinympc_set_u_ref(tinympc_solver *s, const double *u_ref, int cols); /* N-1 | (N-1)*batch */
@@ -210,6 +237,9 @@ const char *tinympc_last_error(void);
 int tinympc_host_precompute(const double *A, const double *B, const double *Q, const double *R,
                             double rho, int nx, int nu, double *Kinf, double *Pinf,
                             double *Quu_inv, double *AmBKt);
+/* Host-only (no GPU): the sensitivities tinympc_compute_sensitivity returns, for a family given directly. */
+int tinympc_host_sensitivity(const double *A, const double *B, const double *Q, const double *R, double rho, int nx,
+                             int nu, double *dKinf, double *dPinf, double *dC1, double *dC2);
 
 #ifdef __cplusplus
 }

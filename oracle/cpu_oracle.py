@@ -16,6 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PORT_LIB = os.path.join(_HERE, "libtinympc_oracle.so")
 REF_LIB = os.path.join(_HERE, "_ref", "libtinympc_ref.so")
+REF_ADAPT_LIB = os.path.join(_HERE, "_ref", "libtinympc_ref_adapt.so")
 
 _c_dp = ctypes.POINTER(ctypes.c_double)
 _c_ip = ctypes.POINTER(ctypes.c_int)
@@ -45,7 +46,7 @@ _libs = {}
 
 
 def _load(kind):
-    path = REF_LIB if kind == "ref" else PORT_LIB
+    path = REF_LIB if kind == "ref" else (REF_ADAPT_LIB if kind == "refa" else PORT_LIB)
     if path not in _libs:
         if not os.path.isfile(path):
             raise FileNotFoundError(f"{path} not built (run oracle.cpu_oracle.build())")
@@ -57,9 +58,12 @@ class CpuSolver:
     """One CPU solver instance (single problem), same call sequence as the reference's API."""
 
     def __init__(self, kind, A, B, Q, R, rho, N):
-        assert kind in ("orc64", "orc32", "ref")
-        self.kind = kind
+        assert kind in ("orc64", "orc32", "ref", "refa")
         self.lib = _load(kind)
+        # "refa": the same snapshot and driver built with automatic variables zero-initialised, the only way the
+        # snapshot's adaptive-rho branch is defined behaviour (see oracle/Makefile)
+        kind = "ref" if kind == "refa" else kind
+        self.kind = kind
         self.p = kind + "_"
         self.nx, self.nu, self.N = A.shape[0], B.shape[1], N
         fn = getattr(self.lib, self.p + "create")
@@ -133,6 +137,31 @@ class CpuSolver:
     def set_cache_terms(self, Kinf, Pinf, Quu_inv, AmBKt):
         a = [_f(m) for m in (Kinf, Pinf, Quu_inv, AmBKt)]
         self._call("set_cache_terms", *[_dp(m) for m in a])
+
+    def set_adaptive_rho(self, enable, rho_min=0.1, rho_max=10.0, clip=True):
+        """admm.cpp:147-174; the defaults are TinyMPC.jl:59-61's"""
+        self._call("set_adaptive_rho", int(bool(enable)), ctypes.c_double(rho_min), ctypes.c_double(rho_max),
+                   int(bool(clip)))
+
+    def set_sensitivity(self, dK, dP):
+        a = [_f(m) for m in (dK, dP)]
+        self._call("set_sensitivity", _dp(a[0]), _dp(a[1]))
+
+    def get_builtin_sensitivity(self):
+        """compiled reference only: the tables tiny_setup hard-codes (tiny_api.cpp:279-329), 12x4 problems only"""
+        assert self.kind == "ref"
+        dK = np.zeros((self.nu, self.nx), order="F")
+        dP = np.zeros((self.nx, self.nx), order="F")
+        if self._call("get_sensitivity", _dp(dK), _dp(dP)) != 0:
+            raise ValueError("the built-in tables are 4x12 / 12x12")
+        return dK, dP
+
+    def get_adapted(self):
+        rho = ctypes.c_double()
+        K = np.zeros((self.nu, self.nx), order="F")
+        P = np.zeros((self.nx, self.nx), order="F")
+        self._call("get_adapted", ctypes.byref(rho), _dp(K), _dp(P))
+        return dict(rho=rho.value, Kinf=K, Pinf=P)
 
     def reset(self):
         self._call("reset")

@@ -132,7 +132,53 @@ def case_trace(name, prob, x0, iters, note=""):
     return dict(case=name, note=note, problem=_prob_dict(prob), x0=_l(x0), trace=tr)
 
 
+def _fd_sensitivity(prob, h=1e-6):
+    """Sensitivities handed to the reference as INPUT for the cartpole case: forward differences of the
+    rho-regularised LQR gains, the recipe of TinyMPC.jl:301-352 in numpy."""
+    def lqr(rho):
+        nx, nu = prob.nx, prob.nu
+        Qr, Rr = prob.Q + rho * np.eye(nx), prob.R + rho * np.eye(nu)
+        Pm, K = Qr.copy(), np.zeros((nu, nx))
+        for it in range(1, 5001):
+            Kp = K
+            K = np.linalg.solve(Rr + prob.B.T @ Pm @ prob.B + 1e-8 * np.eye(nu), prob.B.T @ Pm @ prob.A)
+            Pm = Qr + prob.A.T @ Pm @ (prob.A - prob.B @ K)
+            if it > 1 and np.linalg.norm(K - Kp) < 1e-10:
+                break
+        return K, Pm
+    (K0, P0), (K1, P1) = lqr(prob.rho), lqr(prob.rho + h)
+    return (K1 - K0) / h, (P1 - P0) / h
+
+
+def case_adaptive(name, prob, x0s, settings, adaptive, sens=None, solves=2, note=""):
+    """Adaptive rho (admm.cpp:147-174): per instance, `solves` consecutive solves of one solver (the adapted
+    cache persists, the workspace warm-starts).  Runs on the zero-initialised build of the snapshot ("refa",
+    oracle/Makefile).  sens=None: the tables tiny_setup hard-codes (12x4 only), stored as inputs."""
+    inst = []
+    for b in range(x0s.shape[1]):
+        s = CpuSolver("refa", prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N)
+        s.update_settings(**settings)
+        if prob.has_bounds():
+            s.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        if sens is None:
+            sens = s.get_builtin_sensitivity()
+        s.set_sensitivity(*sens)
+        s.set_adaptive_rho(1, adaptive["rho_min"], adaptive["rho_max"], adaptive["clip"])
+        s.set_x0(x0s[:, b])
+        seq = []
+        for _ in range(solves):
+            st = s.solve()
+            o = _sol(s, st)
+            a = s.get_adapted()
+            o.update(rho=a["rho"], Kinf=_l(a["Kinf"]), Pinf=_l(a["Pinf"]))
+            seq.append(o)
+        inst.append(seq)
+    return dict(case=name, note=note, problem=_prob_dict(prob), settings=settings, adaptive=adaptive,
+                dKinf_drho=_l(sens[0]), dPinf_drho=_l(sens[1]), x0=_l(x0s), batch=int(x0s.shape[1]), expect=inst)
+
+
 def main():
+    only = sys.argv[1] if len(sys.argv) > 1 else ""
     build(port=False, ref=True)
     os.makedirs(OUT, exist_ok=True)
     fixed100 = dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=100, check_termination=1)
@@ -201,7 +247,23 @@ def main():
     cases.append(case_trace("G8a_cartpole_trace", P.cartpole(20, u_bound=0.5), [0.5, 0, 0, 0], 100))
     cases.append(case_trace("G8b_quadrotor_trace", P.quadrotor(30), P.quadrotor_x0(1, seed=1)[:, 0], 60))
 
+    # G9: adaptive rho
+    ad = dict(rho_min=0.1, rho_max=10.0, clip=True)
+    cases.append(case_adaptive("G9a_quadrotor_adaptive_fixed100", P.quadrotor(30), P.quadrotor_x0(4, seed=1), fixed100,
+                               ad, note="config 3 with adaptive_rho, the reference's built-in 12x4 tables, 2 solves"))
+    cases.append(case_adaptive("G9b_quadrotor_adaptive_tol", P.quadrotor(30), P.quadrotor_x0(4, seed=3), tol, ad,
+                               note="tolerance-terminated, per-instance iteration counts"))
+    pc9 = P.cartpole(20, u_bound=0.5)
+    cases.append(case_adaptive("G9c_cartpole_adaptive", pc9, P.cartpole_x0(4, seed=0), fixed100,
+                               dict(rho_min=0.5, rho_max=4.0, clip=True), sens=_fd_sensitivity(pc9),
+                               note="config 2 with adaptive_rho, finite-difference sensitivities as input"))
+    cases.append(case_adaptive("G9d_cartpole_adaptive_noclip", pc9, P.cartpole_x0(2, seed=5), fixed100,
+                               dict(rho_min=0.5, rho_max=4.0, clip=False), sens=_fd_sensitivity(pc9), solves=1,
+                               note="clipping off"))
+
     for c in cases:
+        if only and not c["case"].startswith(only):
+            continue
         path = os.path.join(OUT, c["case"] + ".json")
         with open(path, "w") as f:
             json.dump(c, f, allow_nan=True)

@@ -192,6 +192,40 @@ void ref_set_cache_terms(void *hp, const double *Kinf, const double *Pinf, const
     h->s->cache->AmBKt = map_cm(AmBKt, h->nx, h->nx);
 }
 
+// Adaptive rho (admm.cpp:147-174, rho_benchmark.cpp): the settings update_settings would push
+// (bindings.cpp:360-364) and the public cache fields the Taylor update reads and writes (types.hpp:51-55).
+void ref_set_adaptive_rho(void *hp, int enable, double rho_min, double rho_max, int clip) {
+    RefSolver *h = static_cast<RefSolver *>(hp);
+    h->s->settings->adaptive_rho = enable;
+    h->s->settings->adaptive_rho_min = rho_min;
+    h->s->settings->adaptive_rho_max = rho_max;
+    h->s->settings->adaptive_rho_enable_clipping = clip;
+}
+// What tiny_setup left in the cache (its built-in tables, whatever the problem is); meaningful for nx=12, nu=4 only.
+int ref_get_sensitivity(void *hp, double *dK, double *dP) {
+    RefSolver *h = static_cast<RefSolver *>(hp);
+    const TinyCache *c = h->s->cache;
+    if (c->dKinf_drho.rows() != h->nu || c->dKinf_drho.cols() != h->nx || c->dPinf_drho.rows() != h->nx) return 1;
+    std::memcpy(dK, c->dKinf_drho.data(), sizeof(double) * h->nu * h->nx);
+    std::memcpy(dP, c->dPinf_drho.data(), sizeof(double) * h->nx * h->nx);
+    return 0;
+}
+// Caller-supplied sensitivities; dC1/dC2 are sized and zeroed (they only reach the dead C1/C2 copies).
+void ref_set_sensitivity(void *hp, const double *dK, const double *dP) {
+    RefSolver *h = static_cast<RefSolver *>(hp);
+    h->s->cache->dKinf_drho = map_cm(dK, h->nu, h->nx);
+    h->s->cache->dPinf_drho = map_cm(dP, h->nx, h->nx);
+    h->s->cache->dC1_drho = tinyMatrix::Zero(h->nu, h->nu);
+    h->s->cache->dC2_drho = tinyMatrix::Zero(h->nx, h->nx);
+}
+void ref_get_adapted(void *hp, double *rho, double *Kinf, double *Pinf) {
+    RefSolver *h = static_cast<RefSolver *>(hp);
+    const TinyCache *c = h->s->cache;
+    if (rho) *rho = c->rho;
+    if (Kinf) std::memcpy(Kinf, c->Kinf.data(), sizeof(double) * h->nu * h->nx);
+    if (Pinf) std::memcpy(Pinf, c->Pinf.data(), sizeof(double) * h->nx * h->nx);
+}
+
 // Warm-start state of the workspace (what persists between solves).
 void ref_get_state(void *hp, double *d, double *y, double *g, double *v, double *z) {
     RefSolver *h = static_cast<RefSolver *>(hp);

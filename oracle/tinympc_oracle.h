@@ -43,6 +43,9 @@ extern "C" {
                                      const double *b, int m);                                 \
     void P##set_cache_terms(void *h, const double *Kinf, const double *Pinf,                  \
                             const double *Quu_inv, const double *AmBKt);                      \
+    void P##set_adaptive_rho(void *h, int enable, double rho_min, double rho_max, int clip);   \
+    void P##set_sensitivity(void *h, const double *dKinf_drho, const double *dPinf_drho);     \
+    void P##get_adapted(void *h, double *rho, double *Kinf, double *Pinf);                    \
     void P##reset(void *h);                                                                    \
     int P##solve(void *h);                                                                     \
     void P##get_solution(void *h, double *x, double *u, int *iter, int *solved, double *res4); \

@@ -1259,3 +1259,115 @@ def test_per_instance_families_vs_oracle(hip_lib, oracle_built):
     with pytest.raises(t.TinyMPCError):
         bh.set_cache_terms(*[b1.get_cache_terms()[k] for k in ("Kinf", "Pinf", "Quu_inv", "AmBKt")])
     bh.close(); b1.close()
+
+
+ADAPTIVE = ["G9a_quadrotor_adaptive_fixed100", "G9b_quadrotor_adaptive_tol", "G9c_cartpole_adaptive",
+            "G9d_cartpole_adaptive_noclip"]
+
+
+@pytest.mark.parametrize("name", ADAPTIVE)
+def test_adaptive_rho_vs_reference_golden(hip_lib, name):
+    """adaptive rho (admm.cpp:147-174, rho_benchmark.cpp) per instance on the generic kernel against
+    outputs of the compiled reference: consecutive solves of one solver (workspace warm-starts, adapted cache
+    persists), built-in 12x4 tables on the quadrotor, finite-difference sensitivities on the cartpole, clipping on and
+    off.  Same iteration counts, rho path within 1e-5 relative, adapted Kinf / Pinf and the solution within the fp32
+    tolerance."""
+    g = load_golden(name)
+    prob = problem_of(g)
+    B = g["batch"]
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+    bs.update_settings(**g["settings"])
+    if prob.has_bounds():
+        bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    bs.set_sensitivity(cm(g["dKinf_drho"], prob.nu, prob.nx), cm(g["dPinf_drho"], prob.nx, prob.nx))
+    a = g["adaptive"]
+    bs.set_adaptive_rho(True, a["rho_min"], a["rho_max"], a["clip"])
+    bs.set_x0(cm(g["x0"], prob.nx, B))
+    for k in range(len(g["expect"][0])):
+        status = bs.solve()
+        assert bs.kernel_name == "generic"
+        sol, st, ad = bs.get_solution(), bs.get_status(), bs.get_adaptive_state()
+        assert status == max(e[k]["status"] for e in g["expect"])
+        for b in range(B):
+            e = g["expect"][b][k]
+            assert (int(st["iter"][b]), int(st["solved"][b])) == (e["iter"], e["solved"])
+            _check_instance(sol["states"][:, :, b], sol["controls"][:, :, b], e, prob.nx, prob.nu, prob.N)
+            assert abs(ad["rho"][b] - e["rho"]) <= 1e-5 * e["rho"]
+            assert nrel(ad["Kinf"][:, :, b], cm(e["Kinf"], prob.nu, prob.nx)) <= FP32_TOL
+            assert nrel(ad["Pinf"][:, :, b], cm(e["Pinf"], prob.nx, prob.nx)) <= FP32_TOL
+
+
+def test_adaptive_rho_through_dropin_api(hip_lib, oracle_built):
+    """setup(..., adaptive_rho=true) as TinyMPC.jl:55-112 pushes it, sensitivities left to the library (computed on
+    first use as TinyMPC.jl:301-352 would), a seeded batch against the fp64 restatement fed the same sensitivities;
+    reset_workspace() returns every instance to the family's rho; switching it off again is the plain solve."""
+    prob = t.problems.cartpole(20, u_bound=0.5)
+    B = 64
+    x0 = t.problems.cartpole_x0(B, seed=21)
+    s = t.TinyMPCSolver()
+    t.setup(s, prob.A, prob.B, np.zeros(4), prob.Q, prob.R, prob.rho, 4, 1, 20, batch=B, abs_pri_tol=0.0,
+            abs_dua_tol=0.0, max_iter=60, adaptive_rho=True, adaptive_rho_min=0.3, adaptive_rho_max=3.0)
+    t.update_settings(s, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=60, adaptive_rho=True, adaptive_rho_min=0.3,
+                      adaptive_rho_max=3.0)
+    t.set_bound_constraints(s, prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    t.set_x0(s, x0)
+    t.solve(s)
+    sol = t.get_solution(s)
+    dK, dP, _, _ = t.host_sensitivity(prob.A, prob.B, prob.Q, prob.R, prob.rho)
+    want = t.compute_sensitivity_autograd(s)
+    assert np.abs(want[0] - dK).max() <= 2e-3 * np.abs(dK).max()
+    moved = 0
+    for b in range(B):
+        o = oracle_built.CpuSolver("orc64", prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N)
+        o.update_settings(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=60, check_termination=1)
+        o.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        o.set_sensitivity(dK, dP)
+        o.set_adaptive_rho(1, 0.3, 3.0, True)
+        o.set_x0(x0[:, b])
+        o.solve()
+        r = o.get_solution()
+        assert nrel(sol["states"][:, :, b], r["x"]) <= FP32_TOL and nrel(sol["controls"][:, :, b], r["u"]) <= FP32_TOL
+        moved += abs(o.get_adapted()["rho"] - prob.rho) > 1e-3
+    assert moved >= B // 2  # the case does adapt
+    # plain solve after switching off + reset: identical to a solver that never adapted
+    t.update_settings(s, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=60, en_state_bound=True, en_input_bound=True)
+    t.reset_workspace(s)
+    t.solve(s)
+    plain = t.get_solution(s)
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+    bs.update_settings(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=60)
+    bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    bs.set_x0(x0)
+    bs.solve()
+    assert nrel_batch(plain["states"], bs.get_solution()["states"]).max() <= 2e-6
+    t.cleanup()
+
+
+def test_adaptive_rho_state_and_errors(hip_lib):
+    """The adapted (rho, Kinf, Pinf) are solver state: reported per instance, reset by reset() and set_cache_terms();
+    per-instance-family solvers and the fused rollout refuse adaptive rho."""
+    prob = t.problems.quadrotor(30)
+    B = 8
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+    bs.update_settings(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=30)
+    bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    c = bs.get_cache_terms()
+    ad = bs.get_adaptive_state()
+    assert np.all(ad["rho"] == prob.rho) and np.all(ad["Kinf"] == c["Kinf"][:, :, None])
+    bs.set_adaptive_rho(True, 0.1, 10.0, True)
+    bs.set_x0(t.problems.quadrotor_x0(B, seed=4))
+    bs.solve()
+    ad = bs.get_adaptive_state()
+    assert np.all(ad["rho"] != prob.rho) and np.all((ad["rho"] >= 0.1 - 1e-7) & (ad["rho"] <= 10.0))
+    # Kinf moved by exactly delta_rho * dK (first-order update, rho_benchmark.cpp:197-213)
+    dK = bs.compute_sensitivity()[0]
+    assert np.abs(ad["Kinf"] - (c["Kinf"][:, :, None] + (ad["rho"] - prob.rho)[None, None, :] * dK[:, :, None])).max() <= 1e-9
+    with pytest.raises(t.TinyMPCError):
+        bs.mpc_rollout(2)
+    bs.reset()
+    assert np.all(bs.get_adaptive_state()["rho"] == prob.rho)
+    bs.solve()
+    bs.set_cache_terms(c["Kinf"], c["Pinf"], c["Quu_inv"], c["AmBKt"])
+    assert np.all(bs.get_adaptive_state()["rho"] == prob.rho)
+    with pytest.raises(t.TinyMPCError):
+        bs.set_adaptive_rho(True, 2.0, 1.0, True)

@@ -155,3 +155,88 @@ def test_live_reference_when_present(oracle_built):
         assert np.array_equal(a["iter"], b["iter"]) and np.array_equal(a["solved"], b["solved"])
         assert np.abs(a["x"] - b["x"]).max() <= 1e-11 and np.abs(a["u"] - b["u"]).max() <= 1e-11
     del rng
+
+
+ADAPTIVE = [n for n in golden_names() if n.startswith("G9")]
+
+
+def _adaptive_solver(oracle, kind, g):
+    prob = problem_of(g)
+    s, _ = _mk(oracle, kind, g, prob)
+    s.set_sensitivity(cm(g["dKinf_drho"], prob.nu, prob.nx), cm(g["dPinf_drho"], prob.nx, prob.nx))
+    a = g["adaptive"]
+    s.set_adaptive_rho(1, a["rho_min"], a["rho_max"], a["clip"])
+    return s, prob
+
+
+def test_adaptive_inventory():
+    """adaptive rho is pinned by reference outputs too (G9a-d)."""
+    assert len(ADAPTIVE) == 4
+
+
+@pytest.mark.parametrize("name", ADAPTIVE)
+def test_orc64_adaptive_rho(oracle_built, name):
+    """admm.cpp:147-174 + rho_benchmark.cpp restated without the sparse matrices: same rho path, same adapted
+    Kinf / Pinf, same solution as the compiled reference, over consecutive solves of one solver (the adapted cache
+    persists)."""
+    g = load_golden(name)
+    prob = problem_of(g)
+    x0 = cm(g["x0"], prob.nx, g["batch"])
+    for b, seq in enumerate(g["expect"]):
+        s, _ = _adaptive_solver(oracle_built, "orc64", g)
+        s.set_x0(x0[:, b])
+        for exp in seq:
+            status = s.solve()
+            o = s.get_solution()
+            assert (status, o["iter"], o["solved"]) == (exp["status"], exp["iter"], exp["solved"])
+            _cmp(o, exp, prob, 1e-10)
+            a = s.get_adapted()
+            assert abs(a["rho"] - exp["rho"]) <= 1e-10 * exp["rho"]
+            assert nrel(a["Kinf"], cm(exp["Kinf"], prob.nu, prob.nx)) <= 1e-10
+            assert nrel(a["Pinf"], cm(exp["Pinf"], prob.nx, prob.nx)) <= 1e-10
+
+
+def test_adaptive_rho_live_reference(oracle_built):
+    """dev container only: the zero-initialised build of the snapshot re-run against the restatement on a fresh seed."""
+    import os
+    if not os.path.isfile(oracle_built.REF_ADAPT_LIB):
+        pytest.skip("compiled reference not present")
+    prob = t.problems.quadrotor(30)
+    x0 = t.problems.quadrotor_x0(3, seed=11)
+    st = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=60, check_termination=1)
+    for b in range(3):
+        out = []
+        sens = None
+        for kind in ("refa", "orc64"):
+            s = oracle_built.CpuSolver(kind, prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N)
+            s.update_settings(**st)
+            s.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+            sens = sens or s.get_builtin_sensitivity()
+            s.set_sensitivity(*sens)
+            s.set_adaptive_rho(1, 1.0, 20.0, True)
+            s.set_x0(x0[:, b])
+            s.solve()
+            o = s.get_solution()
+            o.update(s.get_adapted())
+            out.append(o)
+        assert out[0]["iter"] == out[1]["iter"]
+        assert abs(out[0]["rho"] - out[1]["rho"]) <= 1e-10 * out[0]["rho"]
+        assert nrel(out[1]["x"], out[0]["x"]) <= 1e-10 and nrel(out[1]["u"], out[0]["u"]) <= 1e-10
+
+
+def test_host_sensitivity_matches_the_recipe():
+    """The library's host finite differences (csrc/host_setup.cpp) against the numpy mirror of TinyMPC.jl:301-352
+    in tinympc.py; both difference two Riccati fixed points with h = 1e-6, so agreement is to the fixed points'
+    own 1e-10 stopping noise over h."""
+    for prob in (t.problems.cartpole(20), t.problems.quadrotor(30), t.problems.rocket(50)):
+        got = t.host_sensitivity(prob.A, prob.B, prob.Q, prob.R, prob.rho)
+        s = t.TinyMPCSolver()
+        s.A, s.B, s.Q, s.R, s.rho, s.is_setup = prob.A, prob.B, prob.Q, prob.R, prob.rho, True
+        want = t.compute_sensitivity_autograd(s)
+        for a, b in zip(got, want):
+            assert a.shape == b.shape
+            assert np.abs(a - b).max() <= 2e-3 * max(1.0, np.abs(b).max())
+        # and they are derivatives: a centred difference with a larger step agrees to first order
+        K0 = t.tinympc._solve_lqr(prob.A, prob.B, prob.Q, prob.R, prob.rho - 1e-3)[0]
+        K1 = t.tinympc._solve_lqr(prob.A, prob.B, prob.Q, prob.R, prob.rho + 1e-3)[0]
+        assert np.abs((K1 - K0) / 2e-3 - got[0]).max() <= 1e-2 * max(1e-3, np.abs(got[0]).max()) + 1e-3

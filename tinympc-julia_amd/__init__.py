@@ -37,9 +37,11 @@ from .tinympc import (  # noqa: E402,F401
     TinyMPCError,
     TinyMPCSolver,
     cleanup,
+    compute_sensitivity_autograd,
     get_solution,
     get_status,
     host_precompute,
+    host_sensitivity,
     load_library,
     print_problem_data,
     reset_workspace,
@@ -49,6 +51,8 @@ from .tinympc import (  # noqa: E402,F401
     set_cone_constraints,
     set_equality_constraints,
     set_linear_constraints,
+    set_sensitivity,
+    get_adaptive_rho,
     set_u_ref,
     set_x0,
     set_x_ref,

@@ -36,6 +36,8 @@ struct GenericPack {
 
 __device__ __forceinline__ float gfma(float a, float b, float c) { return fmaf(a, b, c); }
 __device__ __forceinline__ double gfma(double a, double b, double c) { return fma(a, b, c); }
+__device__ __forceinline__ void gupmax(float &m, float v) { m = fmaxf(m, fabsf(v)); }
+__device__ __forceinline__ void gupmax(double &m, double v) { m = fmax(m, fabs(v)); }
 
 template <class RT>
 __global__ __launch_bounds__(256) void admm_generic_kernel(const AdmmParams P) {
@@ -64,7 +66,12 @@ __global__ __launch_bounds__(256) void admm_generic_kernel(const AdmmParams P) {
     float *svl = syc + (long)EU * B, *svln = svl + (long)EX * B, *sgl = svln + (long)EX * B;
     float *szl = sgl + (long)EX * B, *szln = szl + (long)EU * B, *syl = szln + (long)EU * B;
 #define AT(arr, e) arr[(long)(e)*B]
-    const float rho = P.rho;
+    // adaptive rho: this instance's own rho, Kinf (nu x nx), Pinf (nx x nx) instead of the family's
+    const bool adaptive = P.adaptive_rho != 0;
+    double *arho = P.adapt + b, *aK = arho + B, *aP = aK + (long)nu * nx * B;
+    float rho = adaptive ? (float)arho[0] : P.rho;
+    auto Kc = [&](int a, int j) -> RT { return adaptive ? (RT)AT(aK, a + j * nu) : cK[a + j * nu]; };
+    auto Pc = [&](int r, int j) -> RT { return adaptive ? (RT)AT(aP, r + j * nx) : cP[r + j * nx]; };
     const bool warm = !P.cold_start;
     for (int e = 0; e < EX; ++e) {
         AT(sx, e) = e < nx ? P.x0[b * nx + e] : 0.f;
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(256) void admm_generic_kernel(const AdmmParams P) {
         for (int k = 0; k < N - 1; ++k) {
             for (int a = 0; a < nu; ++a) {
                 RT acc = 0;
-                for (int j = 0; j < nx; ++j) acc = gfma(cK[a + j * nu], xv[j], acc);
+                for (int j = 0; j < nx; ++j) acc = gfma(Kc(a, j), xv[j], acc);
                 uv[a] = -acc - (RT)AT(sd, k * nu + a);
                 AT(su, k * nu + a) = (float)uv[a];
             }
@@ -268,13 +275,75 @@ __global__ __launch_bounds__(256) void admm_generic_kernel(const AdmmParams P) {
         for (int r = 0; r < nx; ++r) {
             const int e = (N - 1) * nx + r;
             RT acc = 0;
-            for (int j = 0; j < nx; ++j) acc = gfma(cP[j + r * nx], (RT)xref(N - 1, j), acc);
+            for (int j = 0; j < nx; ++j) acc = gfma(Pc(j, r), (RT)xref(N - 1, j), acc);
             float tail = rho * (AT(svn, e) - AT(sg, e));
             if (soc_x) tail += rho * (AT(svcn, e) - AT(sgc, e));
             if (lin_x) tail += rho * (AT(svln, e) - AT(sgl, e));
             xn[r] = -acc - (RT)tail;  // p_{N-1}
         }
         it += 1;
+        // adaptive rho — admm.cpp:147-174 with rho_benchmark.cpp:44-213, the sparse products written out:
+        //   rows i = 0..N-2: u_i against znew_i, A x_i + B u_i (+ fdyn) - x_{i+1} against vnew_{i+1};
+        //   P = blkdiag(Q~, R~, .., Pinf), q = [Q~ x_i; R~ u_i] (zero reference), A' y with y = [y_i; g_{i+1}]
+        if (adaptive && i > 0 && i % 5 == 0) {
+            RT pri = 0, axm = 0, zm = 0, dres = 0, pxm = 0, atym = 0, qm = 0;
+            for (int k = 0; k < N - 1; ++k) {
+                for (int a = 0; a < nu; ++a) {
+                    const RT u = (RT)AT(su, k * nu + a), zn = (RT)AT(szn, k * nu + a);
+                    gupmax(pri, u - zn);
+                    gupmax(axm, u);
+                    gupmax(zm, zn);
+                }
+                for (int r = 0; r < nx; ++r) {
+                    RT acc = cF[r];
+                    for (int j = 0; j < nx; ++j) acc = gfma(cA[r + j * nx], (RT)AT(sx, k * nx + j), acc);
+                    for (int a = 0; a < nu; ++a) acc = gfma(cB[r + a * nx], (RT)AT(su, k * nu + a), acc);
+                    acc -= (RT)AT(sx, (k + 1) * nx + r);
+                    const RT vn = (RT)AT(svn, (k + 1) * nx + r);
+                    gupmax(pri, acc - vn);
+                    gupmax(axm, acc);
+                    gupmax(zm, vn);
+                }
+            }
+            for (int k = 0; k < N; ++k) {
+                for (int r = 0; r < nx; ++r) {
+                    const RT x = (RT)AT(sx, k * nx + r), qv = (RT)cQd[r] * x;
+                    RT px = qv, aty = 0;
+                    if (k == N - 1) {
+                        px = 0;
+                        for (int j = 0; j < nx; ++j) px = gfma(Pc(r, j), (RT)AT(sx, k * nx + j), px);
+                    } else {
+                        for (int j = 0; j < nx; ++j) aty = gfma(cA[j + r * nx], (RT)AT(sg, (k + 1) * nx + j), aty);
+                    }
+                    if (k >= 1) aty -= (RT)AT(sg, k * nx + r);
+                    gupmax(dres, px + qv + aty);
+                    gupmax(pxm, px);
+                    gupmax(atym, aty);
+                    gupmax(qm, qv);
+                }
+                if (k < N - 1)
+                    for (int a = 0; a < nu; ++a) {
+                        const RT px = (RT)cRd[a] * (RT)AT(su, k * nu + a);
+                        RT aty = (RT)AT(sy, k * nu + a);
+                        for (int j = 0; j < nx; ++j) aty = gfma(cB[j + a * nx], (RT)AT(sg, (k + 1) * nx + j), aty);
+                        gupmax(dres, px + px + aty);
+                        gupmax(pxm, px);
+                        gupmax(atym, aty);
+                        gupmax(qm, px);
+                    }
+            }
+            const RT eps = (RT)1e-10, prin = axm > zm ? axm : zm;
+            RT duan = pxm > atym ? pxm : atym;
+            duan = qm > duan ? qm : duan;
+            const RT ratio = (pri / (prin + eps)) / (dres / (duan + eps) + eps);  // predict_rho, rho_benchmark.cpp:173-195
+            RT nrho = (RT)arho[0] * (RT)sqrt((double)ratio);
+            if (P.rho_clip) nrho = nrho < (RT)P.rho_min ? (RT)P.rho_min : (nrho > (RT)P.rho_max ? (RT)P.rho_max : nrho);
+            const double delta = (double)nrho - arho[0];
+            for (int e = 0; e < nu * nx; ++e) AT(aK, e) += delta * P.sens[e];
+            for (int e = 0; e < nx * nx; ++e) AT(aP, e) += delta * P.sens[nu * nx + e];
+            arho[0] = (double)nrho;
+            rho = (float)nrho;
+        }
         // termination_condition — admm.cpp:89-107
         if (P.check_termination > 0 && it % P.check_termination == 0) {
             res0 = pri_x;
@@ -314,7 +383,7 @@ __global__ __launch_bounds__(256) void admm_generic_kernel(const AdmmParams P) {
             for (int r = 0; r < nx; ++r) {
                 RT ap = (RT)AT(sq, k * nx + r) + cAPf[r], kr = 0;
                 for (int j = 0; j < nx; ++j) ap = gfma(cAt[r + j * nx], xv[j], ap);
-                for (int a = 0; a < nu; ++a) kr = gfma(cK[a + r * nu], rv[a], kr);
+                for (int a = 0; a < nu; ++a) kr = gfma(Kc(a, r), rv[a], kr);
                 xn[r] = ap - kr;
             }
             for (int r = 0; r < nx; ++r) xv[r] = xn[r];

@@ -160,7 +160,57 @@ int tinympc_set_cache_terms(tinympc_solver *s, const double *Kinf, const double 
     v.cache.Quu_inv = tmpc::Mat(v.nu, v.nu, Quu_inv);
     v.cache.AmBKt = tmpc::Mat(v.nx, v.nx, AmBKt);
     v.packs_dirty = true;
+    v.adapt_dirty = true;  // adaptive rho restarts from the new cache
     return 0;
+}
+
+int tinympc_set_adaptive_rho(tinympc_solver *s, int enable, double rho_min, double rho_max, int enable_clipping) {
+    if (!s) return -1;
+    tmpc::Solver &v = s->s;
+    if (enable && v.hetero) {
+        set_error("adaptive_rho is not available on a per-instance-family solver");
+        return -1;
+    }
+    if (enable && !(rho_min > 0.0 && rho_max >= rho_min)) {
+        set_error("adaptive_rho: need 0 < rho_min <= rho_max");
+        return -1;
+    }
+    if ((enable != 0) != (v.st.adaptive_rho != 0)) v.adapt_dirty = true;
+    v.st.adaptive_rho = enable ? 1 : 0;
+    v.st.adaptive_rho_min = rho_min;
+    v.st.adaptive_rho_max = rho_max;
+    v.st.adaptive_rho_clip = enable_clipping ? 1 : 0;
+    return 0;
+}
+
+int tinympc_set_sensitivity(tinympc_solver *s, const double *dKinf, const double *dPinf, const double *dC1,
+                            const double *dC2) {
+    (void)dC1;  // accepted for the reference's call shape; they only ever reach dead copies there
+    (void)dC2;
+    if (!s || !dKinf || !dPinf) return -1;
+    return guarded("set_sensitivity", [&] { return s->s.set_sensitivity(dKinf, dPinf); });
+}
+
+int tinympc_compute_sensitivity(tinympc_solver *s, double *dKinf, double *dPinf, double *dC1, double *dC2) {
+    if (!s) return -1;
+    return guarded("compute_sensitivity", [&] {
+        tmpc::Solver &v = s->s;
+        tmpc::Mat dK, dP, d1, d2;
+        if (tmpc::compute_sensitivity(v.A, v.B, v.Q, v.R, v.cache.rho, dK, dP, d1, d2)) {
+            set_error("compute_sensitivity: singular R + rho I + B'PB");
+            return -1;
+        }
+        if (dKinf) std::copy(dK.a.begin(), dK.a.end(), dKinf);
+        if (dPinf) std::copy(dP.a.begin(), dP.a.end(), dPinf);
+        if (dC1) std::copy(d1.a.begin(), d1.a.end(), dC1);
+        if (dC2) std::copy(d2.a.begin(), d2.a.end(), dC2);
+        return 0;
+    });
+}
+
+int tinympc_get_adaptive_state(tinympc_solver *s, double *rho, double *Kinf, double *Pinf) {
+    if (!s) return -1;
+    return guarded("get_adaptive_state", [&] { return s->s.get_adaptive_state(rho, Kinf, Pinf); });
 }
 
 int tinympc_get_cache_terms(tinympc_solver *s, double *Kinf, double *Pinf, double *Quu_inv,
@@ -340,6 +390,24 @@ int tinympc_host_precompute(const double *A, const double *B, const double *Q, c
     });
 }
 
+int tinympc_host_sensitivity(const double *A, const double *B, const double *Q, const double *R, double rho, int nx,
+                             int nu, double *dKinf, double *dPinf, double *dC1, double *dC2) {
+    return guarded("host_sensitivity", [&]() -> int {
+        if (!A || !B || !Q || !R || nx < 1 || nu < 1) return -1;
+        tmpc::Mat dK, dP, d1, d2;
+        if (tmpc::compute_sensitivity(tmpc::Mat(nx, nx, A), tmpc::Mat(nx, nu, B), tmpc::Mat(nx, nx, Q),
+                                      tmpc::Mat(nu, nu, R), rho, dK, dP, d1, d2)) {
+            set_error("host_sensitivity: singular R + rho I + B'PB");
+            return -1;
+        }
+        if (dKinf) std::copy(dK.a.begin(), dK.a.end(), dKinf);
+        if (dPinf) std::copy(dP.a.begin(), dP.a.end(), dPinf);
+        if (dC1) std::copy(d1.a.begin(), d1.a.end(), dC1);
+        if (dC2) std::copy(d2.a.begin(), d2.a.end(), dC2);
+        return 0;
+    });
+}
+
 /* --------------------- process-global solver (drop-in) --------------------- */
 
 int setup_solver(double *A_data, int A_rows, int A_cols, double *B_data, int B_rows, int B_cols,
@@ -438,17 +506,13 @@ int update_settings(double abs_pri_tol, double abs_dua_tol, int max_iter, int ch
                     int en_state_linear, int en_input_linear, int adaptive_rho,
                     double adaptive_rho_min, double adaptive_rho_max,
                     int adaptive_rho_enable_clipping, int verbose) {
-    (void)adaptive_rho_min;
-    (void)adaptive_rho_max;
-    (void)adaptive_rho_enable_clipping;
     (void)verbose;
     if (need_global("update_settings")) return -1;
     tinympc_enable_cones(g_solver.get(), en_state_soc, en_input_soc);
     tinympc_enable_linear(g_solver.get(), en_state_linear, en_input_linear);
-    if (adaptive_rho) {
-        set_error("update_settings: adaptive_rho is not supported (out of scope, SURVEY.md §2 #7)");
+    if (tinympc_set_adaptive_rho(g_solver.get(), adaptive_rho, adaptive_rho_min, adaptive_rho_max,
+                                 adaptive_rho_enable_clipping))
         return -1;
-    }
     return tinympc_update_settings(g_solver.get(), abs_pri_tol, abs_dua_tol, max_iter, check_termination,
                                    en_state_bound, en_input_bound);
 }
@@ -481,6 +545,25 @@ int set_cache_terms(double *Kinf_data, int Kinf_rows, int Kinf_cols, double *Pin
         !dims_ok("AmBKt", AmBKt_rows, AmBKt_cols, v.nx, v.nx))
         return -1;
     return tinympc_set_cache_terms(g_solver.get(), Kinf_data, Pinf_data, Quu_inv_data, AmBKt_data);
+}
+
+int set_sensitivity(double *dK_data, int dK_rows, int dK_cols, double *dP_data, int dP_rows, int dP_cols,
+                    double *dC1_data, int dC1_rows, int dC1_cols, double *dC2_data, int dC2_rows, int dC2_cols,
+                    int verbose) {
+    (void)verbose;
+    if (need_global("set_sensitivity")) return -1;
+    const tmpc::Solver &v = g_solver->s;
+    if (!dims_ok("dK", dK_rows, dK_cols, v.nu, v.nx) || !dims_ok("dP", dP_rows, dP_cols, v.nx, v.nx) ||
+        (dC1_data && !dims_ok("dC1", dC1_rows, dC1_cols, v.nu, v.nu)) ||
+        (dC2_data && !dims_ok("dC2", dC2_rows, dC2_cols, v.nx, v.nx)))
+        return -1;
+    return tinympc_set_sensitivity(g_solver.get(), dK_data, dP_data, dC1_data, dC2_data);
+}
+
+int get_adaptive_rho(double *rho_buffer, int *count) {
+    if (need_global("get_adaptive_rho") || !rho_buffer || !count) return -1;
+    *count = g_solver->s.batch;
+    return tinympc_get_adaptive_state(g_solver.get(), rho_buffer, nullptr, nullptr);
 }
 
 int print_problem_data(int verbose) {

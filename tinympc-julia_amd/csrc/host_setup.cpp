@@ -109,4 +109,57 @@ int precompute_cache(const Mat &A, const Mat &B, const Mat &Q, const Mat &R, dou
     return 0;
 }
 
+namespace {
+
+// The reference host's LQR for the sensitivities (TinyMPC.jl:326-352, solve_lqr) — NOT the recursion of setup():
+// full Q, R with rho added ONCE, P_0 = Q + rho I, K = (R + rho I + B'PB + 1e-8 I) \ B'PA, at most 5000 sweeps,
+// stop when ||K - K_prev||_F < 1e-10 (from the second sweep on).
+bool lqr_for_sensitivity(const Mat &A, const Mat &B, const Mat &Q, const Mat &R, double rho, Mat &K, Mat &P, Mat &C1,
+                         Mat &C2) {
+    const int nx = A.r, nu = B.c;
+    Mat Qr = Q, Rr = R, Rreg;
+    for (int i = 0; i < nx; ++i) Qr(i, i) += rho;
+    for (int i = 0; i < nu; ++i) Rr(i, i) += rho;
+    Rreg = Rr;
+    for (int i = 0; i < nu; ++i) Rreg(i, i) += 1e-8;
+    const Mat Bt = transpose(B), At = transpose(A);
+    P = Qr;
+    K = Mat(nu, nx);
+    for (int it = 1; it <= 5000; ++it) {
+        const Mat Kprev = K, BtP = mul(Bt, P);
+        if (!lu_solve(add(Rreg, mul(BtP, B)), mul(BtP, A), K)) return false;
+        P = add(Qr, mul(mul(At, P), add(A, mul(B, K), -1.0)));
+        double n2 = 0.0;
+        for (size_t i = 0; i < K.a.size(); ++i) n2 += (K.a[i] - Kprev.a[i]) * (K.a[i] - Kprev.a[i]);
+        if (it > 1 && std::sqrt(n2) < 1e-10) break;
+    }
+    Mat I(nu, nu);
+    for (int i = 0; i < nu; ++i) I(i, i) = 1.0;
+    if (!lu_solve(add(Rr, mul(mul(Bt, P), B)), I, C1)) return false;
+    C2 = transpose(add(A, mul(B, K), -1.0));
+    return true;
+}
+
+}  // namespace
+
+// Forward differences with h = 1e-6 (TinyMPC.jl:301-323, compute_sensitivity_autograd).
+int compute_sensitivity(const Mat &A, const Mat &B, const Mat &Q, const Mat &R, double rho, Mat &dK, Mat &dP, Mat &dC1,
+                        Mat &dC2) {
+    const double h = 1e-6;
+    Mat K0, P0, C10, C20, K1, P1, C11, C21;
+    if (!lqr_for_sensitivity(A, B, Q, R, rho, K0, P0, C10, C20) ||
+        !lqr_for_sensitivity(A, B, Q, R, rho + h, K1, P1, C11, C21))
+        return 1;
+    auto diff = [h](const Mat &X1, const Mat &X0) {
+        Mat D(X0.r, X0.c);
+        for (size_t i = 0; i < D.a.size(); ++i) D.a[i] = (X1.a[i] - X0.a[i]) / h;
+        return D;
+    };
+    dK = diff(K1, K0);
+    dP = diff(P1, P0);
+    dC1 = diff(C11, C10);
+    dC2 = diff(C21, C20);
+    return 0;
+}
+
 }  // namespace tmpc

@@ -27,4 +27,9 @@ struct Cache {
 // Returns 0 on success, 1 if (R1 + B'PB) is singular.
 int precompute_cache(const Mat &A, const Mat &B, const Mat &Q, const Mat &R, double rho, Cache &out);
 
+// d(Kinf, Pinf, Quu_inv, AmBKt)/d rho for adaptive rho, as the reference's host computes them (TinyMPC.jl:301-352).
+// Returns 0 on success, 1 if a linear solve failed.
+int compute_sensitivity(const Mat &A, const Mat &B, const Mat &Q, const Mat &R, double rho, Mat &dK, Mat &dP, Mat &dC1,
+                        Mat &dC2);
+
 }  // namespace tmpc

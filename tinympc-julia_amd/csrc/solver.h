@@ -51,6 +51,8 @@ struct Settings {
     int en_state_bound = 0, en_input_bound = 0;      // TinyMPC.jl:94-95
     int en_state_soc = 0, en_input_soc = 0;          // TinyMPC.jl:96-97 (parity unpinned)
     int en_state_linear = 0, en_input_linear = 0;    // TinyMPC.jl:98-99 (parity unpinned)
+    int adaptive_rho = 0, adaptive_rho_clip = 1;     // TinyMPC.jl:59-61,100-103
+    double adaptive_rho_min = 0.1, adaptive_rho_max = 10.0;
 };
 
 struct Solver {
@@ -79,6 +81,14 @@ struct Solver {
     bool lin_active() const { return (st.en_state_linear && mlx > 0) || (st.en_input_linear && mlu > 0); }
     // constraint sets whose arrays the stream / generic scratch lays out: box | + cones | + linear
     int constraint_sets() const { return lin_active() ? 3 : (cones_active() ? 2 : 1); }
+    // adaptive rho (admm.cpp:147-174): sensitivities d(Kinf | Pinf)/d rho of the family (column-major, set by the
+    // caller or computed on first use as TinyMPC.jl:301-352 does) and each instance's own (rho, Kinf, Pinf) on the
+    // device; generic kernel only
+    std::vector<double> sens;
+    bool sens_set = false, sens_dirty = true, adapt_dirty = true;
+    double *d_sens = nullptr, *d_adapt = nullptr;
+    int set_sensitivity(const double *dK, const double *dP);
+    int get_adaptive_state(double *rho, double *Kinf, double *Pinf);
     // one problem family PER INSTANCE: per-instance A, B (column-major, concatenated),
     // Riccati caches and diag/rho scalars; runs on the stream kernel with per-lane coefficient columns
     bool hetero = false;

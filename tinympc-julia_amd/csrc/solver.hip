@@ -139,6 +139,7 @@ Solver::~Solver() {
     dev_free(d_coef);
     dev_free(d_bounds);
     dev_free(d_gstat);
+    dev_free(d_sens);
     if (h_gstat) (void)hipHostFree(h_gstat);
     h_gstat = nullptr;
     for (hipEvent_t e : ev_ring)
@@ -177,6 +178,8 @@ void Solver::free_batch() {
     dev_free(d_svl);
     dev_free(d_syl);
     dev_free(d_szl);
+    dev_free(d_adapt);
+    adapt_dirty = true;
     dev_free(d_mpc_x);
     dev_free(d_mpc_u);
     dev_free(d_mpc_iter);
@@ -268,6 +271,13 @@ int Solver::select_kernel() {
     const KernelEntry *k = genv ? find_quad_kernel(nx, nu, N, std::atoi(genv)) : nullptr;
     if (!k) k = select_quad_kernel(nx, nu, N, batch);
     if (has_fdyn || cones_active() || lin_active() || hetero) k = nullptr;  // extensions run on the stream / generic kernels
+    if (st.adaptive_rho) {
+        if (hetero) {
+            set_error("adaptive_rho is not available on a per-instance-family solver");
+            return -1;
+        }
+        k = nullptr;  // adaptive rho: generic kernel only (per-instance rho, Kinf, Pinf in HBM)
+    }
     if (std::getenv("TINYMPC_HIP_NO_QUAD")) k = nullptr;    // tuning aid: time the fallback kernels on any shape
     // one-shot solves (cold start, workspace not kept) with fp64 recurrences: the matrix-core kernel of the shape
     if (k && !warm_start && precision == 0 && chunk_iters == 0 && !genv && !std::getenv("TINYMPC_HIP_NO_MFMA"))
@@ -278,7 +288,7 @@ int Solver::select_kernel() {
     }
     // shapes / options without a quad kernel: the stream kernel for (nx, nu) if its LDS image fits
     const StreamEntry *s2 = nullptr;
-    if (!k && !std::getenv("TINYMPC_HIP_NO_STREAM")) {
+    if (!k && !st.adaptive_rho && !std::getenv("TINYMPC_HIP_NO_STREAM")) {
         s2 = find_stream_kernel(nx, nu);
         // 32-bit lane byte offsets into one knot's rows; LDS image of coefficients + bounds
         if (s2 && 16.0 * batch * std::max(nx, nu) >= 4.0e9) s2 = nullptr;
@@ -356,6 +366,44 @@ int Solver::reset() {
         HIP_TRY(hipMemset(d_svl, 0, Bn * EX * sizeof(float)));
         HIP_TRY(hipMemset(d_syl, 0, Bn * EU * sizeof(float)));
         HIP_TRY(hipMemset(d_szl, 0, Bn * EU * sizeof(float)));
+    }
+    adapt_dirty = true;  // adapted (rho, Kinf, Pinf) go back to the family's cache
+    return 0;
+}
+
+__global__ void adapt_fill_kernel(double *adapt, const double *family, int n, long batch) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (long)n * batch) adapt[i] = family[i / batch];
+}
+
+int Solver::set_sensitivity(const double *dK, const double *dP) {
+    sens.assign((size_t)nu * nx + (size_t)nx * nx, 0.0);
+    std::copy(dK, dK + (size_t)nu * nx, sens.begin());
+    std::copy(dP, dP + (size_t)nx * nx, sens.begin() + (size_t)nu * nx);
+    sens_set = true;
+    sens_dirty = true;
+    return 0;
+}
+
+int Solver::get_adaptive_state(double *rho, double *Kinf, double *Pinf) {
+    HIP_TRY(hipSetDevice(device));
+    const size_t Bn = (size_t)batch, nk = (size_t)nu * nx, np = (size_t)nx * nx;
+    if (!d_adapt || adapt_dirty) {  // nothing adapted yet: every instance holds the family's values
+        for (size_t b = 0; b < Bn; ++b) {
+            if (rho) rho[b] = cache.rho;
+            if (Kinf) std::copy(cache.Kinf.a.begin(), cache.Kinf.a.end(), Kinf + b * nk);
+            if (Pinf) std::copy(cache.Pinf.a.begin(), cache.Pinf.a.end(), Pinf + b * np);
+        }
+        return 0;
+    }
+    std::vector<double> h((1 + nk + np) * Bn);
+    HIP_TRY(hipMemcpy(h.data(), d_adapt, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t b = 0; b < Bn; ++b) {
+        if (rho) rho[b] = h[b];
+        if (Kinf)
+            for (size_t e = 0; e < nk; ++e) Kinf[b * nk + e] = h[(1 + e) * Bn + b];
+        if (Pinf)
+            for (size_t e = 0; e < np; ++e) Pinf[b * np + e] = h[(1 + nk + e) * Bn + b];
     }
     return 0;
 }
@@ -565,6 +613,37 @@ int Solver::ensure_extension_buffers() {
     if (ke) return 0;
     HIP_TRY(hipSetDevice(device));
     const size_t Bn = (size_t)batch, EX = (size_t)ex(), EU = (size_t)eu();
+    if (st.adaptive_rho) {
+        const size_t nk = (size_t)nu * nx, np = (size_t)nx * nx;
+        if (!sens_set) {  // what the reference's host would compute and hand over (TinyMPC.jl:301-323)
+            Mat dK, dP, dC1, dC2;
+            if (compute_sensitivity(A, B, Q, R, cache.rho, dK, dP, dC1, dC2)) {
+                set_error("adaptive_rho: sensitivity computation failed (singular R + rho I + B'PB)");
+                return -1;
+            }
+            set_sensitivity(dK.a.data(), dP.a.data());
+        }
+        if (sens_dirty) {
+            if (dev_alloc(d_sens, nk + np)) return -1;
+            HIP_TRY(hipMemcpy(d_sens, sens.data(), (nk + np) * sizeof(double), hipMemcpyHostToDevice));
+            sens_dirty = false;
+        }
+        if (!d_adapt && dev_alloc(d_adapt, (1 + nk + np) * Bn)) return -1;
+        if (adapt_dirty) {
+            std::vector<double> fam(1 + nk + np);
+            fam[0] = cache.rho;
+            std::copy(cache.Kinf.a.begin(), cache.Kinf.a.end(), fam.begin() + 1);
+            std::copy(cache.Pinf.a.begin(), cache.Pinf.a.end(), fam.begin() + 1 + nk);
+            double *d_fam = nullptr;
+            if (dev_alloc(d_fam, fam.size())) return -1;
+            HIP_TRY(hipMemcpy(d_fam, fam.data(), fam.size() * sizeof(double), hipMemcpyHostToDevice));
+            const long total = (long)fam.size() * (long)Bn;
+            adapt_fill_kernel<<<(unsigned)((total + 255) / 256), 256>>>(d_adapt, d_fam, (int)fam.size(), (long)Bn);
+            HIP_TRY(hipDeviceSynchronize());
+            dev_free(d_fam);
+            adapt_dirty = false;
+        }
+    }
     const size_t sets = (size_t)constraint_sets();
     size_t need = Bn * ((2 + 3 * sets) * EX + (3 + 3 * sets) * EU);  // generic kernel: admm_generic.hip.h
     if (se) need = std::max(need, Bn * se->scratch_floats(N, (int)sets));
@@ -744,6 +823,12 @@ int Solver::launch_pass(hipStream_t stream, int mpc_steps, const int *idx, int n
         P.cu[i] = (float)cu[i];
     }
     P.het_aux = d_het_aux;
+    P.adaptive_rho = st.adaptive_rho;
+    P.rho_clip = st.adaptive_rho_clip;
+    P.rho_min = (float)st.adaptive_rho_min;
+    P.rho_max = (float)st.adaptive_rho_max;
+    P.sens = d_sens;
+    P.adapt = d_adapt;
     P.sgc = d_sgc;
     P.svc = d_svc;
     P.syc = d_syc;

@@ -21,7 +21,8 @@ module TinyMPC
 
 export TinyMPCSolver, setup, solve, get_solution, get_status, set_x0, set_x_ref, set_u_ref,
        set_bound_constraints, set_linear_constraints, set_equality_constraints, set_cone_constraints, update_settings,
-       set_cache_terms, set_batch_size, reset_workspace, print_problem_data
+       set_cache_terms, set_batch_size, reset_workspace, print_problem_data,
+       compute_sensitivity_autograd, set_sensitivity, get_adaptive_rho
 
 using LinearAlgebra, Libdl, Printf
 
@@ -218,6 +219,58 @@ function set_cache_terms(solver::TinyMPCSolver, Kinf::Matrix{Float64}, Pinf::Mat
               Kinf, size(Kinf, 1), size(Kinf, 2), Pinf, size(Pinf, 1), size(Pinf, 2),
               Quu_inv, size(Quu_inv, 1), size(Quu_inv, 2), AmBKt, size(AmBKt, 1), size(AmBKt, 2), _flag(verbose)),
         "Failed to set cache terms")
+end
+
+# LQR gains of the rho-regularised problem the sensitivities are differenced on (reference TinyMPC.jl:326-352):
+# rho enters once, P starts at Q + rho I, a 1e-8 ridge in the gain solve only, at most 5000 sweeps.
+function _lqr_gains(A, B, Q, R, rho)
+    nx, nu = size(A, 1), size(B, 2)
+    Qr = Q + rho * Matrix{Float64}(I, nx, nx)
+    Rr = R + rho * Matrix{Float64}(I, nu, nu)
+    P = copy(Qr)
+    K = zeros(nu, nx)
+    for sweep in 1:5000
+        Kold = K
+        K = (Rr + B' * P * B + 1e-8 * Matrix{Float64}(I, nu, nu)) \ (B' * P * A)
+        P = Qr + A' * P * (A - B * K)
+        (sweep > 1 && norm(K - Kold) < 1e-10) && break
+    end
+    return K, P, inv(Rr + B' * P * B), Matrix((A - B * K)')
+end
+
+"""
+    compute_sensitivity_autograd(solver) -> (dK, dP, dC1, dC2)
+
+Forward differences (h = 1e-6) of the cache terms in rho, as the reference's function of the same name
+(TinyMPC.jl:301-323).  `update_settings(adaptive_rho=true)` without `set_sensitivity` makes the library do the same.
+"""
+function compute_sensitivity_autograd(solver::TinyMPCSolver)
+    _need(solver)
+    h = 1e-6
+    g0 = _lqr_gains(solver.A, solver.B, solver.Q, solver.R, solver.rho)
+    g1 = _lqr_gains(solver.A, solver.B, solver.Q, solver.R, solver.rho + h)
+    return ntuple(i -> (g1[i] - g0[i]) / h, 4)
+end
+
+# What codegen_with_sensitivity (reference TinyMPC.jl:374-394) bakes into generated code, for the live solver.
+function set_sensitivity(solver::TinyMPCSolver, dK::Matrix{Float64}, dP::Matrix{Float64},
+                         dC1::Matrix{Float64}, dC2::Matrix{Float64}; verbose::Bool=false)
+    _need(solver)
+    _ok(ccall((:set_sensitivity, _lib_path()), Int32,
+              (Ptr{Float64}, Int32, Int32, Ptr{Float64}, Int32, Int32,
+               Ptr{Float64}, Int32, Int32, Ptr{Float64}, Int32, Int32, Int32),
+              dK, size(dK, 1), size(dK, 2), dP, size(dP, 1), size(dP, 2),
+              dC1, size(dC1, 1), size(dC1, 2), dC2, size(dC2, 1), size(dC2, 2), _flag(verbose)),
+        "Failed to set sensitivity matrices")
+end
+
+# rho of every instance after adaptation
+function get_adaptive_rho(solver::TinyMPCSolver)
+    _need(solver)
+    rho = zeros(Float64, solver.batch)
+    n = Ref{Int32}(0)
+    _ok(ccall((:get_adaptive_rho, _lib_path()), Int32, (Ptr{Float64}, Ptr{Int32}), rho, n), "Failed to get adaptive rho")
+    return rho
 end
 
 function print_problem_data(solver::TinyMPCSolver; verbose::Bool=false)

@@ -54,6 +54,8 @@ SIGNATURES = {
                                       c_dp, c_int, c_int, c_int]),
     "set_cache_terms": (c_int, [c_dp, c_int, c_int, c_dp, c_int, c_int, c_dp, c_int, c_int, c_dp,
                                 c_int, c_int, c_int]),
+    "set_sensitivity": (c_int, [c_dp, c_int, c_int, c_dp, c_int, c_int, c_dp, c_int, c_int, c_dp, c_int, c_int, c_int]),
+    "get_adaptive_rho": (c_int, [c_dp, c_ip]),
     "print_problem_data": (c_int, [c_int]),
     "set_linear_constraints": (c_int, [c_dp, c_int, c_int, c_dp, c_int, c_dp, c_int, c_int, c_dp,
                                        c_int, c_int]),
@@ -96,6 +98,10 @@ SIGNATURES = {
     "tinympc_get_mpc_log": (c_int, [c_vp, c_dp, c_dp, c_ip]),
     "tinympc_set_profiling": (c_int, [c_vp, c_int]),
     "tinympc_set_compaction": (c_int, [c_vp, c_int]),
+    "tinympc_set_adaptive_rho": (c_int, [c_vp, c_int, c_dbl, c_dbl, c_int]),
+    "tinympc_set_sensitivity": (c_int, [c_vp, c_dp, c_dp, c_dp, c_dp]),
+    "tinympc_compute_sensitivity": (c_int, [c_vp, c_dp, c_dp, c_dp, c_dp]),
+    "tinympc_get_adaptive_state": (c_int, [c_vp, c_dp, c_dp, c_dp]),
     "tinympc_kernel_elapsed_ms": (c_dbl, [c_vp]),
     "tinympc_kernel_elapsed_mean_ms": (c_dbl, [c_vp, c_int]),
     "tinympc_set_precision": (c_int, [c_vp, c_int]),
@@ -104,6 +110,7 @@ SIGNATURES = {
     "tinympc_algorithmic_flops": (c_dbl, [c_vp, c_int]),
     "tinympc_last_error": (ctypes.c_char_p, []),
     "tinympc_host_precompute": (c_int, [c_dp, c_dp, c_dp, c_dp, c_dbl, c_int, c_int, c_dp, c_dp, c_dp, c_dp]),
+    "tinympc_host_sensitivity": (c_int, [c_dp, c_dp, c_dp, c_dp, c_dbl, c_int, c_int, c_dp, c_dp, c_dp, c_dp]),
 }
 
 
@@ -356,6 +363,50 @@ def set_cone_constraints(solver, Acu, qcu, cu, Acx, qcx, cx, *, verbose=False):
     return status
 
 
+def _solve_lqr(A, B, Q, R, rho):
+    """TinyMPC.jl:326-352: the rho-regularised LQR the sensitivities are differenced on (rho enters once, P0 = Q + rho I)"""
+    nx, nu = A.shape[0], B.shape[1]
+    Qr, Rr = Q + rho * np.eye(nx), R + rho * np.eye(nu)
+    P, K = Qr.copy(), np.zeros((nu, nx))
+    for it in range(1, 5001):
+        Kp = K
+        K = np.linalg.solve(Rr + B.T @ P @ B + 1e-8 * np.eye(nu), B.T @ P @ A)
+        P = Qr + A.T @ P @ (A - B @ K)
+        if it > 1 and np.linalg.norm(K - Kp) < 1e-10:
+            break
+    return K, P, np.linalg.inv(Rr + B.T @ P @ B), (A - B @ K).T
+
+
+def compute_sensitivity_autograd(solver):
+    """TinyMPC.jl:301-323: forward differences (h = 1e-6) of (Kinf, Pinf, Quu_inv, AmBKt) in rho -> (dK, dP, dC1, dC2)"""
+    _need_setup(solver)
+    h = 1e-6
+    m0 = _solve_lqr(solver.A, solver.B, solver.Q, solver.R, solver.rho)
+    m1 = _solve_lqr(solver.A, solver.B, solver.Q, solver.R, solver.rho + h)
+    return tuple((b - a) / h for a, b in zip(m0, m1))
+
+
+def set_sensitivity(solver, dK, dP, dC1=None, dC2=None, *, verbose=False):
+    """hand the live solver the sensitivities codegen_with_sensitivity would bake in (TinyMPC.jl:374-394)"""
+    _need_setup(solver)
+    ms = [None if m is None else _mat(m) for m in (dK, dP, dC1, dC2)]
+    args = []
+    for m in ms:
+        args += [None, 0, 0] if m is None else [_dp(m), m.shape[0], m.shape[1]]
+    if load_library().set_sensitivity(*args, 1 if verbose else 0) != 0:
+        raise TinyMPCError(f"Failed to set sensitivity matrices ({_err()})")
+    return 0
+
+
+def get_adaptive_rho(solver):
+    """rho of each instance after adaptation, shape (batch,)"""
+    _need_setup(solver)
+    rho, n = np.zeros(solver.batch), ctypes.c_int()
+    if load_library().get_adaptive_rho(_dp(rho), ctypes.byref(n)) != 0:
+        raise TinyMPCError(f"Failed to get adaptive rho ({_err()})")
+    return rho[: n.value]
+
+
 def set_cache_terms(solver, Kinf, Pinf, Quu_inv, AmBKt, *, verbose=False):
     """TinyMPC.jl:278-292"""
     _need_setup(solver)
@@ -380,6 +431,18 @@ def cleanup():
         load_library().cleanup_solver()
     except Exception:
         pass
+
+
+def host_sensitivity(A, B, Q, R, rho):
+    """the library's host finite differences (dK, dP, dC1, dC2) without a GPU (TinyMPC.jl:301-352 semantics)"""
+    A, B, Q, R = _mat(A), _mat(B), _mat(Q), _mat(R)
+    nx, nu = A.shape[0], B.shape[1]
+    dK, dP = np.zeros((nu, nx), order="F"), np.zeros((nx, nx), order="F")
+    d1, d2 = np.zeros((nu, nu), order="F"), np.zeros((nx, nx), order="F")
+    if load_library().tinympc_host_sensitivity(_dp(A), _dp(B), _dp(Q), _dp(R), float(rho), nx, nu, _dp(dK), _dp(dP),
+                                               _dp(d1), _dp(d2)) != 0:
+        raise TinyMPCError(f"host_sensitivity failed ({_err()})")
+    return dK, dP, d1, d2
 
 
 def host_precompute(A, B, Q, R, rho):
@@ -482,6 +545,31 @@ class BatchSolver:
         Au, bu = _lin_block(np.zeros((0, self.nu)) if Aeq_u is None else Aeq_u, [] if beq_u is None else beq_u, self.nu)
         self.set_linear_constraints(np.vstack([Ax, -Ax]), np.concatenate([bx, -bx]), np.vstack([Au, -Au]),
                                     np.concatenate([bu, -bu]))
+
+    def set_adaptive_rho(self, enable=True, rho_min=0.1, rho_max=10.0, enable_clipping=True):
+        """per-instance rho adaptation every 5th iteration (admm.cpp:147-174); defaults TinyMPC.jl:59-61"""
+        self._chk(self.lib.tinympc_set_adaptive_rho(self.h, int(bool(enable)), float(rho_min), float(rho_max),
+                                                    int(bool(enable_clipping))), "set_adaptive_rho")
+
+    def set_sensitivity(self, dK, dP, dC1=None, dC2=None):
+        """dKinf/drho, dPinf/drho (dC1, dC2 accepted and unused, as in the reference's iteration)"""
+        ms = [None if m is None else _mat(m) for m in (dK, dP, dC1, dC2)]
+        self._chk(self.lib.tinympc_set_sensitivity(self.h, *[None if m is None else _dp(m) for m in ms]), "set_sensitivity")
+
+    def compute_sensitivity(self):
+        """(dK, dP, dC1, dC2) by the library's host finite differences (TinyMPC.jl:301-352)"""
+        nx, nu = self.nx, self.nu
+        dK, dP = np.zeros((nu, nx), order="F"), np.zeros((nx, nx), order="F")
+        d1, d2 = np.zeros((nu, nu), order="F"), np.zeros((nx, nx), order="F")
+        self._chk(self.lib.tinympc_compute_sensitivity(self.h, _dp(dK), _dp(dP), _dp(d1), _dp(d2)), "compute_sensitivity")
+        return dK, dP, d1, d2
+
+    def get_adaptive_state(self):
+        """each instance's current rho (batch,), Kinf (nu, nx, batch), Pinf (nx, nx, batch)"""
+        nx, nu, Bn = self.nx, self.nu, self.batch
+        rho, K, P = np.zeros(Bn), np.zeros((nu, nx, Bn), order="F"), np.zeros((nx, nx, Bn), order="F")
+        self._chk(self.lib.tinympc_get_adaptive_state(self.h, _dp(rho), _dp(K), _dp(P)), "get_adaptive_state")
+        return dict(rho=rho, Kinf=K, Pinf=P)
 
     def get_cache_terms(self):
         nx, nu = self.nx, self.nu
