@@ -495,7 +495,7 @@ def test_error_behaviour(hip_lib):
     with pytest.raises(t.TinyMPCError):
         t.set_x_ref(s, np.zeros((4, 7)))                # wrong horizon
     with pytest.raises(t.TinyMPCError):
-        t.update_settings(s, adaptive_rho=True)         # adaptive rho is refused, not silently dropped
+        t.update_settings(s, adaptive_rho=True, adaptive_rho_min=2.0, adaptive_rho_max=1.0)   # empty rho interval
     with pytest.raises(t.TinyMPCError):
         t.set_cone_constraints(s, [0], [3], [0.25], [], [], [])   # a 3-row cone on a 1-row input
     assert t.set_cone_constraints(s, [], [], [], [], [], []) == 0
@@ -1371,3 +1371,20 @@ def test_adaptive_rho_state_and_errors(hip_lib):
     assert np.all(bs.get_adaptive_state()["rho"] == prob.rho)
     with pytest.raises(t.TinyMPCError):
         bs.set_adaptive_rho(True, 2.0, 1.0, True)
+
+
+def test_reference_settings_test_adaptive_rho_binding(hip_lib):
+    """tests/test_settings.jl:66-75 ("Adaptive Rho Settings"): setup(..., adaptive_rho=true, adaptive_rho_min=0.5,
+    adaptive_rho_max=5.0) on the N=2 cartpole returns 0 and leaves the solver set up; here it also solves."""
+    prob = t.problems.cartpole(2)
+    s = t.TinyMPCSolver()
+    assert t.setup(s, prob.A, prob.B, np.zeros(4), prob.Q, prob.R, 1.0, 4, 1, 2, adaptive_rho=True,
+                   adaptive_rho_min=0.5, adaptive_rho_max=5.0) == 0
+    assert s.is_setup
+    t.set_x0(s, [0.1, 0, 0, 0])
+    assert t.solve(s) in (0, 1)
+    rho = t.get_adaptive_rho(s)
+    assert rho.shape == (1,) and 0.5 <= rho[0] <= 5.0
+    sol = t.get_solution(s)
+    assert np.all(np.isfinite(sol["states"])) and np.all(np.isfinite(sol["controls"]))
+    t.cleanup()
