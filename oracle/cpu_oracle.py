@@ -187,6 +187,10 @@ class CpuSolver:
         self._call("get_cache", _dp(K), _dp(P), _dp(Qi), _dp(Am))
         return dict(Kinf=K, Pinf=P, Quu_inv=Qi, AmBKt=Am)
 
+    def set_state(self, d, y, g, v, z):
+        a = [_f(m) for m in (d, y, g, v, z)]
+        self._call("set_state", *[_dp(m) for m in a])
+
     def get_state(self):
         nx, nu, N = self.nx, self.nu, self.N
         d = np.zeros((nu, N - 1), order="F")

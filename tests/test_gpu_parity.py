@@ -1078,14 +1078,16 @@ def test_config5_shard_tolerance_terminated(hip_lib, oracle_built):
     bs.close()
 
 
-@pytest.mark.parametrize("family,kernel", [("cartpole", "quad<4,1,20"), ("quadrotor", "quad<12,4,30"),
-                                           ("cartpole19", "stream4<4,1>")])
-def test_chunked_solve_with_compaction_is_the_same_solve(hip_lib, oracle_built, family, kernel):
+@pytest.mark.parametrize("family,kernel", [("cartpole", "quad<4,1,20"), ("quadrotor", "mfma<12,4,30"),
+                                           ("quadrotor_quad", "quad<12,4,30"), ("cartpole19", "stream4<4,1>")])
+def test_chunked_solve_with_compaction_is_the_same_solve(hip_lib, oracle_built, monkeypatch, family, kernel):
     """tinympc_set_compaction: chunks of iterations with the unconverged instances gathered in between give bit for
     bit the single-launch result (iterates, iteration counts, solved flags, residuals, global status), cold and
     warm-started; and the oracle agrees."""
     B = 3000
-    if family == "quadrotor":
+    if family == "quadrotor_quad":                        # the quad kernel on the shape the matrix-core kernel serves
+        monkeypatch.setenv("TINYMPC_HIP_MFMA_ONESHOT_ONLY", "1")
+    if family.startswith("quadrotor"):
         prob, x0 = t.problems.quadrotor(30), t.problems.quadrotor_x0(B, seed=3)
     else:
         prob, x0 = t.problems.cartpole(20 if family == "cartpole" else 19, u_bound=0.5), t.problems.cartpole_x0(B, seed=8)
@@ -1179,9 +1181,11 @@ def test_matrix_core_kernel_vs_oracle(hip_lib, oracle_built, monkeypatch, case):
     monkeypatch.delenv("TINYMPC_HIP_NO_MFMA")
     if "tol" in case:
         assert len(set(st["iter"].tolist())) > 2 or np.all(st["solved"] == 0)   # instances stop at different iterations
-    # warm-started / workspace-keeping solves stay on the quad kernel
+    # workspace-keeping solves run on the matrix-core kernel's WS variant; only the fused closed loop needs the quad kernel
     bs.set_warm_start(True)
     bs.solve()
+    assert bs.kernel_name.startswith("mfma<")
+    bs.mpc_rollout(2)
     assert bs.kernel_name.startswith("quad<")
     bs.close()
 
@@ -1195,6 +1199,10 @@ def test_kernel_selection_by_batch(hip_lib):
         bs.close()
     q = t.problems.quadrotor(30)
     bs = t.BatchSolver(q.A, q.B, q.Q, q.R, q.rho, q.N, batch=8)
+    assert bs.kernel_name == "mfma<12,4,30>"
+    bs.set_precision(1)                                   # all-fp32 recurrences: not what the fp64 matrix cores run
+    bs.set_x0(np.zeros((12, 8)))
+    bs.solve()
     assert bs.kernel_name == "quad<12,4,30,g4>"
     bs.close()
     q = t.problems.quadrotor(25)
@@ -1388,3 +1396,66 @@ def test_reference_settings_test_adaptive_rho_binding(hip_lib):
     sol = t.get_solution(s)
     assert np.all(np.isfinite(sol["states"])) and np.all(np.isfinite(sol["controls"]))
     t.cleanup()
+
+
+@pytest.mark.parametrize("case", ["input_bounds", "state_bounds", "state_bounds_then_off"])
+def test_matrix_core_workspace_variant_vs_oracle(hip_lib, oracle_built, case):
+    """Warm-started sequences on the matrix-core kernel's WS variant: a closed loop of tolerance-terminated solves per
+    instance against the fp64 restatement run the same way — solutions, iteration counts and the workspace itself
+    (d, y, g, v, z) after every solve, including v, z of a CONVERGED solve (the previous iteration's slack,
+    admm.cpp:181-197: parked in LDS by the kernel).  Without a finite state bound since the last reset the kernel does not
+    carry g at all (it is identically zero); once one has been active it must, also for the first iteration after the
+    bound is switched off (where the reference still reads the old dual)."""
+    N, B, steps = 20, 70, 4
+    prob = t.problems.quadrotor(N)
+    x0 = t.problems.quadrotor_x0(B, seed=9)
+    if case != "input_bounds":                            # position rows boxed just outside the initial states: binds on overshoot
+        prob.x_min, prob.x_max = np.full((12, N), -1e17), np.full((12, N), 1e17)
+        prob.x_min[:3, :], prob.x_max[:3, :] = -0.31, 0.31
+    kw = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=40, check_termination=1)
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+    bs.update_settings(**kw)
+    bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    orcs = []
+    for b in range(B):
+        o = oracle_built.CpuSolver("orc64", prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N)
+        o.update_settings(**kw)
+        o.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        orcs.append(o)
+    x = x0.copy()
+    converged_steps = 0
+    for k in range(steps):
+        if case == "state_bounds_then_off" and k == 2:   # bounds off, duals stay: g is still needed
+            bs.update_settings(en_state_bound=0, en_input_bound=1, **kw)
+            for o in orcs:
+                o.update_settings(en_state_bound=0, en_input_bound=1, **kw)
+        bs.set_x0(x)
+        bs.solve()
+        assert bs.kernel_name == f"mfma<12,4,{N}>"
+        sol, st, ws = bs.get_solution(), bs.get_status(), bs.get_workspace()
+        xn = np.zeros_like(x)
+        for b in range(B):
+            o = orcs[b]
+            o.set_x0(x[:, b])
+            o.solve()
+            r, sv = o.get_solution(), o.get_state()
+            assert abs(int(st["iter"][b]) - r["iter"]) <= 1
+            if int(st["iter"][b]) != r["iter"]:           # a residual within rounding of the tolerance: skip, resync below
+                o.set_state(*[ws[key][:, :, b] for key in ("d", "y", "g", "v", "z")])
+            else:
+                converged_steps += r["solved"]
+                assert nrel(sol["states"][:, :, b], r["x"]) <= 2e-5 and nrel(sol["controls"][:, :, b], r["u"]) <= 2e-5
+                for key in ("d", "y", "g", "v", "z"):
+                    scale = max(np.abs(sv[key]).max(), 1e-2)
+                    assert np.abs(ws[key][:, :, b] - sv[key]).max() <= 5e-5 * scale, (k, b, key)
+            xn[:, b] = prob.A @ x[:, b] + prob.B @ r["u"][:, 0]
+        x = xn
+    assert converged_steps >= B                           # the converged-exit path is exercised
+    gmax = np.abs(bs.get_workspace()["g"]).max()
+    if case == "input_bounds":
+        assert gmax == 0.0
+    elif case == "state_bounds":
+        assert gmax > 1e-3                                # the bound does bind
+    else:
+        assert gmax <= 1e-5                               # g + x - (x + g): the dual empties once nothing clamps
+    bs.close()

@@ -18,9 +18,15 @@
 // and the 48 + 48 fp64 FMAs per lane and knot pair of the quad kernel leave the VALU, which does the elementwise
 // slack / dual / cost work while the matrix core runs.
 //
-// Scope: cold-start solves whose workspace is not kept (what the quad kernel's OS / UNI variants serve); other modes
-// stay on the quad kernel.  An instance that converges stores its solution at that iteration and idles (its lanes keep
-// iterating, results discarded) until its wavefront is done.
+// Scope: plain solves (cold one-shot, warm-started, workspace-keeping, chunked with compaction); the fused closed loop
+// stays on the quad kernel.  An instance that converges stores its solution (and, WS, its workspace) at that iteration
+// and idles (its lanes keep iterating, results discarded) until its wavefront is done.
+//
+// WS (workspace variant): d, y, g, v, z are loaded from / saved to the persistent workspace.  The slack registers are
+// updated in place, but a solve that converges must leave the PREVIOUS iteration's slack in v, z (admm.cpp:181-197
+// returns before `v = vnew`), and that is what the next solve's first dual residual is measured against.  So on
+// iterations that can converge each lane parks the slack it is about to overwrite in LDS ([row][64 instances],
+// (nx N + nu (N-1)) * 256 B per workgroup: 119 KB for the quadrotor) and a converging instance saves v, z from there.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -61,12 +67,21 @@ __device__ __forceinline__ float mf_inst_max(float m) {
     return m;
 }
 
-template <int NX, int NU, int N, int REFS, bool XB>
+// dynamic LDS of the WS variant: the parked slack of the workgroup's 64 instances
+template <int NX, int NU, int N>
+constexpr size_t mfma_ws_lds_bytes() {
+    return (size_t)(NX * N + NU * (N - 1)) * 64 * sizeof(float);
+}
+
+template <int NX, int NU, int N, int REFS, bool XB, bool WS = false>
 __global__ __launch_bounds__(256) void admm_mfma_kernel(const AdmmParams P) {
+    // XB = false with WS: the caller guarantees that the workspace's state dual is zero and stays zero (no finite
+    // state bound now, none since the last reset) — g is then neither loaded, carried nor written.
     using S = MfmaShape<NX, NU, N>;
     constexpr int VX = S::VX, T = 256;
     __shared__ float s_bnd[S::BOUNDS_LEN];
     __shared__ float s_ref[REFS == REF_SHARED ? S::REFS_LEN : 1];
+    extern __shared__ float s_old[];  // WS: [row of v | row of z][64 instances]
     const int tid = threadIdx.x;
     for (int i = tid; i < S::BOUNDS_LEN; i += T) s_bnd[i] = P.bounds[i];
     if constexpr (REFS == REF_SHARED)
@@ -74,7 +89,8 @@ __global__ __launch_bounds__(256) void admm_mfma_kernel(const AdmmParams P) {
     __syncthreads();
 
     const int l = tid & 63, g = l >> 4, j = l & 15;
-    const long slot = (long)blockIdx.x * 64 + (tid >> 6) * 16 + j;
+    const int inst = (tid >> 6) * 16 + j;  // instance of the workgroup
+    const long slot = (long)blockIdx.x * 64 + inst;
     const bool active = slot < P.batch;
     const long b = (active && P.idx) ? P.idx[slot] : slot;
     constexpr long EX = (long)NX * N, EU = (long)NU * (N - 1);
@@ -114,6 +130,29 @@ __global__ __launch_bounds__(256) void admm_mfma_kernel(const AdmmParams P) {
         sy[k] = szw[k] = sd[k] = 0.f;
         if constexpr (REFS == REF_PER_INSTANCE) ur[k] = (active && uok) ? P.uref[b * EU + k * NU + g] : 0.f;
     }
+    float res0 = 0.f, res1 = 0.f, res2 = 0.f, res3 = 0.f;
+    if constexpr (WS) {
+        if (!P.cold_start && active) {  // warm start: d, y, g, v, z of the previous solve
+#pragma unroll
+            for (int v = 0; v < VX; ++v)
+                if (xok[v]) {
+#pragma unroll
+                    for (int k = 0; k < N; ++k) {
+                        if constexpr (XB) sg[k][v] = P.sg[b * EX + k * NX + 4 * v + g];
+                        sw[k][v] = P.sv[b * EX + k * NX + 4 * v + g];
+                    }
+                }
+            if (uok) {
+#pragma unroll
+                for (int k = 0; k < N - 1; ++k) {
+                    sy[k] = P.sy[b * EU + k * NU + g];
+                    szw[k] = P.sz[b * EU + k * NU + g];
+                    sd[k] = P.sd[b * EU + k * NU + g];
+                }
+            }
+            res0 = P.res[b * 4 + 0], res1 = P.res[b * 4 + 1], res2 = P.res[b * 4 + 2], res3 = P.res[b * 4 + 3];
+        }
+    }
     auto ref_x = [&](auto kk, int v) -> float {
         constexpr int K = decltype(kk)::value;
         if constexpr (REFS == REF_SHARED) return xok[v] ? s_ref[K * NX + 4 * v + g] : 0.f;
@@ -129,7 +168,6 @@ __global__ __launch_bounds__(256) void admm_mfma_kernel(const AdmmParams P) {
     constexpr float kInf = __builtin_inff();
 
     int it = 0, conv = 0;
-    float res0 = 0.f, res1 = 0.f, res2 = 0.f, res3 = 0.f;
     const int ct = P.check_termination;
     const bool can_converge = P.abs_pri_tol > 0.f && P.abs_dua_tol > 0.f;
     const int last_check_it = ct > 0 ? (P.max_iter / ct) * ct : 0;
@@ -152,6 +190,28 @@ __global__ __launch_bounds__(256) void admm_mfma_kernel(const AdmmParams P) {
             P.res[b * 4 + 1] = res1;
             P.res[b * 4 + 2] = res2;
             P.res[b * 4 + 3] = res3;
+        }
+    };
+
+    // WS: the workspace as the reference leaves it.  `parked`: v, z are the slack of the iteration BEFORE the one just
+    // run (a converged solve), read back from where this lane parked them.
+    auto store_workspace = [&](bool parked) {
+#pragma unroll
+        for (int v = 0; v < VX; ++v)
+            if (xok[v]) {
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    if constexpr (XB) P.sg[b * EX + k * NX + 4 * v + g] = sg[XB ? k : 0][v];
+                    P.sv[b * EX + k * NX + 4 * v + g] = parked ? s_old[(k * NX + 4 * v + g) * 64 + inst] : sw[k][v];
+                }
+            }
+        if (uok) {
+#pragma unroll
+            for (int k = 0; k < N - 1; ++k) {
+                P.sy[b * EU + k * NU + g] = sy[k];
+                P.sz[b * EU + k * NU + g] = parked ? s_old[(N * NX + k * NU + g) * 64 + inst] : szw[k];
+                P.sd[b * EU + k * NU + g] = sd[k];
+            }
         }
     };
 
@@ -190,6 +250,8 @@ __global__ __launch_bounds__(256) void admm_mfma_kernel(const AdmmParams P) {
                     pri_x = fmaxf(pri_x, fabsf(xf - vn));
                     dua_x = fmaxf(dua_x, fabsf(sw[k][v] - vn));
                 }
+                if constexpr (WS)
+                    if (xok[v]) s_old[(k * NX + 4 * v + g) * 64 + inst] = sw[k][v];  // unconditional: no branch in the knot
                 sw[k][v] = vn;
             }
             if constexpr (k < N - 1) {
@@ -203,6 +265,8 @@ __global__ __launch_bounds__(256) void admm_mfma_kernel(const AdmmParams P) {
                     pri_u = fmaxf(pri_u, fabsf(uf - zn));
                     dua_u = fmaxf(dua_u, fabsf(szw[k] - zn));
                 }
+                if constexpr (WS)
+                    if (uok) s_old[(N * NX + k * NU + g) * 64 + inst] = szw[k];
                 szw[k] = zn;
                 c[3] = 0.0;
                 c = mf_mma(cf[S::O_BF], u, c);                                 // + [B; 0] u
@@ -224,7 +288,11 @@ __global__ __launch_bounds__(256) void admm_mfma_kernel(const AdmmParams P) {
             }
         }
         if (__builtin_amdgcn_ballot_w64(newly)) {
-            if (newly && active) store_solution();
+            if (newly && active) {
+                store_solution();
+                if constexpr (WS)
+                    if (P.save_state) store_workspace(true);
+            }
         }
         if (!__builtin_amdgcn_ballot_w64(active && !conv)) break;
         // ================= fused backward sweep (admm.cpp:75-83, :13-20) =================
@@ -265,7 +333,11 @@ __global__ __launch_bounds__(256) void admm_mfma_kernel(const AdmmParams P) {
         });
     }
 
-    if (active && !conv) store_solution();
+    if (active && !conv) {
+        store_solution();
+        if constexpr (WS)
+            if (P.save_state) store_workspace(false);
+    }
     {
         float m0 = active ? res0 : 0.f, m1 = active ? res1 : 0.f, m2 = active ? res2 : 0.f, m3 = active ? res3 : 0.f;
 #pragma unroll

@@ -62,27 +62,36 @@ void build_mfma_bounds(const Solver &sv, std::vector<float> &out) {
     for (int a = 0; a < NU; ++a) out[S::B_RD + a] = (float)sv.cache.Rd[a];
 }
 
-template <int NX, int NU, int N, bool XB>
+template <int NX, int NU, int N, bool XB, bool WS>
 hipError_t launch_mfma_xb(const AdmmParams &P, hipStream_t stream) {
     const int grid = (P.batch + 63) / 64;
+    const size_t lds = WS ? mfma_ws_lds_bytes<NX, NU, N>() : 0;
+#define TMPC_MFMA_LAUNCH(REFS_)                                                                                     \
+    do {                                                                                                            \
+        if (lds > 48 * 1024)                                                                                        \
+            (void)hipFuncSetAttribute((const void *)admm_mfma_kernel<NX, NU, N, REFS_, XB, WS>,                     \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
+        hipLaunchKernelGGL((admm_mfma_kernel<NX, NU, N, REFS_, XB, WS>), dim3(grid), dim3(256), lds, stream, P);    \
+    } while (0)
     switch (P.ref_mode) {
-        case REF_ZERO:
-            hipLaunchKernelGGL((admm_mfma_kernel<NX, NU, N, REF_ZERO, XB>), dim3(grid), dim3(256), 0, stream, P);
-            break;
-        case REF_SHARED:
-            hipLaunchKernelGGL((admm_mfma_kernel<NX, NU, N, REF_SHARED, XB>), dim3(grid), dim3(256), 0, stream, P);
-            break;
-        default:
-            hipLaunchKernelGGL((admm_mfma_kernel<NX, NU, N, REF_PER_INSTANCE, XB>), dim3(grid), dim3(256), 0, stream, P);
-            break;
+        case REF_ZERO: TMPC_MFMA_LAUNCH(REF_ZERO); break;
+        case REF_SHARED: TMPC_MFMA_LAUNCH(REF_SHARED); break;
+        default: TMPC_MFMA_LAUNCH(REF_PER_INSTANCE); break;
     }
+#undef TMPC_MFMA_LAUNCH
     return hipGetLastError();
 }
 
-// precision is ignored: the matrix cores run the recurrences in fp64 (the kernel is only selected for precision 0)
+// precision is ignored: the matrix cores run the recurrences in fp64 (the kernel is only selected for precision 0).
+// A launch that reads or keeps the workspace takes the WS variant (old slack parked in LDS).  `state_bounds_active`
+// here also covers "the workspace's state dual may be non-zero" (Solver::launch_pass) — only then is g carried.
 template <int NX, int NU, int N>
 hipError_t launch_mfma(const AdmmParams &P, int /*precision*/, bool state_bounds_active, hipStream_t stream) {
-    return state_bounds_active ? launch_mfma_xb<NX, NU, N, true>(P, stream) : launch_mfma_xb<NX, NU, N, false>(P, stream);
+    if (!P.cold_start || P.save_state)
+        return state_bounds_active ? launch_mfma_xb<NX, NU, N, true, true>(P, stream)
+                                   : launch_mfma_xb<NX, NU, N, false, true>(P, stream);
+    return state_bounds_active ? launch_mfma_xb<NX, NU, N, true, false>(P, stream)
+                               : launch_mfma_xb<NX, NU, N, false, false>(P, stream);
 }
 
 #define TMPC_DEFINE_MFMA_ENTRY(NX, NU, NN)                                                                 \

@@ -130,6 +130,7 @@ struct Solver {
     int mpc_cap = 0, mpc_steps_last = 0;
     size_t scratch_cap = 0;
     bool solved_once = false;
+    bool g_maybe_nonzero = false;  // the workspace's state dual may hold non-zeros (see launch_pass)
     bool profiling = false;
     static constexpr int EV_RING = 256;  // event pairs around the most recent launches (profiling mode)
     std::vector<hipEvent_t> ev_ring;     // [2 * EV_RING], created on first use
@@ -145,7 +146,7 @@ struct Solver {
     int init_families(const double *A_, const double *B_, const double *Q_, const double *R_, const double *rho_,
                       int nx_, int nu_, int N_, int batch_, int device_, int verbose_);
     int alloc_batch(int batch_);
-    int select_kernel();
+    int select_kernel(bool rollout = false);  // rollout: the next launch is the fused closed loop (quad kernel only)
     void free_batch();
     int upload_packs();
     int upload_refs();

@@ -266,7 +266,7 @@ int Solver::init_families(const double *A_, const double *B_, const double *Q_, 
 
 // Picks the kernel variant for (shape, batch).  TINYMPC_HIP_GROUP=1|2|4 forces a lanes-per-instance
 // variant (tuning aid); shapes without a specialised kernel run on the generic one.
-int Solver::select_kernel() {
+int Solver::select_kernel(bool rollout) {
     const char *genv = std::getenv("TINYMPC_HIP_GROUP");
     const KernelEntry *k = genv ? find_quad_kernel(nx, nu, N, std::atoi(genv)) : nullptr;
     if (!k) k = select_quad_kernel(nx, nu, N, batch);
@@ -279,8 +279,11 @@ int Solver::select_kernel() {
         k = nullptr;  // adaptive rho: generic kernel only (per-instance rho, Kinf, Pinf in HBM)
     }
     if (std::getenv("TINYMPC_HIP_NO_QUAD")) k = nullptr;    // tuning aid: time the fallback kernels on any shape
-    // one-shot solves (cold start, workspace not kept) with fp64 recurrences: the matrix-core kernel of the shape
-    if (k && !warm_start && precision == 0 && chunk_iters == 0 && !genv && !std::getenv("TINYMPC_HIP_NO_MFMA"))
+    // plain solves with fp64 recurrences: the matrix-core kernel of the shape (the fused closed loop stays on the quad
+    // kernel; TINYMPC_HIP_MFMA_ONESHOT_ONLY=1 keeps workspace-carrying solves there too — tuning aid)
+    const bool mfma_ws_ok = !std::getenv("TINYMPC_HIP_MFMA_ONESHOT_ONLY");
+    if (k && !rollout && (mfma_ws_ok || (!warm_start && chunk_iters == 0)) && precision == 0 && !genv &&
+        !std::getenv("TINYMPC_HIP_NO_MFMA"))
         if (const KernelEntry *m = find_mfma_kernel(nx, nu, N)) k = m;
     if (!k && (nx > GEN_MAX_NX || nu > GEN_MAX_NU)) {
         set_error("problem shape exceeds the generic kernel limits (nx <= 64, nu <= 32)");
@@ -368,6 +371,7 @@ int Solver::reset() {
         HIP_TRY(hipMemset(d_szl, 0, Bn * EU * sizeof(float)));
     }
     adapt_dirty = true;  // adapted (rho, Kinf, Pinf) go back to the family's cache
+    g_maybe_nonzero = false;
     return 0;
 }
 
@@ -701,7 +705,7 @@ __global__ void compact_unsolved_kernel(const int *solved, const int *idx_in, in
 
 int Solver::solve_async(hipStream_t stream, int mpc_steps) {
     HIP_TRY(hipSetDevice(device));
-    if (select_kernel() || ensure_extension_buffers()) return -1;
+    if (select_kernel(mpc_steps > 0) || ensure_extension_buffers()) return -1;
     const bool chunkable = chunk_iters > 0 && mpc_steps == 0 && !hetero && (ke || se) && st.check_termination > 0 &&
                            st.abs_pri_tol > 0.0 && st.abs_dua_tol > 0.0 && st.max_iter > chunk_iters;
     if (chunkable) return solve_chunked(stream);
@@ -853,7 +857,11 @@ int Solver::launch_pass(hipStream_t stream, int mpc_steps, const int *idx, int n
         ev1 = ev_ring[2 * (launches % EV_RING) + 1];
         HIP_TRY(hipEventRecord(ev0, stream));
     }
-    HIP_TRY(ke ? ke->launch(P, precision, state_bounds_active, stream)
+    // the workspace's state dual is non-zero only if some solve since the last reset had a finite state bound (or the
+    // caller wrote one in): the matrix-core kernel (G == 16) carries g only then
+    if (state_bounds_active && save) g_maybe_nonzero = true;
+    const bool carry_g = state_bounds_active || (ke && ke->G == 16 && g_maybe_nonzero);
+    HIP_TRY(ke ? ke->launch(P, precision, carry_g, stream)
                : (se ? se->launch(P, precision, lin_active() ? 2 : ((has_fdyn || cones_active()) ? 1 : 0), hetero, stream)
                      : launch_generic(P, precision, stream)));
     if (profiling) {
@@ -986,6 +994,7 @@ int Solver::set_workspace(const double *d, const double *y, const double *g, con
     if (h2d_float(d_sd, d, Bn * EU) || h2d_float(d_sy, y, Bn * EU) || h2d_float(d_sz, z, Bn * EU) ||
         h2d_float(d_sg, g, Bn * EX) || h2d_float(d_sv, v, Bn * EX))
         return -1;
+    g_maybe_nonzero = true;
     return 0;
 }
 
