@@ -562,15 +562,21 @@ def test_fused_mpc_rollout_vs_golden(hip_lib, name):
     bs.close()
 
 
-def test_fused_mpc_rollout_batch_vs_oracle(hip_lib, oracle_built):
+@pytest.mark.parametrize("family,kernel", [("cartpole", "quad<4,1,20"), ("quadrotor", "mfma<12,4,30")])
+def test_fused_mpc_rollout_batch_vs_oracle(hip_lib, oracle_built, family, kernel):
     """A batch of closed loops (different x0 per instance, input bound active early on) against the
-    fp64 oracle driven step by step on the host."""
+    fp64 oracle driven step by step on the host: fused into one launch on the quad kernel (cartpole), as a
+    stream-ordered chain of workspace-carrying solves and plant updates on the matrix-core kernel (quadrotor)."""
     B, steps = 24, 15
-    prob = t.problems.cartpole(20, u_bound=0.8)
-    x0 = t.problems.cartpole_x0(B, seed=31)
+    if family == "cartpole":
+        prob = t.problems.cartpole(20, u_bound=0.8)
+        x0 = t.problems.cartpole_x0(B, seed=31)
+    else:
+        prob = t.problems.quadrotor(30)
+        x0 = t.problems.quadrotor_x0(B, seed=31)
     kw = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=10, check_termination=1)
-    ref_u = np.zeros((1, steps, B))
-    ref_x = np.zeros((4, steps, B))
+    ref_u = np.zeros((prob.nu, steps, B))
+    ref_x = np.zeros((prob.nx, steps, B))
     ref_it = np.zeros((steps, B), dtype=int)
     for b in range(B):
         o = oracle_built.CpuSolver("orc64", prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N)
@@ -588,6 +594,7 @@ def test_fused_mpc_rollout_batch_vs_oracle(hip_lib, oracle_built):
     bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
     bs.set_x0(x0)
     log = bs.mpc_rollout(steps)
+    assert bs.kernel_name.startswith(kernel)
     # iteration counts decide the trajectory; allow a rare +-1 near the tolerance, then compare the rest
     same = np.all(log["iter"] == ref_it, axis=0)
     assert same.mean() >= 0.9
@@ -1186,7 +1193,7 @@ def test_matrix_core_kernel_vs_oracle(hip_lib, oracle_built, monkeypatch, case):
     bs.solve()
     assert bs.kernel_name.startswith("mfma<")
     bs.mpc_rollout(2)
-    assert bs.kernel_name.startswith("quad<")
+    assert bs.kernel_name.startswith("mfma<")
     bs.close()
 
 

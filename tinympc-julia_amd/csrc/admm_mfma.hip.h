@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256) void admm_mfma_kernel(const AdmmParams P) {
     float xr[REFS == REF_PER_INSTANCE ? N : 1][VX], ur[REFS == REF_PER_INSTANCE ? N - 1 : 1];
     double x0[VX];
 #pragma unroll
-    for (int v = 0; v < VX; ++v) x0[v] = (active && xok[v]) ? (double)P.x0[b * NX + 4 * v + g] : 0.0;
+    for (int v = 0; v < VX; ++v)
+        x0[v] = (active && xok[v]) ? (P.x0d ? P.x0d[b * NX + 4 * v + g] : (double)P.x0[b * NX + 4 * v + g]) : 0.0;
 #pragma unroll
     for (int k = 0; k < N; ++k)
 #pragma unroll

@@ -28,6 +28,7 @@ struct AdmmParams {
     const float *bounds;  // per-knot bounds pack
     // per-instance inputs
     const float *x0;    // [B][nx]
+    const double *x0d;  // matrix-core kernel, closed loop: the plant state in fp64 (NULL: x0)
     const float *xref;  // REF_SHARED: [N][nx]   REF_PER_INSTANCE: [B][N][nx]
     const float *uref;  // REF_SHARED: [N-1][nu] REF_PER_INSTANCE: [B][N-1][nu]
     // per-instance outputs

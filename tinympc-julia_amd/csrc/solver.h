@@ -130,6 +130,7 @@ struct Solver {
     int mpc_cap = 0, mpc_steps_last = 0;
     size_t scratch_cap = 0;
     bool solved_once = false;
+    bool rollout_quad = false;     // the pending closed loop runs fused on the quad kernel
     bool g_maybe_nonzero = false;  // the workspace's state dual may hold non-zeros (see launch_pass)
     bool profiling = false;
     static constexpr int EV_RING = 256;  // event pairs around the most recent launches (profiling mode)
@@ -167,6 +168,11 @@ struct Solver {
     // tolerance-terminated solves of big batches in chunks of `chunk_iters` iterations: after each chunk the
     // instances still iterating are compacted, so wavefronts do not idle behind their slowest instance
     int solve_chunked(hipStream_t stream);
+    // closed loop on the matrix-core kernel: per step one WS launch and a plant-update kernel, stream-ordered, the plant
+    // state kept in fp64 on the device between steps (what the quad kernel's fused loop keeps in registers)
+    int rollout_steps(hipStream_t stream, int mpc_steps);
+    double *d_plant = nullptr, *d_x0d = nullptr;  // [A | B] column-major fp64; [B][nx] plant state
+    const double *x0d_launch = nullptr;           // handed to the next launch_pass
     int chunk_iters = 0;  // 0: off
     int *d_idx[2] = {nullptr, nullptr};
     int *d_count = nullptr;

@@ -140,6 +140,7 @@ Solver::~Solver() {
     dev_free(d_bounds);
     dev_free(d_gstat);
     dev_free(d_sens);
+    dev_free(d_plant);
     if (h_gstat) (void)hipHostFree(h_gstat);
     h_gstat = nullptr;
     for (hipEvent_t e : ev_ring)
@@ -179,6 +180,7 @@ void Solver::free_batch() {
     dev_free(d_syl);
     dev_free(d_szl);
     dev_free(d_adapt);
+    dev_free(d_x0d);
     adapt_dirty = true;
     dev_free(d_mpc_x);
     dev_free(d_mpc_u);
@@ -282,7 +284,9 @@ int Solver::select_kernel(bool rollout) {
     // plain solves with fp64 recurrences: the matrix-core kernel of the shape (the fused closed loop stays on the quad
     // kernel; TINYMPC_HIP_MFMA_ONESHOT_ONLY=1 keeps workspace-carrying solves there too — tuning aid)
     const bool mfma_ws_ok = !std::getenv("TINYMPC_HIP_MFMA_ONESHOT_ONLY");
-    if (k && !rollout && (mfma_ws_ok || (!warm_start && chunk_iters == 0)) && precision == 0 && !genv &&
+    if (rollout && (!mfma_ws_ok || !warm_start)) rollout_quad = true;  // else: rollout_steps() on the matrix-core kernel
+    else rollout_quad = false;
+    if (k && !(rollout && rollout_quad) && (mfma_ws_ok || (!warm_start && chunk_iters == 0)) && precision == 0 && !genv &&
         !std::getenv("TINYMPC_HIP_NO_MFMA"))
         if (const KernelEntry *m = find_mfma_kernel(nx, nu, N)) k = m;
     if (!k && (nx > GEN_MAX_NX || nu > GEN_MAX_NU)) {
@@ -709,6 +713,7 @@ int Solver::solve_async(hipStream_t stream, int mpc_steps) {
     const bool chunkable = chunk_iters > 0 && mpc_steps == 0 && !hetero && (ke || se) && st.check_termination > 0 &&
                            st.abs_pri_tol > 0.0 && st.abs_dua_tol > 0.0 && st.max_iter > chunk_iters;
     if (chunkable) return solve_chunked(stream);
+    if (mpc_steps > 0 && ke && ke->G == 16) return rollout_steps(stream, mpc_steps);
     return launch_pass(stream, mpc_steps, nullptr, batch, 0, st.max_iter, !warm_start, warm_start);
 }
 
@@ -780,6 +785,7 @@ int Solver::launch_pass(hipStream_t stream, int mpc_steps, const int *idx, int n
     P.coef = reinterpret_cast<const float *>(d_coef);
     P.bounds = d_bounds;
     P.x0 = d_x0;
+    P.x0d = x0d_launch;
     P.xref = d_xref;
     P.uref = d_uref;
     P.xout = d_xout;
@@ -871,6 +877,72 @@ int Solver::launch_pass(hipStream_t stream, int mpc_steps, const int *idx, int n
     // the status block stays on the device; solve_status() fetches it when asked (nothing but the kernel and the
     // 32-byte clear is enqueued per solve)
     solved_once = true;
+    return 0;
+}
+
+// x0d <- x0 (start of a closed loop)
+__global__ void plant_init_kernel(double *x0d, const float *x0, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x0d[i] = (double)x0[i];
+}
+
+// One closed-loop step after a solve (cartpole_example_mpc.jl:35-51): u0 = first column of the solution,
+// x0 <- A x0 + B u0 in fp64, logged like the quad kernel's fused loop does (iteration count signed by the solved flag).
+__global__ void plant_step_kernel(double *x0d, float *x0, const float *uout, const int *iter, const int *solved,
+                                  const double *AB, float *mpc_x, float *mpc_u, int *mpc_iter, int nx, int nu, int N,
+                                  long batch, int steps, int step) {
+    const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const double *A = AB, *Bm = AB + nx * nx;
+    const float *u0 = uout + b * (long)nu * (N - 1);
+    const long so = b * steps + step;
+    double xn[GEN_MAX_NX];
+    for (int r = 0; r < nx; ++r) {
+        double acc = 0.0;
+        for (int j = 0; j < nx; ++j) acc = fma(A[r + j * nx], x0d[b * nx + j], acc);
+        for (int a = 0; a < nu; ++a) acc = fma(Bm[r + a * nx], (double)u0[a], acc);
+        xn[r] = acc;
+    }
+    for (int r = 0; r < nx; ++r) {
+        x0d[b * nx + r] = xn[r];
+        x0[b * nx + r] = (float)xn[r];
+        mpc_x[so * nx + r] = (float)xn[r];
+    }
+    for (int a = 0; a < nu; ++a) mpc_u[so * nu + a] = u0[a];
+    mpc_iter[so] = solved[b] ? iter[b] : -iter[b];
+}
+
+int Solver::rollout_steps(hipStream_t stream, int mpc_steps) {
+    if (!warm_start) {
+        set_error("mpc_rollout needs the persistent workspace (set_warm_start(1))");
+        return -1;
+    }
+    const size_t Bn = (size_t)batch;
+    if (mpc_cap < mpc_steps) {
+        const size_t n = Bn * mpc_steps;
+        if (dev_alloc(d_mpc_x, n * nx) || dev_alloc(d_mpc_u, n * nu) || dev_alloc(d_mpc_iter, n)) return -1;
+        mpc_cap = mpc_steps;
+    }
+    if (!d_x0d && dev_alloc(d_x0d, Bn * nx)) return -1;
+    if (!d_plant) {
+        if (dev_alloc(d_plant, (size_t)nx * nx + (size_t)nx * nu)) return -1;
+        std::vector<double> ab(A.a);
+        ab.insert(ab.end(), B.a.begin(), B.a.end());
+        HIP_TRY(hipMemcpy(d_plant, ab.data(), ab.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    const long n0 = (long)Bn * nx;
+    plant_init_kernel<<<(unsigned)((n0 + 255) / 256), 256, 0, stream>>>(d_x0d, d_x0, n0);
+    for (int step = 0; step < mpc_steps; ++step) {
+        x0d_launch = d_x0d;
+        const int rc = launch_pass(stream, 0, nullptr, batch, 0, st.max_iter, false, true);
+        x0d_launch = nullptr;
+        if (rc) return -1;
+        plant_step_kernel<<<(unsigned)((Bn + 255) / 256), 256, 0, stream>>>(d_x0d, d_x0, d_uout, d_iter, d_solved, d_plant,
+                                                                        d_mpc_x, d_mpc_u, d_mpc_iter, nx, nu, N,
+                                                                        (long)Bn, mpc_steps, step);
+    }
+    HIP_TRY(hipGetLastError());
+    mpc_steps_last = mpc_steps;
     return 0;
 }
 
