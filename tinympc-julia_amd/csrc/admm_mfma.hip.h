@@ -9,10 +9,9 @@
 // v = 0, 1, 2) and input row g (register v = 3), a RESULT IS ALREADY LAID OUT AS THE NEXT PRODUCT'S B OPERAND: register
 // s of lane group g is row 4 s + g, i.e. K-slice s.  The whole forward / backward recurrence chains MFMAs without a
 // single cross-lane move:
-//     forward  : c = {0, 0, 0, -d};  c += [A; -Kinf] x (one MFMA per K-slice)  ->  c[0..2] = A x,  c[3] = u = -d - Kinf x
-//                c += [B; 0] u                                                 ->  c[0..2] = x+
-//     backward : c = {q, r};         c += [AmBKt; B^T] p                       ->  c[0..2] = q + AmBKt p,  c[3] = B^T p + r
-//                d = [0; Quu_inv] c[3];   c += [-Kinf^T; 0] r                  ->  c[0..2] = p-
+//     forward  : c = [B; 0] (-d);  c += [A - B Kinf; -Kinf] x (one MFMA per K-slice)  ->  c[0..2] = x+,  u = c[3] - d
+//     backward : c = {q, r} + [-Kinf^T; 0] r;  c += [AmBKt; B^T] p              ->  c[0..2] = p-,  c[3] = B^T p + r
+//                d = [0; Quu_inv] c[3], issued one knot later
 // with the stacked matrices ([A; -Kinf] is 16 x 12 for the quadrotor: a full tile) spread over the 64 lanes, three
 // doubles per lane and matrix, held in registers for the whole solve: no LDS coefficient traffic, no DPP broadcasts,
 // and the 48 + 48 fp64 FMAs per lane and knot pair of the quad kernel leave the VALU, which does the elementwise
@@ -227,12 +226,19 @@ __global__ __launch_bounds__(256) void admm_mfma_kernel(const AdmmParams P) {
         mf_for<0, N>([&](auto kk) {
             constexpr int k = decltype(kk)::value;
             asm volatile("" ::: "memory");  // LDS constants (bounds, shared references) are re-read per knot, not hoisted
+            // x+ = A x + B u, u = -Kinf x - d, regrouped as ONE accumulation chain that never waits for u and whose first
+            // product does not depend on x at all (the matrix core runs it while the previous knot's result drains):
+            //   c = [B; 0] (-d);   c += [A - B Kinf; -Kinf] x      ->  c[0..2] = x+,  c[3] = -Kinf x  (u = c[3] - d)
+            // fp64 throughout: the regrouping moves results by a few 1e-16.  The chain starts from the constant-zero
+            // accumulator (an inline operand), so no register tuple is initialised or copied between knots.
             mf_d4 c = {0.0, 0.0, 0.0, 0.0};
+            double nd = 0.0;
             if constexpr (k < N - 1) {
-                c[3] = -(double)sd[k];
+                nd = -(double)sd[k];
+                c = mf_mma(cf[S::O_BF], nd, c);                                // [B; 0] (-d)
                 mf_for<0, VX>([&](auto ss) {
                     constexpr int s = decltype(ss)::value;
-                    c = mf_mma(cf[S::O_MF + s], x[s], c);                      // [A; -Kinf] x
+                    c = mf_mma(cf[S::O_MF + s], x[s], c);                      // + [A - B Kinf; -Kinf] x
                 });
             }
             // slack / dual of the state rows at this knot (the matrix core works on the products meanwhile)
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(256) void admm_mfma_kernel(const AdmmParams P) {
             for (int v = 0; v < VX; ++v) {
                 const float xf = (float)x[v];
                 const float gk = XB ? sg[XB ? k : 0][v] : 0.f;
-                float vn = xf + gk;
+                float vn = XB ? xf + gk : xf;
                 if constexpr (XB) {
                     const float lo = xok[v] ? s_bnd[S::B_XMIN + k * NX + 4 * v + g] : -kInf;
                     const float hi = xok[v] ? s_bnd[S::B_XMAX + k * NX + 4 * v + g] : kInf;
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(256) void admm_mfma_kernel(const AdmmParams P) {
                 sw[k][v] = vn;
             }
             if constexpr (k < N - 1) {
-                const double u = c[3];                                         // -d - Kinf x
+                const double u = c[3] + nd;                                    // -Kinf x - d
                 const float uf = (float)u, yk = sy[k];
                 float zn = uf + yk;
                 const float lo = uok ? s_bnd[S::B_UMIN + k * NU + g] : -kInf, hi = uok ? s_bnd[S::B_UMAX + k * NU + g] : kInf;
@@ -269,8 +275,6 @@ __global__ __launch_bounds__(256) void admm_mfma_kernel(const AdmmParams P) {
                 if constexpr (WS)
                     if (uok) s_old[(N * NX + k * NU + g) * 64 + inst] = szw[k];
                 szw[k] = zn;
-                c[3] = 0.0;
-                c = mf_mma(cf[S::O_BF], u, c);                                 // + [B; 0] u
 #pragma unroll
                 for (int v = 0; v < VX; ++v) x[v] = c[v];
             }
@@ -309,6 +313,10 @@ __global__ __launch_bounds__(256) void admm_mfma_kernel(const AdmmParams P) {
 #pragma unroll
             for (int v = 0; v < VX; ++v) p[v] = -c[v] - (double)(rho * (sw[N - 1][v] - (XB ? sg[XB ? N - 1 : 0][v] : 0.f)));
         }
+        // p- = q + AmBKt p - Kinf^T r and d = Quu_inv (B^T p + r), again ordered for the matrix core: the product that
+        // does not depend on p opens the chain, and the d product of a knot is issued one knot later, when its operand
+        // has long drained — the chain p -> p- is the only thing the sweep ever waits for.
+        double t_pend = 0.0;                                                   // B^T p + r of the knot above
         mf_for<0, N - 1>([&](auto kk) {
             constexpr int k = N - 2 - decltype(kk)::value;
             constexpr std::integral_constant<int, k> kc{};
@@ -321,17 +329,25 @@ __global__ __launch_bounds__(256) void admm_mfma_kernel(const AdmmParams P) {
                                          rho * (sw[k][v < VX ? v : 0] - (XB ? sg[XB ? k : 0][v < VX ? v : 0] : 0.f)))
                               : 0.0;
             c[3] = r;
+            c = mf_mma(cf[S::O_KT], r, c);                                     // {q, r} + [-Kinf^T; 0] r
+            if constexpr (k < N - 2) {
+                mf_d4 dq = {0.0, 0.0, 0.0, 0.0};
+                dq = mf_mma(cf[S::O_QI], t_pend, dq);                          // [0; Quu_inv] (B^T p + r) of knot k + 1
+                sd[k + 1] = (float)dq[3];
+            }
             mf_for<0, VX>([&](auto ss) {
                 constexpr int s = decltype(ss)::value;
-                c = mf_mma(cf[S::O_MB + s], p[s], c);                          // [AmBKt; B^T] p
+                c = mf_mma(cf[S::O_MB + s], p[s], c);                          // + [AmBKt; B^T] p
             });
-            mf_d4 dq = {0.0, 0.0, 0.0, 0.0};
-            dq = mf_mma(cf[S::O_QI], c[3], dq);                                // [0; Quu_inv] (B^T p + r)
-            sd[k] = (float)dq[3];
-            c = mf_mma(cf[S::O_KT], r, c);                                     // + [-Kinf^T; 0] r
+            t_pend = c[3];
 #pragma unroll
             for (int v = 0; v < VX; ++v) p[v] = c[v];
         });
+        {
+            mf_d4 dq = {0.0, 0.0, 0.0, 0.0};
+            dq = mf_mma(cf[S::O_QI], t_pend, dq);
+            sd[0] = (float)dq[3];
+        }
     }
 
     if (active && !conv) {

@@ -25,7 +25,8 @@ void build_mfma_coef(const Solver &sv, std::vector<unsigned char> &out) {
             double mf = 0.0, mb = 0.0, pt = 0.0;
             if (col < NX) {
                 if (xrow) {
-                    mf = sv.A(i, col);
+                    mf = sv.A(i, col);              // (A - B Kinf)[i][col], from A, B, Kinf themselves (set_cache_terms may
+                    for (int a2 = 0; a2 < NU; ++a2) mf -= sv.B(i, a2) * c.Kinf(a2, col);   // hand in an AmBKt that differs)
                     mb = c.AmBKt(i, col);
                     pt = c.Pinf(col, i);            // (Pinf^T)[i][col]
                 } else if (urow) {
