@@ -35,6 +35,13 @@ namespace tmpc {
 
 typedef double mf_d4 __attribute__((ext_vector_type(4)));
 
+#ifndef TMPC_MFMA_INTERLEAVE_B
+#define TMPC_MFMA_INTERLEAVE_B 0  // same for the backward sweep (measured: no gain)
+#endif
+#ifndef TMPC_MFMA_INTERLEAVE
+#define TMPC_MFMA_INTERLEAVE 6  // > 0: VALU instructions the scheduler is asked to place after each matrix product
+#endif
+
 template <int NX, int NU, int N>
 struct MfmaShape {
     static_assert(NX >= 1 && NX <= 12 && NU >= 1 && NU <= 4, "mfma kernel: nx <= 12, nu <= 4");
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(256) void admm_mfma_kernel(const AdmmParams P) {
         const bool need_res = check && (can_converge || i + 1 == last_check_it);
         // ================= fused forward sweep (admm.cpp:25-69, :93-96) =================
         float pri_x = 0.f, dua_x = 0.f, pri_u = 0.f, dua_u = 0.f;
-        double x[VX];
+        double x[VX], c3_pend = 0.0, nd_pend = 0.0;
 #pragma unroll
         for (int v = 0; v < VX; ++v) x[v] = x0[v];
         mf_for<0, N>([&](auto kk) {
@@ -261,22 +268,36 @@ __global__ __launch_bounds__(256) void admm_mfma_kernel(const AdmmParams P) {
                     if (xok[v]) s_old[(k * NX + 4 * v + g) * 64 + inst] = sw[k][v];  // unconditional: no branch in the knot
                 sw[k][v] = vn;
             }
-            if constexpr (k < N - 1) {
-                const double u = c[3] + nd;                                    // -Kinf x - d
-                const float uf = (float)u, yk = sy[k];
+            // slack / dual of the input row of the knot BEFORE (its u left the matrix core while this knot's chain was being
+            // issued): by then nothing here waits for a result
+            if constexpr (k >= 1) {
+                constexpr int j = k - 1;
+                const double u = c3_pend + nd_pend;                            // -Kinf x - d
+                const float uf = (float)u, yk = sy[j];
                 float zn = uf + yk;
-                const float lo = uok ? s_bnd[S::B_UMIN + k * NU + g] : -kInf, hi = uok ? s_bnd[S::B_UMAX + k * NU + g] : kInf;
+                const float lo = uok ? s_bnd[S::B_UMIN + j * NU + g] : -kInf, hi = uok ? s_bnd[S::B_UMAX + j * NU + g] : kInf;
                 zn = fminf(hi, fmaxf(lo, zn));
-                sy[k] = (yk + uf) - zn;
+                sy[j] = (yk + uf) - zn;
                 if (need_res) {
                     pri_u = fmaxf(pri_u, fabsf(uf - zn));
-                    dua_u = fmaxf(dua_u, fabsf(szw[k] - zn));
+                    dua_u = fmaxf(dua_u, fabsf(szw[j] - zn));
                 }
                 if constexpr (WS)
-                    if (uok) s_old[(N * NX + k * NU + g) * 64 + inst] = szw[k];
-                szw[k] = zn;
+                    if (uok) s_old[(N * NX + j * NU + g) * 64 + inst] = szw[j];
+                szw[j] = zn;
+            }
+            if constexpr (k < N - 1) {
+                c3_pend = c[3];
+                nd_pend = nd;
 #pragma unroll
                 for (int v = 0; v < VX; ++v) x[v] = c[v];
+                if constexpr (TMPC_MFMA_INTERLEAVE > 0) {  // one matrix product, then a share of the knot's VALU work, ...
+#pragma unroll
+                    for (int q4 = 0; q4 < 1 + VX; ++q4) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, TMPC_MFMA_INTERLEAVE, 0);
+                    }
+                }
             }
         });
         it += 1;
@@ -342,6 +363,13 @@ __global__ __launch_bounds__(256) void admm_mfma_kernel(const AdmmParams P) {
             t_pend = c[3];
 #pragma unroll
             for (int v = 0; v < VX; ++v) p[v] = c[v];
+            if constexpr (TMPC_MFMA_INTERLEAVE_B > 0) {
+#pragma unroll
+                for (int q5 = 0; q5 < 2 + VX; ++q5) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x002, TMPC_MFMA_INTERLEAVE_B, 1);
+                }
+            }
         });
         {
             mf_d4 dq = {0.0, 0.0, 0.0, 0.0};
