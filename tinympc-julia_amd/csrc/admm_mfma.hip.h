@@ -35,6 +35,12 @@ namespace tmpc {
 
 typedef double mf_d4 __attribute__((ext_vector_type(4)));
 
+#ifndef TMPC_MFMA_TWO_WAVES
+#define TMPC_MFMA_TWO_WAVES 1
+#endif
+#ifndef TMPC_MFMA_TWO_WAVES_MAX_STATE
+#define TMPC_MFMA_TWO_WAVES_MAX_STATE 120  // floats of state per lane: N = 20 yes (85 dwords spilled, -3 %), N = 30 no (261 spilled, +-0)
+#endif
 #ifndef TMPC_MFMA_INTERLEAVE_B
 #define TMPC_MFMA_INTERLEAVE_B 0  // same for the backward sweep (measured: no gain)
 #endif
@@ -53,6 +59,11 @@ struct MfmaShape {
                          B_QD = 2 * N * NX + 2 * (N - 1) * NU, B_RD = B_QD + NX, BOUNDS_LEN = B_RD + NU;
     static constexpr int REFS_LEN = N * NX + (N - 1) * NU;  // shared references: xref[N][NX] uref[N-1][NU]
 };
+
+template <int NX>
+constexpr int VXof() {
+    return (NX + 3) / 4;
+}
 
 template <int I, int E, class F>
 __device__ __forceinline__ void mf_for(F &&f) {
@@ -79,8 +90,16 @@ constexpr size_t mfma_ws_lds_bytes() {
     return (size_t)(NX * N + NU * (N - 1)) * 64 * sizeof(float);
 }
 
+// Workgroups per CU the register allocation is held to: 2 (two wavefronts per SIMD, 256 registers each, so one
+// wavefront's VALU work and result latencies hide behind the other's matrix products) where the state is small enough
+// to fit without spilling, else 1.
+template <int NX, int NU, int N, int REFS, bool XB, bool WS>
+constexpr int mfma_blocks_per_cu() {
+    return (TMPC_MFMA_TWO_WAVES && VXof<NX>() * N + 3 * (N - 1) <= TMPC_MFMA_TWO_WAVES_MAX_STATE && !XB && !WS && REFS != REF_PER_INSTANCE) ? 2 : 1;
+}
+
 template <int NX, int NU, int N, int REFS, bool XB, bool WS = false>
-__global__ __launch_bounds__(256) void admm_mfma_kernel(const AdmmParams P) {
+__global__ __launch_bounds__(256, (mfma_blocks_per_cu<NX, NU, N, REFS, XB, WS>())) void admm_mfma_kernel(const AdmmParams P) {
     // XB = false with WS: the caller guarantees that the workspace's state dual is zero and stays zero (no finite
     // state bound now, none since the last reset) — g is then neither loaded, carried nor written.
     using S = MfmaShape<NX, NU, N>;
