@@ -35,7 +35,7 @@ const KernelEntry *mfma_entry_12_4_20();
 // matrix-core kernels (admm_mfma.hip.h): one-shot solves of the shapes instantiated.  The kernel is fully unrolled with its
 // state in registers: rocket N=50 (347 state floats per lane with finite state bounds) spills ~1 000 registers and runs
 // 18 ms against the quad kernel's 5.5, and rocket N=10 fills only 9 of a tile's 16 rows (1.13 ms against 0.74):
-// neither is instantiated.  Quadrotor ([A; -Kinf] is a full 16 x 12): N=30 4.96 against 11.6 ms, N=20 3.1 against 5.9
+// neither is instantiated.  Quadrotor ([A; -Kinf] is a full 16 x 12): N=30 4.13 against 11.6 ms, N=20 2.7 against 5.9
 const KernelEntry *find_mfma_kernel(int nx, int nu, int N) {
     static const KernelEntry *const table[] = {mfma_entry_12_4_30(), mfma_entry_12_4_20()};
     for (const KernelEntry *e : table)
