@@ -5,150 +5,303 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one batched solve of the workload on every rank: BASELINE.json configs[1] —
-cartpole nx=4 nu=1 N=20, u in [-0.5, 0.5], batch 65 536 per GPU, cold start, exactly 100 ADMM
-iterations per instance (tolerances 0).  Inputs are resident in HBM before the timed region.
-One process per GPU; the batch shards with no data-path collective.  The path's only exchange is an
-all-reduce(MAX) over RCCL of the 5-word status block (4 residual maxima + unsolved count) that decides the
-global solve status: the fixed-iteration workload needs it once, after the last solve (SURVEY 8e);
---status-every-step does it after every solve, overlapped with the next one.  scaling = weak (per-GPU batch
-fixed).  Rank 0 prints ONE JSON line.  Before the W warm-up steps the GPU clocks are ramped with 150 ms of untimed
-solves (set-up, like building the solver); the timed region is exactly K steps.
+A "step" is one batched solve of the workload on every rank.  Default workload = BASELINE.json configs[1]:
+cartpole nx=4 nu=1 N=20, u in [-0.5, 0.5], batch 65 536 per GPU, cold start, exactly 100 ADMM iterations per
+instance (tolerances 0); scaling = weak (per-GPU batch fixed).  `--scaling strong` = configs[4]: quadrotor
+nx=12 nu=4 N=30, 2^20 instances IN TOTAL (seed 3), rank r solving the contiguous shard
+sharding.shard_range(2^20, r, N).  Inputs are resident in HBM before the timed region.
+
+One process per GPU.  `--gpus N` with N > 1 and no WORLD_SIZE in the environment makes THIS process a launcher:
+before anything touches a GPU it starts `python -m torch.distributed.run --nproc-per-node N bench.py <same args>`
+as a child process and exits with its code (the ranks are fresh processes; nothing is re-exec'd).  Under a launcher
+(WORLD_SIZE set) the process is a rank and asserts WORLD_SIZE == --gpus.
+
+The batch shards with no data-path collective.  The path's only exchange is an all-reduce(MAX) over RCCL of the
+5-word status block (4 residual maxima + unsolved count) that decides the global solve status: the fixed-iteration
+workload needs it once, after the last solve; `--status-every-step` (and every tolerance-terminated
+run, `--tol`) does it after every solve, overlapped with the next one.  Rank 0 prints ONE JSON line.
+
+Before the W warm-up steps the GPU clocks are ramped with 150 ms of untimed solves (set-up, like building the
+solver); the timed region is exactly K steps, bracketed by barrier + synchronize, max over ranks.
+
+On one GPU the same line also carries `configs`: five timed steps each of BASELINE configs[2] (quadrotor 65 536),
+configs[3] (rocket + cones 32 768) and one rank's shard of configs[4] (quadrotor 131 072, tolerance-terminated),
+each with its kernel time and roofline (`--no-extras` skips them), and `cpu_baseline`.
+
+`--dry --backend gloo` rehearses the launch / sharding / status-fold path on CPUs (no GPU, no solver): the CPU test
+of the N > 1 launch.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector
-FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD MI355X spec: dense fp64 matrix (= fp64 vector) rate
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: peak FP32 vector
+FP64_PEAK_TFLOPS = 78.6       # AMD MI355X spec: fp64 vector = dense fp64 matrix rate (half the FP32 rate of the guide's
+                              # table, 32 FLOP/clk/SIMD; the guide has no fp64 row of its own)
+STRONG_TOTAL = 1 << 20        # BASELINE configs[4]
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="cartpole", choices=["cartpole", "quadrotor", "rocket", "rocket_soc"])
-    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: the config's batch on every GPU (default).  strong: BASELINE configs[4], quadrotor, 2^20 "
+                         "instances in total, contiguous shards")
+    ap.add_argument("--config", default=None, choices=["cartpole", "quadrotor", "rocket", "rocket_soc"])
+    ap.add_argument("--batch", type=int, default=0, help="weak: per-GPU batch; strong: TOTAL batch (default: the config's)")
     ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--tol", type=float, default=0.0,
+                    help="> 0: tolerance-terminated solves (abs_pri_tol = abs_dua_tol = tol) instead of fixed iterations")
+    ap.add_argument("--check-termination", type=int, default=0, help="check interval (default 1; 10 with --tol)")
+    ap.add_argument("--compaction", type=int, default=0, help="tolerance-terminated: chunk size of tinympc_set_compaction")
     ap.add_argument("--precision", type=int, default=0, help="0: fp64 recurrences (default), 1: all fp32")
     ap.add_argument("--mode", default="solve", choices=["solve", "mpc"],
-                    help="solve: BASELINE configs[1] (default).  mpc: warm-started closed loop (SURVEY 8f), extra")
+                    help="solve: the headline.  mpc: additionally the warm-started closed loop (SURVEY 8f)")
     ap.add_argument("--mpc-steps", type=int, default=50)
     ap.add_argument("--mpc-max-iter", type=int, default=10)
     ap.add_argument("--status-every-step", action="store_true",
-                    help="N > 1: all-reduce the status block after every solve (tolerance-terminated use); the default "
-                         "fixed-iteration workload needs no collective (SURVEY 8e) and folds the status once at the end")
+                    help="N > 1: all-reduce the status block after every solve (always on with --tol)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the `configs` block (configs 3, 4, 5-shard)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    return ap.parse_args()
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo only with --dry")
+    ap.add_argument("--dry", action="store_true", help="no GPU, no solver: rehearse launch, sharding and status fold")
+    return ap.parse_args(argv)
 
 
-def make_workload(t, name, batch, rank):
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args):
+    """`--gpus N` without a launcher: start the N ranks as a child `torch.distributed.run` and relay its exit code.
+    Nothing in this process has touched (or will touch) a GPU."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes on this host driver)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# workloads
+# ----------------------------------------------------------------------------------------------------------------------
+def default_batch(name):
+    return 32768 if name.startswith("rocket") else 65536
+
+
+def make_workload(t, name, batch, seed, lo=0, hi=None):
+    """problem family, x0 (nx, hi-lo) = columns [lo, hi) of the seeded batch of `batch` instances, shared references"""
+    import numpy as np
     P = t.problems
+    hi = batch if hi is None else hi
     if name == "cartpole":
-        prob = P.cartpole(20, u_bound=0.5)
-        x0 = P.cartpole_x0(batch, seed=0 + 1000 * rank)
-        refs = None
-        label = "cartpole nx=4 nu=1 N=20 box-only, batch=65536/GPU, fixed 100 ADMM iters, cold start"
+        prob, x0, refs = P.cartpole(20, u_bound=0.5), P.cartpole_x0(batch, seed=seed), None
+        label = "cartpole nx=4 nu=1 N=20 box-only"
     elif name == "quadrotor":
-        prob = P.quadrotor(30, u_bound=0.5)
-        x0 = P.quadrotor_x0(batch, seed=1 + 1000 * rank)
-        refs = None
-        label = "quadrotor nx=12 nu=4 N=30 box, batch=65536/GPU, fixed 100 ADMM iters, cold start"
+        prob, x0, refs = P.quadrotor(30, u_bound=0.5), P.quadrotor_x0(batch, seed=seed), None
+        label = "quadrotor nx=12 nu=4 N=30 box"
     else:
-        prob = P.rocket(50)
-        x0 = P.rocket_x0(batch, seed=2 + 1000 * rank)
-        refs = P.rocket_refs(50)
-        label = "rocket nx=6 nu=3 N=50 box-only sub-problem (no fdyn/SOC), batch=32768/GPU, fixed 100 iters"
+        prob, x0, refs = P.rocket(50), P.rocket_x0(batch, seed=seed), P.rocket_refs(50)
+        label = "rocket nx=6 nu=3 N=50 box-only sub-problem (no fdyn/SOC)"
         if name == "rocket_soc":
-            label = "rocket nx=6 nu=3 N=50 SOC thrust/glide cones + box + fdyn (parity unpinned), batch=32768/GPU, fixed 100 iters"
-    return prob, x0, refs, label
+            label = "rocket nx=6 nu=3 N=50 SOC thrust/glide cones + box + fdyn (parity pinned to the oracle only)"
+    return prob, np.asfortranarray(x0[:, lo:hi]), refs, label
+
+
+def build_solver(t, name, prob, x0, refs, device, iters, tol, check, precision, compaction=0):
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=x0.shape[1], device=device)
+    bs.update_settings(abs_pri_tol=tol, abs_dua_tol=tol, max_iter=iters, check_termination=check)
+    bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    bs.set_precision(precision)
+    if name == "rocket_soc":
+        bs.set_fdyn(prob.fdyn)
+        bs.set_cone_constraints([0], [3], [prob.extra["cone_mu_u"]], [0], [3], [prob.extra["cone_mu_x"]])
+    bs.set_warm_start(False)          # cold start, no state I/O: compulsory traffic only
+    if compaction > 0:
+        bs.set_compaction(compaction)
+    bs.set_x0(x0)                     # H2D once; inputs stay resident in HBM
+    if refs is not None:
+        bs.set_x_ref(refs[0])
+        bs.set_u_ref(refs[1])
+    bs.set_profiling(True)
+    return bs
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# committed counter measurements (static: NOT measured in this run)
+# ----------------------------------------------------------------------------------------------------------------------
+def committed_counters(family, precision, batch, kernel):
+    """rocprofv3 --pmc results committed under profiles/ for exactly this (family, batch, kernel): HBM bytes per launch
+    (separate FETCH_SIZE / WRITE_SIZE passes, FETCH doubled as the gfx950 guide prescribes) and the SQ issue counters.
+    They are replayed from files, not measured here; each carries its source so a stale number can be told."""
+    import glob
+    out = {"traffic": None, "valu_issue": None, "mfma_issue": None, "valu_insts": None, "source": None}
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.isfile(path):
+        for e in json.load(open(path)):
+            if (e["family"], e["precision"], e["batch"], e["kernel"]) == (family, precision, batch, kernel):
+                out["traffic"] = e["hbm_bytes_per_launch"]
+                out["source"] = "profiles/traffic.json (committed rocprofv3 --pmc passes, " + e.get("tag", "r01") + ")"
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{family}_sq_counters.json"))):
+        e = json.load(open(p))
+        if (e.get("kernel"), e.get("batch")) == (kernel, batch) and precision == 0:
+            out["valu_issue"] = e.get("derived_valu_issue_utilisation")
+            out["mfma_issue"] = e.get("derived_mfma_issue_utilisation")
+            out["valu_insts"] = e.get("SQ_INSTS_VALU")
+            out["sq_source"] = "profiles/" + os.path.basename(p) + " (committed)"
+    return out
+
+
+def roofline_of(bs, family, precision, batch, iters_done, k_ms):
+    """roofline + valu objects of one configuration from its kernel time.  Bytes and FLOPs are SURVEY 8(d)'s
+    algorithmic figures (state on chip) x the instances x iterations of one launch."""
+    alg_bytes = bs.algorithmic_bytes()
+    alg_flops = bs.algorithmic_flops(1) * iters_done
+    sec = k_ms * 1e-3
+    ach_gbs, ach_tf = alg_bytes / sec / 1e9, alg_flops / sec / 1e12
+    cc = committed_counters(family, precision, batch, bs.kernel_name)
+    peak_tf = FP64_PEAK_TFLOPS if precision == 0 else FP32_PEAK_TFLOPS
+    roof = {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
+            "traffic": cc["traffic"], "traffic_source": cc["source"], "kernel_ms": k_ms,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "note": "compute-bound path (SURVEY 8d: ~430-950 FLOP/B against a machine balance of ~20): see valu"}
+    valu = {"achieved_tflops": ach_tf, "peak_tflops": peak_tf,
+            "peak_is": "fp64 vector (the recurrences, ~90 % of the FLOPs, run in fp64)" if precision == 0 else "fp32 vector",
+            "frac": ach_tf / peak_tf, "algorithmic_flops_per_launch": alg_flops,
+            "issue_utilisation": cc["valu_issue"], "counters_source": cc.get("sq_source")}
+    if cc["valu_insts"]:
+        # upper bound of what the VALU executed: every wave64 VALU instruction counted as one FMA on 64 lanes
+        valu["executed_flops_upper_bound"] = cc["valu_insts"] * 128.0
+        valu["executed_frac"] = cc["valu_insts"] * 128.0 / sec / 1e12 / peak_tf
+    if bs.kernel_name.startswith("mfma"):
+        roof.update({"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": ach_tf / FP64_PEAK_TFLOPS, "issue_utilisation": cc["mfma_issue"],
+                     "counters_source": cc.get("sq_source"),
+                     "note": "algorithmic FLOPs (SURVEY 8d) over the dense fp64 matrix-core peak; tiles are padded, so the "
+                             "issued MFMA FLOPs are higher (DESIGN.md, mfma kernel)"})
+    if bs.kernel_name.startswith("stream"):
+        roof["note"] = ("run-time-horizon kernel: the per-instance trajectories stream through HBM once per ADMM iteration "
+                        "(traffic >> algorithmic bytes, by design of that kernel; DESIGN.md 3.2)")
+    return roof, valu
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# CPU baseline
+# ----------------------------------------------------------------------------------------------------------------------
+def effective_cpus():
+    """CPUs this process can really use: min(affinity mask, cgroup CPU quota).  A GPU box shows 256 logical CPUs in the
+    affinity mask while the container's cgroup grants a 16-CPU share; threads beyond the quota only time-slice."""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except Exception:
+        aff = os.cpu_count() or 1
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        if q != "max":
+            quota = float(q) / float(p)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())  # cgroup v1
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except Exception:
+            pass
+    eff = aff if quota is None else max(1, min(aff, int(quota + 0.5)))
+    return {"os_cpu_count": os.cpu_count(), "sched_getaffinity": aff, "cgroup_cpu_quota": quota, "effective": eff}
 
 
 def cpu_baseline(prob, x0, refs, iters, seconds):
-    """The reference's own compiled snapshot (oracle/_ref) when its prebuilt .so is present, else our
-    C restatement, threaded over the host cores, on a bounded sample of the same workload."""
+    """The reference's own compiled snapshot (oracle/_ref) when its prebuilt .so is present, else our C restatement,
+    on a bounded sample of the same workload: first one thread (the per-thread rate), then one solver per effective
+    CPU.  `value` is the multi-thread rate."""
     from oracle import cpu_oracle
     kind = "ref" if cpu_oracle.have_ref() else "orc64"
     if kind == "orc64" and not os.path.isfile(cpu_oracle.PORT_LIB):
         cpu_oracle.build(port=True, ref=False)
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        cores = os.cpu_count() or 1
+    cpus = effective_cpus()
+    nthreads = cpus["effective"]
     xr, ur = refs if refs is not None else (None, None)
-    n = min(x0.shape[1], 2048 * cores)
-    done, spent = 0, 0.0
-    while spent < seconds and done < 64 * x0.shape[1]:
-        r = cpu_oracle.solve_batch(kind, prob, x0[:, :n], xref=xr, uref=ur, abs_pri_tol=0.0, abs_dua_tol=0.0,
-                                   max_iter=iters, nthreads=cores, want_outputs=False)
-        done += n
-        spent += r["seconds"]
-    return {"value": done / spent, "unit": "solves/s", "cores": cores,
-            "kind": "reference" if kind == "ref" else "port",
-            "sample": f"{done} cold-start solves of the same workload ({iters} fixed iters) in {spent:.1f} s on "
-                      f"{cores} threads" + (" (compiled reference snapshot, oracle/_ref)" if kind == "ref"
-                                            else " (fp64 C restatement, oracle/)")}
+
+    def run(nt, n, budget):
+        done, spent = 0, 0.0
+        while spent < budget and done < 64 * x0.shape[1]:
+            r = cpu_oracle.solve_batch(kind, prob, x0[:, :n], xref=xr, uref=ur, abs_pri_tol=0.0, abs_dua_tol=0.0,
+                                       max_iter=iters, nthreads=nt, want_outputs=False)
+            done += n
+            spent += r["seconds"]
+        return done, spent
+
+    d1, s1 = run(1, min(x0.shape[1], 2048), min(3.0, seconds / 4))
+    per_thread = d1 / s1
+    # each call starts its threads afresh: size a call at >= ~1 s of work so that start-up stays < 1 %
+    n = int(min(x0.shape[1], max(2048, per_thread * nthreads)))
+    dn, sn = run(nthreads, n, seconds)
+    value = dn / sn
+    what = "compiled reference snapshot, oracle/_ref" if kind == "ref" else "fp64 C restatement, oracle/"
+    return {"value": value, "unit": "solves/s", "cores": nthreads, "kind": "reference" if kind == "ref" else "port",
+            "per_thread": per_thread, "threads_effective": nthreads, "parallel_efficiency": value / (per_thread * nthreads),
+            "cpus": cpus,
+            "sample": f"{dn} cold-start solves of the same workload ({iters} fixed iters) in {sn:.1f} s on {nthreads} threads "
+                      f"({n} per call), after {d1} solves in {s1:.1f} s on 1 thread ({what})"}
 
 
-def streamed_state_bytes(prob, batch, iters, cones, state_bounded=True):
-    """HBM bytes one launch of the run-time-horizon (stream) kernel moves by design: the per-instance trajectories
-    do not fit on chip, so each ADMM iteration streams them through HBM once (stream kernel).  One-shot
-    solve at fixed iterations (no residual check before the last): per knot and iteration the state-shaped arrays
-    cost 3 float transfers per row and set (dual in/out + the fused backward array) and the input-shaped ones 4
-    (d in/out on top), with one extra set each when cones are active."""
-    sets = 2 if cones else 1
-    # without a finite state bound the box set's state dual is identically zero and does not travel
-    per_knot = 4.0 * ((2 * sets + 2 - (0 if state_bounded else 2)) * prob.nx + (2 * sets + 4) * prob.nu)
-    return per_knot * prob.N * iters * batch
+# ----------------------------------------------------------------------------------------------------------------------
+# extra configurations (one GPU): configs 3, 4 and one shard of config 5
+# ----------------------------------------------------------------------------------------------------------------------
+def time_config(t, torch, dev, stream, name, batch, seed, iters=100, tol=0.0, check=1, steps=5, warmup=2, compaction=0):
+    import numpy as np
+    prob, x0, refs, label = make_workload(t, name, batch, seed)
+    bs = build_solver(t, name, prob, x0, refs, dev.index, iters, tol, check, 0, compaction)
+    try:
+        for _ in range(warmup):
+            bs.solve_async(stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            bs.solve_async(stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        ms = 1e3 * (time.perf_counter() - t0) / steps
+        st = bs.get_status()
+        it_mean = float(np.mean(st["iter"]))
+        if tol <= 0.0:
+            assert int(st["iter"].min()) == iters == int(st["iter"].max()), "work skipped"
+        launches_per_step = 1
+        k_ms = bs.kernel_elapsed_ms(steps)
+        if compaction > 0 and tol > 0.0:
+            k_ms, launches_per_step = ms, None      # several launches + compaction kernels per solve: wall time is the figure
+        roof, valu = roofline_of(bs, name, 0, batch, it_mean, k_ms if k_ms > 0 else ms)
+        out = {"workload": f"{label}, batch={batch}, " + (f"tol={tol:g} check every {check}, max_iter={iters}" if tol > 0
+                                                         else f"fixed {iters} ADMM iters") + ", cold start",
+               "ms_per_step": ms, "solves_per_sec": batch / (ms * 1e-3), "kernel": bs.kernel_name, "kernel_ms": k_ms,
+               "mean_iters": it_mean, "unsolved": int((st["solved"] == 0).sum()) if tol > 0 else None,
+               "roofline": roof, "valu": valu, "steps": steps}
+        if launches_per_step is None:
+            out["note"] = f"chunked solve with compaction every {compaction} iterations: kernel_ms = wall time per solve"
+        return out
+    finally:
+        bs.close()
 
 
-def measured_traffic(family, precision, batch, kernel):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json): FETCH_SIZE and
-    WRITE_SIZE collected in separate --pmc runs of this same command; FETCH_SIZE doubled as the gfx950
-    guide prescribes.  None when no matching measurement is committed."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
-    if not os.path.isfile(path):
-        return None
-    for e in json.load(open(path)):
-        if (e["family"], e["precision"], e["batch"], e["kernel"]) == (family, precision, batch, kernel):
-            return e["hbm_bytes_per_launch"]
-    return None
-
-
-def measured_valu_issue(family, batch, kernel):
-    """Fraction of the VALU issue cycles the kernel used, from the committed rocprofv3 SQ counter passes
-    (profiles/*_sq_counters.json: SQ_INSTS_VALU x 4 cycles / (busy cycles x 1 024 SIMDs)); None if not measured."""
-    import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{family}_sq_counters.json"))):
-        e = json.load(open(path))
-        if (e.get("kernel"), e.get("batch")) == (kernel, batch):
-            return e.get("derived_valu_issue_utilisation")
-    return None
-
-
-def measured_mfma_issue(family, batch, kernel):
-    """Fraction of the matrix cores' issue cycles the kernel used (committed rocprofv3 pass: SQ_INSTS_MFMA x 64 cycles
-    over busy cycles x 1 024 SIMDs); None if not measured."""
-    import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{family}_sq_counters.json"))):
-        e = json.load(open(path))
-        if (e.get("kernel"), e.get("batch")) == (kernel, batch):
-            return e.get("derived_mfma_issue_utilisation")
-    return None
-
-
-def run_mpc_mode(args, t, bs, prob, x0, dev, stream, torch):
+def run_mpc_mode(args, bs, prob, x0, dev, torch):
     """Extra (not the headline): the closed-loop regime of SURVEY 8(f) — warm-started solves, max_iter 10,
     tol 1e-3 — as K launches of one step (workspace round-trips through HBM every step) and as one fused
     launch of K steps (workspace stays on chip)."""
@@ -175,18 +328,48 @@ def run_mpc_mode(args, t, bs, prob, x0, dev, stream, torch):
     return res
 
 
+# ----------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.backend == "gloo" and not args.dry:
+        raise SystemExit("--backend gloo is the CPU rehearsal: use it with --dry (the solver has no CPU path)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))          # before torch / HIP are even imported
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    import numpy as np
     import torch
     import torch.distributed as dist
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    from tinympc_julia_amd import sharding
+
+    name = args.config or ("quadrotor" if args.scaling == "strong" else "cartpole")
+    tol = float(args.tol)
+    check = args.check_termination or (10 if tol > 0 else 1)
+    if args.scaling == "strong":
+        total = args.batch or STRONG_TOTAL
+        lo, hi = sharding.shard_range(total, rank, world)
+        seed = 3
+    else:
+        per_gpu = args.batch or default_batch(name)
+        total, lo, hi = per_gpu * world, 0, per_gpu
+        seed = {"cartpole": 0, "quadrotor": 1}.get(name, 2) + 1000 * rank
+    n_local = hi - lo
+    glo, ghi = (lo, hi) if args.scaling == "strong" else (rank * n_local, (rank + 1) * n_local)  # global instance range
+
+    if args.dry:
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     # TINYMPC_BENCH_FORCE_DIST=1: take the multi-rank code path (process group, status all-reduce) on one rank too —
     # a rehearsal of the N > 1 run on a one-GPU box
     dist_on = world > 1 or bool(os.environ.get("TINYMPC_BENCH_FORCE_DIST"))
@@ -199,41 +382,50 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)  # RCCL on ROCm
+            if args.dry:
+                dist.init_process_group(args.backend, rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)  # RCCL on ROCm
             probe = torch.zeros(8, dtype=torch.int32, device=dev)
             dist.all_reduce(probe, op=dist.ReduceOp.MAX)      # brings the communicator up
-            torch.cuda.synchronize(dev)
+            if not args.dry:
+                torch.cuda.synchronize(dev)
         finally:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
+        assert dist.get_world_size() == args.gpus, "process group size differs from --gpus"
 
-    import tinympc_julia_amd as t
-    from tinympc_julia_amd import sharding
+    def sync():
+        if not args.dry:
+            torch.cuda.synchronize(dev)
 
-    batch = args.batch or (32768 if args.config.startswith("rocket") else 65536)
-    prob, x0, refs, label = make_workload(t, args.config, batch, rank)
-    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=batch, device=local_rank)
-    bs.update_settings(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=args.iters, check_termination=1)
-    bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
-    bs.set_precision(args.precision)
-    if args.config == "rocket_soc":
-        bs.set_fdyn(prob.fdyn)
-        bs.set_cone_constraints([0], [3], [prob.extra["cone_mu_u"]], [0], [3], [prob.extra["cone_mu_x"]])
-    bs.set_warm_start(False)          # cold start, no state I/O: compulsory traffic only
-    bs.set_x0(x0)                     # H2D once; inputs stay resident in HBM
-    if refs is not None:
-        bs.set_x_ref(refs[0])
-        bs.set_u_ref(refs[1])
-    bs.set_profiling(True)
-    stream = torch.cuda.current_stream(dev)
-    gstat = sharding.device_tensor(bs.device_buffers()["gstat"], (8,), torch.int32, dev)
+    if args.dry:
+        # no solver: the rank's "status block" is a CPU tensor carrying its shard bounds, so that the fold below
+        # proves every rank took part (max hi == total) — the launch / sharding / exchange path, nothing else
+        t = bs = prob = x0 = refs = None
+        label = f"{name} (dry run: no solves)"
+        gstat = torch.zeros(8, dtype=torch.int32)
+        stream = None
+    else:
+        import tinympc_julia_amd as t
+        if args.scaling == "strong":
+            prob, x0, refs, label = make_workload(t, name, total, seed, lo, hi)
+        else:
+            prob, x0, refs, label = make_workload(t, name, n_local, seed)
+        bs = build_solver(t, name, prob, x0, refs, local_rank, args.iters, tol, check, args.precision, args.compaction)
+        stream = torch.cuda.current_stream(dev)
+        gstat = sharding.device_tensor(bs.device_buffers()["gstat"], (8,), torch.int32, dev)
 
+    every_step = dist_on and (args.status_every_step or tol > 0)
     pending = []
 
     def step():
-        bs.solve_async(stream.cuda_stream)
-        if dist_on and args.status_every_step:
+        if args.dry:
+            gstat[5], gstat[6] = glo, ghi
+        else:
+            bs.solve_async(stream.cuda_stream)
+        if every_step:
             # global max residuals / unsolved count (16 + 4 bytes) after every solve: started on a snapshot of the
             # status block and awaited at the fence, so it overlaps the next solve
             pending.append(sharding.allreduce_status_async(gstat, force=True))
@@ -243,91 +435,102 @@ def main():
             if work is not None:
                 work.wait()
         del pending[:-1]          # the last one carries the global status of the last solve
-        torch.cuda.synchronize(dev)
+        sync()
         if dist_on:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        sync()
 
-    # clock pre-warm (set-up, not a step): the first milliseconds after idle run ~5 % slow while the clocks ramp
-    t_warm = time.perf_counter()
-    while time.perf_counter() - t_warm < 0.15:
-        bs.solve_async(stream.cuda_stream)
-        torch.cuda.synchronize(dev)
+    if not args.dry:
+        # clock pre-warm (set-up, not a step): the first milliseconds after idle run ~5 % slow while the clocks ramp
+        t_warm = time.perf_counter()
+        while time.perf_counter() - t_warm < 0.15:
+            bs.solve_async(stream.cuda_stream)
+            sync()
     for _ in range(args.warmup):
         step()
     fence()
     t0 = time.perf_counter()
-    kernel_ms = []
     for i in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    # per-launch kernel duration: HIP events the library records on the launch stream immediately around each kernel
-    kernel_ms.append(bs.kernel_elapsed_ms(args.steps))  # mean over the timed launches, events immediately around the kernel
     if dist_on:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    status = bs.solve_status()
-    if dist_on and not pending:
+    if dist_on and not every_step:
         # the path's only exchange in the fixed-iteration workload: one fold of the last solve's status block
         pending.append(sharding.allreduce_status_async(gstat, force=True))
         fence()
-    if dist_on and pending:
-        status = max(status, sharding.decode_status(pending[-1][0].cpu().numpy())[0])
-    st = bs.get_status()
-    assert int(st["iter"].min()) == args.iters and int(st["iter"].max()) == args.iters, "work skipped"
+
+    if args.dry:
+        k_ms, status, it_mean, iters_total = -1.0, 0, 0.0, 0.0
+        folded = pending[-1][0].numpy() if pending else gstat.numpy()
+        assert int(folded[6]) == total, "status fold did not reach every rank"
+    else:
+        # per-launch kernel duration: HIP events the library records on the launch stream immediately around each kernel
+        k_ms = bs.kernel_elapsed_ms(args.steps)
+        status = bs.solve_status()
+        if dist_on and pending:
+            status = max(status, sharding.decode_status(pending[-1][0].cpu().numpy())[0])
+        st = bs.get_status()
+        if tol <= 0.0:
+            assert int(st["iter"].min()) == args.iters and int(st["iter"].max()) == args.iters, "work skipped"
+        it_mean = float(np.mean(st["iter"]))
+        iters_total = float(np.sum(st["iter"], dtype=np.float64))
+    if dist_on:
+        # ADMM iterations executed per step over all ranks (tolerance-terminated runs: data-dependent)
+        tsum = torch.tensor([iters_total], device=dev, dtype=torch.float64)
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        iters_total = float(tsum.item())
 
     if rank == 0:
-        total = world * batch * args.steps
-        value = total / elapsed
+        value = total * args.steps / elapsed
         avg_step_ms = 1e3 * elapsed / args.steps
-        k_ms = kernel_ms[-1] if kernel_ms[-1] > 0 else avg_step_ms
-        alg_bytes = bs.algorithmic_bytes()          # per launch (one rank's batch)
-        alg_flops = bs.algorithmic_flops(args.iters)
-        ach_gbs = alg_bytes / (k_ms * 1e-3) / 1e9
-        ach_tf = alg_flops / (k_ms * 1e-3) / 1e12
+        how = (f"tol={tol:g}, check every {check}, max_iter={args.iters}" if tol > 0 else f"fixed {args.iters} ADMM iters")
+        shard = (f"batch={total} in total, contiguous shards of {n_local}" if args.scaling == "strong"
+                 else f"batch={n_local}/GPU")
         out = {
             "metric": "qp_solves_per_sec", "value": value, "unit": "solves/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": avg_step_ms,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32" if args.precision == 1 else "f32 (f64 recurrences)", "data": "synthetic",
-            "config": {"workload": label, "family": args.config, "batch_per_gpu": batch,
-                       "admm_iters_per_solve": args.iters, "kernel": bs.kernel_name,
-                       "sharding": f"batch-sharded x{world}, no data-path collective; status all-reduce " + ("every step" if args.status_every_step else "once")},
-            "admm_iters_per_sec": value * args.iters,
+            "config": {"workload": f"{label}, {shard}, {how}, cold start", "family": name,
+                       "batch_per_gpu": n_local, "batch_total": total, "admm_iters_per_solve": args.iters,
+                       "kernel": None if args.dry else bs.kernel_name,
+                       "sharding": f"batch-sharded x{world}, no data-path collective; status all-reduce "
+                                   + ("every step" if every_step else "once") + (" (RCCL)" if not args.dry else " (gloo, dry)")},
+            "admm_iters_per_sec": iters_total * args.steps / elapsed,
             "solve_status": status,
-            "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach_gbs / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(args.config, args.precision, batch, bs.kernel_name),
-                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "compute-bound path (SURVEY 8d): ~430 FLOP/B; see valu"},
-            "valu": {"achieved_tflops": ach_tf, "peak_tflops": FP32_PEAK_TFLOPS,
-                     "frac": ach_tf / FP32_PEAK_TFLOPS, "algorithmic_flops_per_launch": alg_flops,
-                     "issue_utilisation": measured_valu_issue(args.config, batch, bs.kernel_name) if args.precision == 0 else None},
         }
-        if bs.kernel_name.startswith("mfma"):
-            # matrix-core kernel: its roofline is the dense fp64 MFMA rate (AMD MI355X spec 78.6 TFLOP/s = half the F32
-            # MFMA rate of MI355X_MICROARCH.md's table, i.e. 32 FLOP/clk/SIMD; the guide has no fp64 row of its own)
-            out["roofline"].update({"bound": "mfma", "achieved": ach_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                    "frac": ach_tf / FP64_MFMA_PEAK_TFLOPS,
-                                    "issue_utilisation": measured_mfma_issue(args.config, batch, bs.kernel_name),
-                                    "note": "algorithmic FLOPs (SURVEY 8d) over the fp64 matrix-core peak; tiles are "
-                                            "padded, so the issued MFMA FLOPs are higher (DESIGN.md, mfma kernel)"})
-        if bs.kernel_name.startswith("stream"):
-            # the state lives in HBM by design on this kernel: its roofline is that stream, not the I/O bytes
-            bounded = bool((np.asarray(prob.x_min) > -1e17).any() or (np.asarray(prob.x_max) < 1e17).any())
-            sb = streamed_state_bytes(prob, batch, args.iters, args.config == "rocket_soc",
-                                      bounded or args.config == "rocket_soc") + alg_bytes
-            out["roofline"].update({"achieved": sb / (k_ms * 1e-3) / 1e9, "frac": sb / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                    "algorithmic_bytes_per_launch": sb,
-                                    "note": "stream kernel: per-iteration state traffic (does not fit on chip) + I/O"})
-        if args.mode == "mpc" and world == 1:
-            out["mpc_closed_loop"] = run_mpc_mode(args, t, bs, prob, x0, dev, stream, torch)
-        if world == 1 and not args.no_cpu_baseline and args.config != "rocket_soc":
+        if args.dry:
+            out["dry"] = True
+            out["roofline"] = None
+        else:
+            kk = k_ms if k_ms > 0 else avg_step_ms
+            if args.compaction > 0 and tol > 0:
+                kk = avg_step_ms      # several launches per solve
+            out["roofline"], out["valu"] = roofline_of(bs, name, args.precision, n_local, it_mean, kk)
+            out["mean_iters"] = it_mean
+    if not args.dry and rank == 0 and world == 1 and not dist_on:
+        if args.mode == "mpc":
+            out["mpc_closed_loop"] = run_mpc_mode(args, bs, prob, x0, dev, torch)
+        if not args.no_cpu_baseline and name != "rocket_soc" and tol <= 0:
             out["cpu_baseline"] = cpu_baseline(prob, x0, refs, args.iters, args.cpu_seconds)
+    if bs is not None:
+        bs.close()
+    if not args.dry and rank == 0 and world == 1 and not dist_on and not args.no_extras and args.config is None \
+            and args.scaling == "weak" and tol <= 0 and args.mode == "solve":
+        # BASELINE configs[2], [3] and one rank's shard of configs[4]; a few hundred ms in total
+        ex = {}
+        ex["quadrotor_65536"] = time_config(t, torch, dev, stream, "quadrotor", 65536, 1)
+        ex["rocket_soc_32768"] = time_config(t, torch, dev, stream, "rocket_soc", 32768, 2)
+        ex["quadrotor_131072_tol"] = time_config(t, torch, dev, stream, "quadrotor", 131072, 3, tol=1e-3, check=10)
+        ex["quadrotor_131072_tol_compaction"] = time_config(t, torch, dev, stream, "quadrotor", 131072, 3, tol=1e-3,
+                                                            check=10, compaction=20)
+        out["configs"] = ex
+    if rank == 0:
         print(json.dumps(out), flush=True)
-    bs.close()
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

@@ -241,6 +241,67 @@ int tinympc_host_precompute(const double *A, const double *B, const double *Q, c
 int tinympc_host_sensitivity(const double *A, const double *B, const double *Q, const double *R, double rho, int nx,
                              int nu, double *dKinf, double *dPinf, double *dC1, double *dC2);
 
+/* ------------------------------------------------------------------------- */
+/* (3) multi-GPU: one handle, n_gpus devices of one node, one host process   */
+/* ------------------------------------------------------------------------- */
+/* SURVEY.md 8(b) "what the replacement exports": setup_solver(..., batch, n_gpus); 8(e).  The reference has one
+ * process-global CPU solver (bindings.cpp:15-18) and nothing to distribute; this is the surface a `ccall` host uses to
+ * drive all GPUs of a node without a process launcher.  The batch is cut into contiguous shards (shard i = instances
+ * [lo_i, hi_i), sizes differing by at most one), shard i on devices[i] with its own stream; inputs are scattered and
+ * outputs gathered by offset on the caller's instance-major buffers; no data moves between GPUs.  The one exchange is
+ * the solve status: each solve ends with ONE all-reduce(MAX) over RCCL (ncclCommInitAll at creation, a grouped
+ * ncclAllReduce of 8 uint32 per solve) of the devices' status blocks, enqueued on the shards' streams behind the
+ * kernels.  librccl.so is loaded at run time by the first call of tinympc_create_sharded. */
+typedef struct tinympc_sharded tinympc_sharded;
+/* devices: n_gpus device ordinals, NULL = 0 .. n_gpus-1.  Needs 1 <= n_gpus <= batch.  A list that repeats a device
+ * cannot form an RCCL communicator: such a handle folds the status on the host (one-GPU rehearsal of the multi-shard
+ * path; see tinympc_sharded_fold_backend). */
+int tinympc_create_sharded(tinympc_sharded **out, const double *A, const double *B, const double *Q, const double *R,
+                           double rho, int nx, int nu, int N, int batch, int n_gpus, const int *devices, int verbose);
+void tinympc_sharded_destroy(tinympc_sharded *s);
+int tinympc_sharded_n_shards(tinympc_sharded *s);
+/* "rccl" or "host" */
+const char *tinympc_sharded_fold_backend(tinympc_sharded *s);
+/* shard i: its device, its instance range [lo, hi) and its single-device handle (for the setters not mirrored below:
+ * cones, linear rows, cache terms, adaptive rho ... — family-level calls, to be made on every shard).  Any out may be NULL. */
+int tinympc_sharded_shard(tinympc_sharded *s, int i, int *device, int *lo, int *hi, tinympc_solver **local);
+/* the partition rule itself (pure arithmetic, no GPU): shard `shard` of `n_shards` over `batch` instances */
+void tinympc_shard_range(int batch, int n_shards, int shard, int *lo, int *hi);
+/* family-level: applied to every shard (arguments as the tinympc_* function of the same name) */
+int tinympc_sharded_update_settings(tinympc_sharded *s, double abs_pri_tol, double abs_dua_tol, int max_iter,
+                                    int check_termination, int en_state_bound, int en_input_bound);
+int tinympc_sharded_set_bound_constraints(tinympc_sharded *s, const double *x_min, const double *x_max,
+                                          const double *u_min, const double *u_max);
+int tinympc_sharded_set_warm_start(tinympc_sharded *s, int warm_start);
+int tinympc_sharded_reset(tinympc_sharded *s);
+int tinympc_sharded_set_precision(tinympc_sharded *s, int precision);
+int tinympc_sharded_set_compaction(tinympc_sharded *s, int chunk_iters);
+/* per-instance inputs over the WHOLE batch (cols as tinympc_set_x0 / _x_ref / _u_ref), scattered to the shards */
+int tinympc_sharded_set_x0(tinympc_sharded *s, const double *x0, int cols);
+int tinympc_sharded_set_x_ref(tinympc_sharded *s, const double *x_ref, int cols);
+int tinympc_sharded_set_u_ref(tinympc_sharded *s, const double *u_ref, int cols);
+/* One batched solve on every device + the status all-reduce.  _solve = _solve_async + _wait.  Returns the GLOBAL status:
+ * 0 iff every instance on every device converged, 1 otherwise, -1 on error (solve_mpc's convention, bindings.cpp:144-159). */
+int tinympc_sharded_solve(tinympc_sharded *s);
+int tinympc_sharded_solve_async(tinympc_sharded *s);
+int tinympc_sharded_wait(tinympc_sharded *s);
+/* the folded status block of the last solve: global residual maxima (pri_x, dua_x, pri_u, dua_u) and the largest
+ * per-device count of unsolved instances (> 0 iff the status is 1).  Any out may be NULL. */
+int tinympc_sharded_global_status(tinympc_sharded *s, double *residual_maxima4, int *max_unsolved_per_device);
+/* outputs over the WHOLE batch, gathered from the shards into caller-allocated buffers (sizes as tinympc_get_*) */
+int tinympc_sharded_get_states(tinympc_sharded *s, double *buf);
+int tinympc_sharded_get_controls(tinympc_sharded *s, double *buf);
+int tinympc_sharded_get_status(tinympc_sharded *s, int *iter, int *solved, double *residuals4);
+int tinympc_sharded_get_workspace(tinympc_sharded *s, double *d, double *y, double *g, double *v, double *z);
+
+/* The same on the process-global solver (the bare entry points of section (1)): after setup_solver / set_batch_size,
+ * set_gpus(n) spreads the global solver's batch over devices 0 .. n-1 (n = 1: back to one device).  Every entry point
+ * of section (1) then acts on the whole sharded batch — per-instance buffers are scattered / gathered, family-level
+ * setters reach every shard, solve_mpc returns the all-reduced status — so src/TinyMPC.jl needs one extra ccall in
+ * setup() and nothing else.  Inputs and the workspace are reset, as by set_batch_size. */
+int set_gpus(int n_gpus);
+int get_gpus(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,55 @@
+"""`python bench.py --gpus N` must start N ranks by itself (the driver's N > 1 command form when no launcher is
+used) and print ONE JSON line from rank 0 with n_gpus == N.  Rehearsed on CPUs with `--dry --backend gloo`: the
+launcher, the rendezvous, the sharding arithmetic and the status fold are the real code; only the solver is absent
+(it has no CPU path)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(*argv, env=None):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, BENCH, *argv], cwd=ROOT, env=e, capture_output=True, text=True, timeout=240)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return p, lines
+
+
+def test_gpus_2_launches_two_ranks_weak():
+    p, lines = _run("--gpus", "2", "--dry", "--backend", "gloo", "--steps", "3", "--warmup", "1")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["batch_per_gpu"] == 65536 and d["config"]["batch_total"] == 131072
+    assert d["metric"] == "qp_solves_per_sec" and d["unit"] == "solves/s" and d["dry"] is True
+
+
+def test_gpus_3_strong_scaling_is_config5_sharded():
+    p, lines = _run("--gpus", "3", "--dry", "--backend", "gloo", "--scaling", "strong", "--steps", "2", "--warmup", "1")
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 3 and d["scaling"] == "strong" and d["config"]["family"] == "quadrotor"
+    assert d["config"]["batch_total"] == 2 ** 20 and d["config"]["batch_per_gpu"] == 349526   # rank 0 of a ragged split
+
+
+def test_world_size_mismatch_is_refused():
+    # a launcher that started a different number of ranks than --gpus says
+    p, _ = _run("--gpus", "2", "--dry", "--backend", "gloo", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
+
+
+def test_no_gpu_is_refused_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    p, lines = _run("--steps", "1", "--warmup", "0")
+    assert p.returncode != 0 and not lines and "no CPU fallback" in p.stderr

@@ -1,0 +1,147 @@
+"""Multi-GPU entry of the C-ABI (include/tinympc_hip.h section 3; SURVEY.md 8(b) last row, 8(e)).
+
+CPU part: the partition rule and the error conventions (no compute).  GPU part (one-GPU box): the whole multi-shard
+path for real — per-shard solvers and streams, scatter / gather by offset, the status fold — with (a) one shard, folded
+by a one-rank RCCL communicator (librccl loaded, ncclCommInitAll, ncclAllReduce on the shard's stream), and (b) several
+shards placed on the same device, which RCCL cannot connect, folded on the host.  Results must be BIT-identical to the
+single-device BatchSolver on the same batch: sharding only moves instances."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import tinympc_julia_amd as t
+from tinympc_julia_amd import sharding
+
+
+def test_shard_range_matches_python_rule(hip_lib):
+    for batch in (1, 2, 7, 37, 64, 65536, 2 ** 20, 1000003):
+        for n in (1, 2, 3, 4, 8):
+            if n > batch:
+                continue
+            prev = 0
+            for r in range(n):
+                lo, hi = t.shard_range(batch, n, r)
+                assert (lo, hi) == sharding.shard_range(batch, r, n) and lo == prev
+                prev = hi
+            assert prev == batch
+    assert t.shard_range(2 ** 20, 8, 3) == (3 * 2 ** 17, 4 * 2 ** 17)      # config 5
+
+
+def test_sharded_without_gpu_fails_loudly(hip_lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    p = t.problems.cartpole(20, u_bound=0.5)
+    with pytest.raises(t.TinyMPCError, match="no HIP device"):
+        t.ShardedBatchSolver(p.A, p.B, p.Q, p.R, p.rho, p.N, batch=8, n_gpus=2)
+    assert hip_lib.set_gpus(2) == -1 and b"not initialized" in hip_lib.tinympc_last_error()
+    assert hip_lib.get_gpus() == 0
+
+
+def _configure(bs, prob, x0, tol, max_iter, check=1):
+    bs.update_settings(abs_pri_tol=tol, abs_dua_tol=tol, max_iter=max_iter, check_termination=check)
+    bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    bs.set_x0(x0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices,backend", [([0], "rccl"), ([0, 0, 0], "host")])
+@pytest.mark.parametrize("tol,max_iter", [(0.0, 60), (1e-3, 25)])
+def test_sharded_equals_single_device(hip_lib, devices, backend, tol, max_iter):
+    prob = t.problems.cartpole(20, u_bound=0.5)
+    B = 37                                                    # ragged over 3 shards: 13 + 12 + 12
+    x0 = t.problems.cartpole_x0(B, seed=5)
+    x0[:, 7] *= 6.0                                           # one hard instance: unsolved within 25 iterations
+    one = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B, device=0)
+    _configure(one, prob, x0, tol, max_iter)
+    st1 = one.solve()
+    s1, q1 = one.get_solution(), one.get_status()
+    sh = t.ShardedBatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B, devices=devices)
+    assert sh.fold_backend == backend and sh.n_shards == len(devices)
+    assert [sh.shard(i)[1:3] for i in range(sh.n_shards)] == [sharding.shard_range(B, i, len(devices))
+                                                              for i in range(len(devices))]
+    _configure(sh, prob, x0, tol, max_iter)
+    for rep in range(2):                                      # warm-started second solve goes through the same plumbing
+        st = sh.solve()
+        s, q = sh.get_solution(), sh.get_status()
+        if rep == 0:
+            assert st == st1 == int(np.any(q1["solved"] == 0))
+            assert np.array_equal(q["iter"], q1["iter"]) and np.array_equal(q["solved"], q1["solved"])
+            assert np.array_equal(s["states"], s1["states"]) and np.array_equal(s["controls"], s1["controls"])
+            assert np.array_equal(q["residuals"], q1["residuals"])
+            res, unsolved = sh.global_status()
+            assert np.array_equal(res.astype(np.float32), q1["residuals"].max(axis=0).astype(np.float32))
+            assert (unsolved > 0) == (st == 1)
+            ws1 = one.get_workspace()
+            ws = sh.get_workspace()
+            assert all(np.array_equal(ws[k], ws1[k]) for k in ws)
+        one.solve()                                           # keep the single-device solver in step (warm start)
+    s1b, sb = one.get_solution(), sh.get_solution()
+    assert np.array_equal(sb["controls"], s1b["controls"])
+    # async form: enqueue, then wait
+    sh.reset()
+    sh.solve_async()
+    assert sh.wait() == st1
+    assert np.array_equal(sh.get_solution()["controls"], s1["controls"])
+    sh.close()
+    one.close()
+
+
+@pytest.mark.gpu
+def test_sharded_per_instance_refs_and_quadrotor_kernel(hip_lib):
+    """per-instance references are scattered by offset too; each shard picks its own kernel for its own batch"""
+    prob = t.problems.quadrotor(30, u_bound=0.5)
+    B = 70
+    rng = np.random.default_rng(9)
+    x0 = t.problems.quadrotor_x0(B, seed=4)
+    xr = 0.05 * rng.standard_normal((12, 30, B))
+    ur = 0.02 * rng.standard_normal((4, 29, B))
+    outs = []
+    for mk in (lambda: t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B, device=0),
+               lambda: t.ShardedBatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B, devices=[0, 0])):
+        bs = mk()
+        _configure(bs, prob, x0, 0.0, 30)
+        bs.set_x_ref(xr)
+        bs.set_u_ref(ur)
+        bs.solve()
+        outs.append(bs.get_solution())
+        bs.close()
+    assert np.array_equal(outs[0]["states"], outs[1]["states"]) and np.array_equal(outs[0]["controls"], outs[1]["controls"])
+
+
+@pytest.mark.gpu
+def test_global_solver_set_gpus(hip_lib, monkeypatch):
+    """the drop-in surface: setup(batch) -> set_gpus(n) -> every bare entry point acts on the whole sharded batch"""
+    prob = t.problems.cartpole(20, u_bound=0.5)
+    B = 23
+    x0 = t.problems.cartpole_x0(B, seed=11)
+
+    def run(n_gpus):
+        s = t.TinyMPCSolver()
+        t.setup(s, prob.A, prob.B, None, prob.Q, prob.R, prob.rho, 4, 1, 20, batch=B, n_gpus=n_gpus, max_iter=40,
+                abs_pri_tol=1e-3, abs_dua_tol=1e-3)
+        assert hip_lib.get_gpus() == n_gpus and hip_lib.get_batch_size() == B
+        t.set_bound_constraints(s, prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        t.set_x0(s, x0)
+        st = t.solve(s)
+        return st, t.get_solution(s), t.get_status(s)
+
+    st1, sol1, q1 = run(1)
+    monkeypatch.setenv("TINYMPC_HIP_SHARD_DEVICES", "0,0")
+    st2, sol2, q2 = run(2)
+    assert st1 == st2 and np.array_equal(q1["iter"], q2["iter"])
+    assert np.array_equal(sol1["states"], sol2["states"]) and np.array_equal(sol1["controls"], sol2["controls"])
+    # re-batching keeps the device count; n = 1 returns to the single device
+    s = t.TinyMPCSolver()
+    t.setup(s, prob.A, prob.B, None, prob.Q, prob.R, prob.rho, 4, 1, 20, batch=B, n_gpus=2)
+    t.set_batch_size(s, 9)
+    assert hip_lib.get_gpus() == 2 and hip_lib.get_batch_size() == 9
+    t.set_gpus(s, 1)
+    assert hip_lib.get_gpus() == 1 and hip_lib.get_batch_size() == 9
+    monkeypatch.delenv("TINYMPC_HIP_SHARD_DEVICES")
+    with pytest.raises(t.TinyMPCError, match="does not exist"):
+        t.set_gpus(s, 64)                                        # more devices than the box has
+    assert hip_lib.get_gpus() in (0, 1)
+    t.cleanup()

@@ -34,6 +34,9 @@ def build(jobs=8, verbose=False):
 from . import problems  # noqa: E402,F401
 from .tinympc import (  # noqa: E402,F401
     BatchSolver,
+    ShardedBatchSolver,
+    set_gpus,
+    shard_range,
     TinyMPCError,
     TinyMPCSolver,
     cleanup,

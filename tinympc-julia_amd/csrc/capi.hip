@@ -4,6 +4,8 @@
 // src/TinyMPC.jl's ccalls bind unchanged; the tinympc_* handle API adds the batch.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
+#include <vector>
 #include <exception>
 #include <memory>
 
@@ -15,6 +17,65 @@ using tmpc::set_error;
 namespace {
 
 std::unique_ptr<tinympc_solver> g_solver;  // bindings.cpp:15
+// set_gpus(n > 1): the global solver's batch lives on n devices; g_solver then keeps the family-level state only
+// (batch 1) so that a later set_gpus / set_batch_size can rebuild the shards from it
+struct ShardedDeleter {
+    void operator()(tinympc_sharded *p) const { tinympc_sharded_destroy(p); }
+};
+std::unique_ptr<tinympc_sharded, ShardedDeleter> g_sharded;
+int g_sharded_batch = 0, g_verbose = 0;
+
+tinympc_solver *global_shard(int i) {
+    tinympc_solver *h = nullptr;
+    tinympc_sharded_shard(g_sharded.get(), i, nullptr, nullptr, nullptr, &h);
+    return h;
+}
+// a family-level call on the global solver: on the master and, when sharded, on every shard
+template <class F>
+int each_global(F &&f) {
+    if (int rc = f(g_solver.get())) return rc;
+    if (g_sharded)
+        for (int i = 0; i < tinympc_sharded_n_shards(g_sharded.get()); ++i)
+            if (int rc = f(global_shard(i))) return rc;
+    return 0;
+}
+int global_batch() { return g_sharded ? g_sharded_batch : (g_solver ? g_solver->s.batch : 0); }
+
+// (re)build the shards of the global solver for `batch` instances on `n_gpus` devices from the master's family state
+int reshard_global(int batch, int n_gpus) {
+    tmpc::Solver &m = g_solver->s;
+    if (n_gpus <= 1) {
+        g_sharded.reset();
+        return m.alloc_batch(batch);
+    }
+    // TINYMPC_HIP_SHARD_DEVICES="0,0,...": explicit device list (test aid: several shards on one GPU, host status fold)
+    std::vector<int> devs;
+    if (const char *e = std::getenv("TINYMPC_HIP_SHARD_DEVICES")) {
+        for (const char *p = e; *p;) {
+            devs.push_back(std::atoi(p));
+            while (*p && *p != ',') ++p;
+            if (*p == ',') ++p;
+        }
+        if ((int)devs.size() != n_gpus) {
+            set_error("set_gpus: TINYMPC_HIP_SHARD_DEVICES does not list n_gpus devices");
+            return -1;
+        }
+    }
+    tinympc_sharded *sh = nullptr;
+    if (tinympc_create_sharded(&sh, m.A.a.data(), m.B.a.data(), m.Q.a.data(), m.R.a.data(), m.cache.rho, m.nx, m.nu, m.N,
+                               batch, n_gpus, devs.empty() ? nullptr : devs.data(), g_verbose))
+        return -1;
+    // (a failure above leaves the previous arrangement untouched)
+    g_sharded.reset(sh);
+    g_sharded_batch = batch;
+    for (int i = 0; i < n_gpus; ++i)
+        if (global_shard(i)->s.copy_family_state(m)) {
+            g_sharded.reset();
+            (void)m.alloc_batch(batch);
+            return -1;
+        }
+    return m.batch == 1 ? 0 : m.alloc_batch(1);
+}
 
 template <class F>
 int guarded(const char *what, F &&f) {
@@ -415,6 +476,8 @@ int setup_solver(double *A_data, int A_rows, int A_cols, double *B_data, int B_r
                  int Q_cols, double *R_data, int R_rows, int R_cols, double rho, int nx, int nu,
                  int N, int verbose) {
     return guarded("setup_solver", [&]() -> int {
+        g_sharded.reset();
+        g_verbose = verbose;
         if (!A_data || !B_data || !Q_data || !R_data) {
             set_error("setup_solver: null matrix");
             g_solver.reset();
@@ -447,9 +510,21 @@ int setup_solver(double *A_data, int A_rows, int A_cols, double *B_data, int B_r
 
 int set_batch_size(int batch) {
     if (need_global("set_batch_size")) return -1;
-    return guarded("set_batch_size", [&] { return g_solver->s.alloc_batch(batch); });
+    return guarded("set_batch_size", [&] {
+        return g_sharded ? reshard_global(batch, tinympc_sharded_n_shards(g_sharded.get())) : g_solver->s.alloc_batch(batch);
+    });
 }
-int get_batch_size(void) { return g_solver ? g_solver->s.batch : 0; }
+int get_batch_size(void) { return global_batch(); }
+
+int set_gpus(int n_gpus) {
+    if (need_global("set_gpus")) return -1;
+    if (n_gpus < 1) {
+        set_error("set_gpus: n_gpus must be >= 1");
+        return -1;
+    }
+    return guarded("set_gpus", [&] { return reshard_global(global_batch(), n_gpus); });
+}
+int get_gpus(void) { return g_sharded ? tinympc_sharded_n_shards(g_sharded.get()) : (g_solver ? 1 : 0); }
 
 int set_x0(double *x0_data, int x0_rows, int x0_cols, int verbose) {
     (void)verbose;
@@ -458,6 +533,7 @@ int set_x0(double *x0_data, int x0_rows, int x0_cols, int verbose) {
         set_error("set_x0: x0 is not the correct length");
         return -1;
     }
+    if (g_sharded) return guarded("set_x0", [&] { return tinympc_sharded_set_x0(g_sharded.get(), x0_data, x0_cols); });
     return tinympc_set_x0(g_solver.get(), x0_data, x0_cols);
 }
 int set_x_ref(double *x_ref_data, int x_ref_rows, int x_ref_cols, int verbose) {
@@ -467,6 +543,7 @@ int set_x_ref(double *x_ref_data, int x_ref_rows, int x_ref_cols, int verbose) {
         set_error("set_x_ref: wrong number of rows");
         return -1;
     }
+    if (g_sharded) return guarded("set_x_ref", [&] { return tinympc_sharded_set_x_ref(g_sharded.get(), x_ref_data, x_ref_cols); });
     return tinympc_set_x_ref(g_solver.get(), x_ref_data, x_ref_cols);
 }
 int set_u_ref(double *u_ref_data, int u_ref_rows, int u_ref_cols, int verbose) {
@@ -476,12 +553,14 @@ int set_u_ref(double *u_ref_data, int u_ref_rows, int u_ref_cols, int verbose) {
         set_error("set_u_ref: wrong number of rows");
         return -1;
     }
+    if (g_sharded) return guarded("set_u_ref", [&] { return tinympc_sharded_set_u_ref(g_sharded.get(), u_ref_data, u_ref_cols); });
     return tinympc_set_u_ref(g_solver.get(), u_ref_data, u_ref_cols);
 }
 
 int solve_mpc(int verbose) {
     if (need_global("solve_mpc")) return -1;
-    const int st = tinympc_solve(g_solver.get());
+    const int st = g_sharded ? guarded("solve_mpc", [&] { return tinympc_sharded_solve(g_sharded.get()); })
+                             : tinympc_solve(g_solver.get());
     if (verbose) std::printf("Solve completed with status: %d\n", st);
     return st;
 }
@@ -489,17 +568,22 @@ int solve_mpc(int verbose) {
 int get_states(double *states_buffer, int *rows, int *cols) {
     if (!g_solver || !states_buffer || !rows || !cols) return -1;
     *rows = g_solver->s.nx;
-    *cols = g_solver->s.N * g_solver->s.batch;
+    *cols = g_solver->s.N * global_batch();
+    if (g_sharded) return guarded("get_states", [&] { return tinympc_sharded_get_states(g_sharded.get(), states_buffer); });
     return tinympc_get_states(g_solver.get(), states_buffer);
 }
 int get_controls(double *controls_buffer, int *rows, int *cols) {
     if (!g_solver || !controls_buffer || !rows || !cols) return -1;
     *rows = g_solver->s.nu;
-    *cols = (g_solver->s.N - 1) * g_solver->s.batch;
+    *cols = (g_solver->s.N - 1) * global_batch();
+    if (g_sharded) return guarded("get_controls", [&] { return tinympc_sharded_get_controls(g_sharded.get(), controls_buffer); });
     return tinympc_get_controls(g_solver.get(), controls_buffer);
 }
 
-void cleanup_solver(void) { g_solver.reset(); }
+void cleanup_solver(void) {
+    g_sharded.reset();
+    g_solver.reset();
+}
 
 int update_settings(double abs_pri_tol, double abs_dua_tol, int max_iter, int check_termination,
                     int en_state_bound, int en_input_bound, int en_state_soc, int en_input_soc,
@@ -508,13 +592,14 @@ int update_settings(double abs_pri_tol, double abs_dua_tol, int max_iter, int ch
                     int adaptive_rho_enable_clipping, int verbose) {
     (void)verbose;
     if (need_global("update_settings")) return -1;
-    tinympc_enable_cones(g_solver.get(), en_state_soc, en_input_soc);
-    tinympc_enable_linear(g_solver.get(), en_state_linear, en_input_linear);
-    if (tinympc_set_adaptive_rho(g_solver.get(), adaptive_rho, adaptive_rho_min, adaptive_rho_max,
-                                 adaptive_rho_enable_clipping))
-        return -1;
-    return tinympc_update_settings(g_solver.get(), abs_pri_tol, abs_dua_tol, max_iter, check_termination,
-                                   en_state_bound, en_input_bound);
+    return each_global([&](tinympc_solver *h) -> int {
+        tinympc_enable_cones(h, en_state_soc, en_input_soc);
+        tinympc_enable_linear(h, en_state_linear, en_input_linear);
+        if (tinympc_set_adaptive_rho(h, adaptive_rho, adaptive_rho_min, adaptive_rho_max, adaptive_rho_enable_clipping))
+            return -1;
+        return tinympc_update_settings(h, abs_pri_tol, abs_dua_tol, max_iter, check_termination, en_state_bound,
+                                       en_input_bound);
+    });
 }
 
 int set_bound_constraints(double *x_min_data, int x_min_rows, int x_min_cols, double *x_max_data,
@@ -529,7 +614,8 @@ int set_bound_constraints(double *x_min_data, int x_min_rows, int x_min_cols, do
         !dims_ok("u_min", u_min_rows, u_min_cols, v.nu, v.N - 1) ||
         !dims_ok("u_max", u_max_rows, u_max_cols, v.nu, v.N - 1))
         return -1;
-    return tinympc_set_bound_constraints(g_solver.get(), x_min_data, x_max_data, u_min_data, u_max_data);
+    return each_global(
+        [&](tinympc_solver *h) { return tinympc_set_bound_constraints(h, x_min_data, x_max_data, u_min_data, u_max_data); });
 }
 
 int set_cache_terms(double *Kinf_data, int Kinf_rows, int Kinf_cols, double *Pinf_data,
@@ -544,7 +630,8 @@ int set_cache_terms(double *Kinf_data, int Kinf_rows, int Kinf_cols, double *Pin
         !dims_ok("Quu_inv", Quu_inv_rows, Quu_inv_cols, v.nu, v.nu) ||
         !dims_ok("AmBKt", AmBKt_rows, AmBKt_cols, v.nx, v.nx))
         return -1;
-    return tinympc_set_cache_terms(g_solver.get(), Kinf_data, Pinf_data, Quu_inv_data, AmBKt_data);
+    return each_global(
+        [&](tinympc_solver *h) { return tinympc_set_cache_terms(h, Kinf_data, Pinf_data, Quu_inv_data, AmBKt_data); });
 }
 
 int set_sensitivity(double *dK_data, int dK_rows, int dK_cols, double *dP_data, int dP_rows, int dP_cols,
@@ -557,12 +644,20 @@ int set_sensitivity(double *dK_data, int dK_rows, int dK_cols, double *dP_data, 
         (dC1_data && !dims_ok("dC1", dC1_rows, dC1_cols, v.nu, v.nu)) ||
         (dC2_data && !dims_ok("dC2", dC2_rows, dC2_cols, v.nx, v.nx)))
         return -1;
-    return tinympc_set_sensitivity(g_solver.get(), dK_data, dP_data, dC1_data, dC2_data);
+    return each_global([&](tinympc_solver *h) { return tinympc_set_sensitivity(h, dK_data, dP_data, dC1_data, dC2_data); });
 }
 
 int get_adaptive_rho(double *rho_buffer, int *count) {
     if (need_global("get_adaptive_rho") || !rho_buffer || !count) return -1;
-    *count = g_solver->s.batch;
+    *count = global_batch();
+    if (g_sharded) {
+        for (int i = 0; i < tinympc_sharded_n_shards(g_sharded.get()); ++i) {
+            int lo = 0;
+            tinympc_sharded_shard(g_sharded.get(), i, nullptr, &lo, nullptr, nullptr);
+            if (tinympc_get_adaptive_state(global_shard(i), rho_buffer + lo, nullptr, nullptr)) return -1;
+        }
+        return 0;
+    }
     return tinympc_get_adaptive_state(g_solver.get(), rho_buffer, nullptr, nullptr);
 }
 
@@ -570,8 +665,8 @@ int print_problem_data(int verbose) {
     if (need_global("print_problem_data")) return -1;
     const tmpc::Solver &v = g_solver->s;
     std::printf("=== TinyMPC Problem Data ===\n");
-    std::printf("Problem: nx=%d, nu=%d, N=%d, batch=%d, kernel=%s\n", v.nx, v.nu, v.N, v.batch,
-                v.kernel_name.c_str());
+    std::printf("Problem: nx=%d, nu=%d, N=%d, batch=%d, gpus=%d, kernel=%s\n", v.nx, v.nu, v.N, global_batch(), get_gpus(),
+                (g_sharded ? global_shard(0)->s : v).kernel_name.c_str());
     std::printf("Cache: rho=%g\n", v.cache.rho);
     std::printf("Settings: max_iter=%d, abs_pri_tol=%g, abs_dua_tol=%g, check_termination=%d\n",
                 v.st.max_iter, v.st.abs_pri_tol, v.st.abs_dua_tol, v.st.check_termination);
@@ -598,8 +693,10 @@ int set_linear_constraints(double *Alin_x_data, int Alin_x_rows, int Alin_x_cols
         set_error("set_linear_constraints: Alin_x must be (m x nx) with m entries in blin_x, Alin_u (m x nu) likewise");
         return -1;
     }
-    return tinympc_set_linear_constraints(g_solver.get(), Alin_x_data, has_x ? Alin_x_rows : 0, blin_x_data,
-                                          Alin_u_data, has_u ? Alin_u_rows : 0, blin_u_data);
+    return each_global([&](tinympc_solver *h) {
+        return tinympc_set_linear_constraints(h, Alin_x_data, has_x ? Alin_x_rows : 0, blin_x_data, Alin_u_data,
+                                              has_u ? Alin_u_rows : 0, blin_u_data);
+    });
 }
 
 int set_cone_constraints(int *Acu_data, int Acu_len, int *qcu_data, int qcu_len, double *cu_data,
@@ -612,17 +709,19 @@ int set_cone_constraints(int *Acu_data, int Acu_len, int *qcu_data, int qcu_len,
         return -1;
     }
     // bindings.cpp:478-483: the flags of the non-empty halves are switched on
-    return tinympc_set_cone_constraints(g_solver.get(), Acu_data, qcu_data, cu_data, Acu_len, Acx_data,
-                                        qcx_data, cx_data, Acx_len);
+    return each_global([&](tinympc_solver *h) {
+        return tinympc_set_cone_constraints(h, Acu_data, qcu_data, cu_data, Acu_len, Acx_data, qcx_data, cx_data, Acx_len);
+    });
 }
 
 int get_status(int *iter, int *solved, double *residuals4) {
     if (need_global("get_status")) return -1;
+    if (g_sharded) return guarded("get_status", [&] { return tinympc_sharded_get_status(g_sharded.get(), iter, solved, residuals4); });
     return tinympc_get_status(g_solver.get(), iter, solved, residuals4);
 }
 int reset_workspace(void) {
     if (need_global("reset_workspace")) return -1;
-    return tinympc_reset(g_solver.get());
+    return each_global([&](tinympc_solver *h) { return tinympc_reset(h); });
 }
 
 }  // extern "C"

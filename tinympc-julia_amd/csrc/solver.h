@@ -147,6 +147,13 @@ struct Solver {
     int init_families(const double *A_, const double *B_, const double *Q_, const double *R_, const double *rho_,
                       int nx_, int nu_, int N_, int batch_, int device_, int verbose_);
     int alloc_batch(int batch_);
+    // family-level state of another solver of the SAME family (settings, bounds, affine term, cones, linear rows, cache,
+    // sensitivities, precision / warm-start / compaction switches): what set_gpus() replays onto fresh shards
+    int copy_family_state(const Solver &o);
+    // last launch of this solver, whatever stream it went to: every getter waits for it first
+    hipEvent_t ev_done = nullptr;
+    bool ev_done_pending = false;
+    int wait_last_launch();
     int select_kernel(bool rollout = false);  // rollout: the next launch is the fused closed loop (quad kernel only)
     void free_batch();
     int upload_packs();

@@ -149,6 +149,42 @@ Solver::~Solver() {
     for (hipEvent_t e : ev_copy)
         if (e) (void)hipEventDestroy(e);
     if (s_copy) (void)hipStreamDestroy(s_copy);
+    if (ev_done) (void)hipEventDestroy(ev_done);
+}
+
+// Getters are synchronous, and a solve may have been enqueued on any stream (tinympc_solve_async): they wait for the
+// event recorded behind the last launch rather than relying on null-stream ordering, which a non-blocking stream escapes.
+int Solver::wait_last_launch() {
+    if (ev_done_pending) {
+        HIP_TRY(hipEventSynchronize(ev_done));
+        ev_done_pending = false;
+    }
+    return 0;
+}
+
+int Solver::copy_family_state(const Solver &o) {
+    if (o.nx != nx || o.nu != nu || o.N != N || hetero || o.hetero) {
+        set_error("copy_family_state: solvers of different shape");
+        return -1;
+    }
+    st = o.st;
+    x_min = o.x_min, x_max = o.x_max, u_min = o.u_min, u_max = o.u_max;
+    fdyn = o.fdyn, has_fdyn = o.has_fdyn;
+    ncx = o.ncx, ncu = o.ncu;
+    for (int i = 0; i < 8; ++i) {
+        Acx[i] = o.Acx[i], qcx[i] = o.qcx[i], cx[i] = o.cx[i];
+        Acu[i] = o.Acu[i], qcu[i] = o.qcu[i], cu[i] = o.cu[i];
+    }
+    mlx = o.mlx, mlu = o.mlu;
+    lin_Ax = o.lin_Ax, lin_bx = o.lin_bx, lin_Au = o.lin_Au, lin_bu = o.lin_bu;
+    lin_dirty = true;
+    cache = o.cache;
+    sens = o.sens, sens_set = o.sens_set, sens_dirty = true, adapt_dirty = true;
+    warm_start = o.warm_start;
+    precision = o.precision;
+    chunk_iters = o.chunk_iters;
+    packs_dirty = true;
+    return select_kernel() || ensure_extension_buffers();
 }
 
 void Solver::free_batch() {
@@ -355,6 +391,7 @@ int Solver::alloc_batch(int batch_) {
 
 int Solver::reset() {
     HIP_TRY(hipSetDevice(device));
+    if (wait_last_launch()) return -1;
     const size_t Bn = (size_t)batch, EX = (size_t)ex(), EU = (size_t)eu();
     HIP_TRY(hipMemset(d_sd, 0, Bn * EU * sizeof(float)));
     HIP_TRY(hipMemset(d_sy, 0, Bn * EU * sizeof(float)));
@@ -395,6 +432,7 @@ int Solver::set_sensitivity(const double *dK, const double *dP) {
 
 int Solver::get_adaptive_state(double *rho, double *Kinf, double *Pinf) {
     HIP_TRY(hipSetDevice(device));
+    if (wait_last_launch()) return -1;
     const size_t Bn = (size_t)batch, nk = (size_t)nu * nx, np = (size_t)nx * nx;
     if (!d_adapt || adapt_dirty) {  // nothing adapted yet: every instance holds the family's values
         for (size_t b = 0; b < Bn; ++b) {
@@ -449,6 +487,7 @@ int Solver::set_x0(const double *x0, int cols) {
         return -1;
     }
     HIP_TRY(hipSetDevice(device));
+    if (wait_last_launch()) return -1;
     std::vector<float> h((size_t)batch * nx);
     for (int b = 0; b < batch; ++b)
         for (int i = 0; i < nx; ++i) h[(size_t)b * nx + i] = (float)x0[(cols == 1 ? 0 : (size_t)b * nx) + i];
@@ -707,6 +746,30 @@ __global__ void compact_unsolved_kernel(const int *solved, const int *idx_in, in
     if (!solved[b]) idx_out[atomicAdd(count, 1)] = b;
 }
 
+// status words 0..3 of a chunked solve: the maxima of every instance's FINAL residuals (what one launch would have
+// folded), rebuilt from the per-instance residual array — the chunks' own blocks also hold the larger residuals that
+// late-converging instances had at earlier chunk ends
+__global__ void residual_max_kernel(const float *res, long batch, uint32_t *gstat) {
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+    for (long b = (long)blockIdx.x * blockDim.x + threadIdx.x; b < batch; b += (long)gridDim.x * blockDim.x) {
+        const float4 r = reinterpret_cast<const float4 *>(res)[b];
+        m0 = fmaxf(m0, r.x), m1 = fmaxf(m1, r.y), m2 = fmaxf(m2, r.z), m3 = fmaxf(m3, r.w);
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        m0 = fmaxf(m0, __shfl_xor(m0, off, 64));
+        m1 = fmaxf(m1, __shfl_xor(m1, off, 64));
+        m2 = fmaxf(m2, __shfl_xor(m2, off, 64));
+        m3 = fmaxf(m3, __shfl_xor(m3, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&gstat[0], __float_as_uint(m0));
+        atomicMax(&gstat[1], __float_as_uint(m1));
+        atomicMax(&gstat[2], __float_as_uint(m2));
+        atomicMax(&gstat[3], __float_as_uint(m3));
+    }
+}
+
 int Solver::solve_async(hipStream_t stream, int mpc_steps) {
     HIP_TRY(hipSetDevice(device));
     if (select_kernel(mpc_steps > 0) || ensure_extension_buffers()) return -1;
@@ -745,7 +808,6 @@ int Solver::solve_chunked(hipStream_t stream) {
             HIP_TRY(hipMemcpyAsync(&count, d_count, sizeof(int), hipMemcpyDeviceToHost, stream));
         }
         HIP_TRY(hipStreamSynchronize(stream));
-        for (int i = 0; i < 4; ++i) acc[i] = std::max(acc[i], h_gstat[i]);  // residual maxima over every instance's last check
         acc[4] = h_gstat[4];                                                // unsolved: what the latest chunk left
         if (last || count == 0) {
             if (count == 0 && !last) acc[4] = 0;
@@ -755,7 +817,11 @@ int Solver::solve_chunked(hipStream_t stream) {
         n = count;
         cur ^= 1;
     }
+    // the public block: unsolved count of the last chunk; residual maxima over every instance's final residuals
     HIP_TRY(hipMemcpyAsync(d_gstat, acc, GSTAT_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(residual_max_kernel, dim3((unsigned)std::min<long>(1024, ((long)batch + 255) / 256)), dim3(256), 0,
+                       stream, d_res, (long)batch, d_gstat);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(stream));
     return 0;
 }
@@ -877,6 +943,9 @@ int Solver::launch_pass(hipStream_t stream, int mpc_steps, const int *idx, int n
     // the status block stays on the device; solve_status() fetches it when asked (nothing but the kernel and the
     // 32-byte clear is enqueued per solve)
     solved_once = true;
+    if (!ev_done) HIP_TRY(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ev_done, stream));
+    ev_done_pending = true;
     return 0;
 }
 
@@ -943,6 +1012,9 @@ int Solver::rollout_steps(hipStream_t stream, int mpc_steps) {
     }
     HIP_TRY(hipGetLastError());
     mpc_steps_last = mpc_steps;
+    if (!ev_done) HIP_TRY(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ev_done, stream));
+    ev_done_pending = true;
     return 0;
 }
 
@@ -952,6 +1024,7 @@ int Solver::solve_status() {
         return -1;
     }
     HIP_TRY(hipSetDevice(device));
+    if (wait_last_launch()) return -1;
     HIP_TRY(hipMemcpy(h_gstat, d_gstat, GSTAT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return h_gstat[4] == 0 ? 0 : 1;  // admm.cpp:192 / :206 folded over the batch
 }
@@ -962,6 +1035,7 @@ int Solver::get_mpc_log(double *x, double *u, int *iter) {
         return -1;
     }
     HIP_TRY(hipSetDevice(device));
+    if (wait_last_launch()) return -1;
     const size_t n = (size_t)batch * mpc_steps_last;
     std::vector<float> h;
     if (x) {
@@ -995,11 +1069,13 @@ double Solver::kernel_elapsed_mean_ms(int last_n) {
 
 int Solver::get_traj(bool states, double *buf) {
     HIP_TRY(hipSetDevice(device));
+    if (wait_last_launch()) return -1;
     return d2h_double(states ? d_xout : d_uout, buf, (size_t)batch * (states ? ex() : eu()));
 }
 
 int Solver::get_status(int *iter, int *solved, double *res4) {
     HIP_TRY(hipSetDevice(device));
+    if (wait_last_launch()) return -1;
     const size_t Bn = (size_t)batch;
     if (iter) HIP_TRY(hipMemcpy(iter, d_iter, Bn * sizeof(int), hipMemcpyDeviceToHost));
     if (solved) HIP_TRY(hipMemcpy(solved, d_solved, Bn * sizeof(int), hipMemcpyDeviceToHost));
@@ -1018,7 +1094,7 @@ int Solver::d2h_double(const float *d, double *out, size_t n) {
     if (!out || n == 0) return 0;
     constexpr size_t CHUNK = (size_t)1 << 21;  // floats per slot (8 MB)
     if (!s_copy) {
-        HIP_TRY(hipStreamCreate(&s_copy));  // a blocking stream: ordered after work on the default stream, like hipMemcpy
+        HIP_TRY(hipStreamCreate(&s_copy));  // callers have already waited for the last launch (wait_last_launch)
         for (hipEvent_t &e : ev_copy) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     if (stage_cap < 2 * CHUNK) {
@@ -1052,6 +1128,7 @@ int Solver::h2d_float(float *d, const double *in, size_t n) {
 
 int Solver::get_workspace(double *d, double *y, double *g, double *v, double *z) {
     HIP_TRY(hipSetDevice(device));
+    if (wait_last_launch()) return -1;
     const size_t Bn = (size_t)batch, EX = (size_t)ex(), EU = (size_t)eu();
     if (d2h_double(d_sd, d, Bn * EU) || d2h_double(d_sy, y, Bn * EU) || d2h_double(d_sz, z, Bn * EU) ||
         d2h_double(d_sg, g, Bn * EX) || d2h_double(d_sv, v, Bn * EX))
@@ -1062,6 +1139,7 @@ int Solver::get_workspace(double *d, double *y, double *g, double *v, double *z)
 int Solver::set_workspace(const double *d, const double *y, const double *g, const double *v,
                           const double *z) {
     HIP_TRY(hipSetDevice(device));
+    if (wait_last_launch()) return -1;
     const size_t Bn = (size_t)batch, EX = (size_t)ex(), EU = (size_t)eu();
     if (h2d_float(d_sd, d, Bn * EU) || h2d_float(d_sy, y, Bn * EU) || h2d_float(d_sz, z, Bn * EU) ||
         h2d_float(d_sg, g, Bn * EX) || h2d_float(d_sv, v, Bn * EX))

@@ -111,6 +111,33 @@ SIGNATURES = {
     "tinympc_last_error": (ctypes.c_char_p, []),
     "tinympc_host_precompute": (c_int, [c_dp, c_dp, c_dp, c_dp, c_dbl, c_int, c_int, c_dp, c_dp, c_dp, c_dp]),
     "tinympc_host_sensitivity": (c_int, [c_dp, c_dp, c_dp, c_dp, c_dbl, c_int, c_int, c_dp, c_dp, c_dp, c_dp]),
+    # multi-GPU: one handle, n_gpus devices (include/tinympc_hip.h section 3)
+    "tinympc_create_sharded": (c_int, [ctypes.POINTER(c_vp), c_dp, c_dp, c_dp, c_dp, c_dbl, c_int, c_int, c_int, c_int,
+                                       c_int, c_ip, c_int]),
+    "tinympc_sharded_destroy": (None, [c_vp]),
+    "tinympc_sharded_n_shards": (c_int, [c_vp]),
+    "tinympc_sharded_fold_backend": (ctypes.c_char_p, [c_vp]),
+    "tinympc_sharded_shard": (c_int, [c_vp, c_int, c_ip, c_ip, c_ip, ctypes.POINTER(c_vp)]),
+    "tinympc_shard_range": (None, [c_int, c_int, c_int, c_ip, c_ip]),
+    "tinympc_sharded_update_settings": (c_int, [c_vp, c_dbl, c_dbl, c_int, c_int, c_int, c_int]),
+    "tinympc_sharded_set_bound_constraints": (c_int, [c_vp, c_dp, c_dp, c_dp, c_dp]),
+    "tinympc_sharded_set_warm_start": (c_int, [c_vp, c_int]),
+    "tinympc_sharded_reset": (c_int, [c_vp]),
+    "tinympc_sharded_set_precision": (c_int, [c_vp, c_int]),
+    "tinympc_sharded_set_compaction": (c_int, [c_vp, c_int]),
+    "tinympc_sharded_set_x0": (c_int, [c_vp, c_dp, c_int]),
+    "tinympc_sharded_set_x_ref": (c_int, [c_vp, c_dp, c_int]),
+    "tinympc_sharded_set_u_ref": (c_int, [c_vp, c_dp, c_int]),
+    "tinympc_sharded_solve": (c_int, [c_vp]),
+    "tinympc_sharded_solve_async": (c_int, [c_vp]),
+    "tinympc_sharded_wait": (c_int, [c_vp]),
+    "tinympc_sharded_global_status": (c_int, [c_vp, c_dp, c_ip]),
+    "tinympc_sharded_get_states": (c_int, [c_vp, c_dp]),
+    "tinympc_sharded_get_controls": (c_int, [c_vp, c_dp]),
+    "tinympc_sharded_get_status": (c_int, [c_vp, c_ip, c_ip, c_dp]),
+    "tinympc_sharded_get_workspace": (c_int, [c_vp, c_dp, c_dp, c_dp, c_dp, c_dp]),
+    "set_gpus": (c_int, [c_int]),
+    "get_gpus": (c_int, []),
 }
 
 
@@ -165,7 +192,7 @@ class TinyMPCSolver:
         self.R = np.zeros((0, 0))
 
 
-def setup(solver, A, B, f, Q, R, rho, nx, nu, N, *, batch=1, verbose=False, abs_pri_tol=1e-3,
+def setup(solver, A, B, f, Q, R, rho, nx, nu, N, *, batch=1, n_gpus=1, verbose=False, abs_pri_tol=1e-3,
           abs_dua_tol=1e-3, max_iter=100, check_termination=True, adaptive_rho=False,
           adaptive_rho_min=0.1, adaptive_rho_max=10.0, adaptive_rho_clipping=True):
     """TinyMPC.jl:55-112.  Raises on failure like the Julia `error(...)`; returns the status."""
@@ -183,6 +210,8 @@ def setup(solver, A, B, f, Q, R, rho, nx, nu, N, *, batch=1, verbose=False, abs_
     if batch != 1 and lib.set_batch_size(int(batch)) != 0:
         raise TinyMPCError(f"Failed to set batch size ({_err()})")
     solver.is_setup = True
+    if n_gpus != 1:
+        set_gpus(solver, n_gpus)
     # TinyMPC.jl:89-104 — settings pushed with every en_* false
     update_settings(solver, abs_pri_tol=abs_pri_tol, abs_dua_tol=abs_dua_tol, max_iter=max_iter,
                     check_termination=check_termination, en_state_bound=False, en_input_bound=False,
@@ -196,6 +225,16 @@ def setup(solver, A, B, f, Q, R, rho, nx, nu, N, *, batch=1, verbose=False, abs_
 def _need_setup(solver):
     if not solver.is_setup:
         raise TinyMPCError("Solver not setup")
+
+
+def set_gpus(solver, n_gpus):
+    """Spread the global solver's batch over devices 0 .. n_gpus-1 of this node (contiguous shards, status all-reduced
+    over RCCL): every other call then acts on the whole sharded batch.  Inputs / workspace are reset."""
+    _need_setup(solver)
+    if load_library().set_gpus(int(n_gpus)) != 0:
+        raise TinyMPCError(f"Failed to set the number of GPUs ({_err()})")
+    solver.n_gpus = int(n_gpus)
+    return 0
 
 
 def set_batch_size(solver, batch):
@@ -681,3 +720,138 @@ class BatchSolver:
 
     def algorithmic_flops(self, iters):
         return float(self.lib.tinympc_algorithmic_flops(self.h, int(iters)))
+
+
+def shard_range(batch, n_shards, shard):
+    """the library's partition rule (no GPU needed): [lo, hi) of `shard`"""
+    lo, hi = c_int(), c_int()
+    load_library().tinympc_shard_range(int(batch), int(n_shards), int(shard), ctypes.byref(lo), ctypes.byref(hi))
+    return lo.value, hi.value
+
+
+class ShardedBatchSolver:
+    """One handle, several GPUs of one node, ONE host process (tinympc_sharded_* in include/tinympc_hip.h): the batch in
+    contiguous shards, one per device; inputs scattered, outputs gathered, the solve status all-reduced over RCCL."""
+
+    def __init__(self, A, B, Q, R, rho, N, batch, n_gpus=1, devices=None, verbose=False):
+        self.lib = load_library()
+        A, B, Q, R = _mat(A), _mat(B), _mat(Q), _mat(R)
+        self.nx, self.nu, self.N, self.batch = A.shape[0], B.shape[1], int(N), int(batch)
+        dv = None
+        if devices is not None:
+            devices = np.ascontiguousarray(np.asarray(devices, dtype=np.int32))
+            n_gpus, dv = len(devices), devices.ctypes.data_as(c_ip)
+        h = c_vp()
+        st = self.lib.tinympc_create_sharded(ctypes.byref(h), _dp(A), _dp(B), _dp(Q), _dp(R), float(rho), self.nx, self.nu,
+                                             self.N, self.batch, int(n_gpus), dv, 1 if verbose else 0)
+        if st != 0:
+            raise TinyMPCError(f"tinympc_create_sharded failed ({_err()})")
+        self.h = h
+        self.n_shards = int(self.lib.tinympc_sharded_n_shards(h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tinympc_sharded_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, st, what):
+        if st != 0:
+            raise TinyMPCError(f"{what} failed ({_err()})")
+
+    @property
+    def fold_backend(self):
+        return self.lib.tinympc_sharded_fold_backend(self.h).decode()
+
+    def shard(self, i):
+        """(device, lo, hi, handle of the shard's single-device solver)"""
+        d, lo, hi, loc = c_int(), c_int(), c_int(), c_vp()
+        self._chk(self.lib.tinympc_sharded_shard(self.h, int(i), ctypes.byref(d), ctypes.byref(lo), ctypes.byref(hi),
+                                                 ctypes.byref(loc)), "shard")
+        return d.value, lo.value, hi.value, loc
+
+    def kernel_names(self):
+        return [self.lib.tinympc_kernel_name(self.shard(i)[3]).decode() for i in range(self.n_shards)]
+
+    def update_settings(self, abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1, en_state_bound=0,
+                        en_input_bound=0):
+        self._chk(self.lib.tinympc_sharded_update_settings(self.h, float(abs_pri_tol), float(abs_dua_tol), int(max_iter),
+                                                           int(check_termination), int(en_state_bound),
+                                                           int(en_input_bound)), "update_settings")
+
+    def set_bound_constraints(self, x_min, x_max, u_min, u_max):
+        ms = [_mat(m) for m in (x_min, x_max, u_min, u_max)]
+        self._chk(self.lib.tinympc_sharded_set_bound_constraints(self.h, *[_dp(m) for m in ms]), "set_bound_constraints")
+
+    def set_warm_start(self, on):
+        self._chk(self.lib.tinympc_sharded_set_warm_start(self.h, 1 if on else 0), "set_warm_start")
+
+    def reset(self):
+        self._chk(self.lib.tinympc_sharded_reset(self.h), "reset")
+
+    def set_precision(self, precision):
+        self._chk(self.lib.tinympc_sharded_set_precision(self.h, int(precision)), "set_precision")
+
+    def set_compaction(self, chunk_iters):
+        self._chk(self.lib.tinympc_sharded_set_compaction(self.h, int(chunk_iters)), "set_compaction")
+
+    def set_x0(self, x0):
+        m = _mat(x0)
+        self._chk(self.lib.tinympc_sharded_set_x0(self.h, _dp(m), m.shape[1]), "set_x0")
+
+    def set_x_ref(self, x_ref):
+        m = _ref3(x_ref)
+        self._chk(self.lib.tinympc_sharded_set_x_ref(self.h, _dp(m), m.shape[1]), "set_x_ref")
+
+    def set_u_ref(self, u_ref):
+        m = _ref3(u_ref)
+        self._chk(self.lib.tinympc_sharded_set_u_ref(self.h, _dp(m), m.shape[1]), "set_u_ref")
+
+    def solve(self):
+        st = int(self.lib.tinympc_sharded_solve(self.h))
+        if st < 0:
+            raise TinyMPCError(f"sharded solve failed ({_err()})")
+        return st
+
+    def solve_async(self):
+        self._chk(self.lib.tinympc_sharded_solve_async(self.h), "solve_async")
+
+    def wait(self):
+        st = int(self.lib.tinympc_sharded_wait(self.h))
+        if st < 0:
+            raise TinyMPCError(f"sharded wait failed ({_err()})")
+        return st
+
+    def global_status(self):
+        """(residual maxima over all instances (4,), largest per-device unsolved count) of the last solve"""
+        res, n = np.zeros(4), c_int()
+        self._chk(self.lib.tinympc_sharded_global_status(self.h, _dp(res), ctypes.byref(n)), "global_status")
+        return res, n.value
+
+    def get_solution(self):
+        nx, nu, N, B = self.nx, self.nu, self.N, self.batch
+        sb, cb = np.zeros(nx * N * B), np.zeros(nu * (N - 1) * B)
+        self._chk(self.lib.tinympc_sharded_get_states(self.h, _dp(sb)), "get_states")
+        self._chk(self.lib.tinympc_sharded_get_controls(self.h, _dp(cb)), "get_controls")
+        return dict(states=sb.reshape((nx, N, B), order="F"), controls=cb.reshape((nu, N - 1, B), order="F"))
+
+    def get_status(self):
+        B = self.batch
+        it, so, res = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32), np.zeros((B, 4))
+        self._chk(self.lib.tinympc_sharded_get_status(self.h, it.ctypes.data_as(c_ip), so.ctypes.data_as(c_ip), _dp(res)),
+                  "get_status")
+        return dict(iter=it, solved=so, residuals=res)
+
+    def get_workspace(self):
+        nx, nu, N, B = self.nx, self.nu, self.N, self.batch
+        d, y, z = (np.zeros(nu * (N - 1) * B) for _ in range(3))
+        g, v = (np.zeros(nx * N * B) for _ in range(2))
+        self._chk(self.lib.tinympc_sharded_get_workspace(self.h, _dp(d), _dp(y), _dp(g), _dp(v), _dp(z)), "get_workspace")
+        ru = lambda a: a.reshape((nu, N - 1, B), order="F")
+        rx = lambda a: a.reshape((nx, N, B), order="F")
+        return dict(d=ru(d), y=ru(y), z=ru(z), g=rx(g), v=rx(v))
