@@ -166,6 +166,11 @@ class CpuSolver:
     def reset(self):
         self._call("reset")
 
+    def set_forced_exit(self, k):
+        """test knob (restatement only): 0 off; k > 0: leave as converged exactly at iteration k; -1: never converge"""
+        assert self.kind != "ref", "the compiled reference decides by its own residuals"
+        self._call("set_forced_exit", int(k))
+
     def solve(self):
         return int(self._call("solve"))
 

@@ -47,6 +47,7 @@ extern "C" {
     void P##set_sensitivity(void *h, const double *dKinf_drho, const double *dPinf_drho);     \
     void P##get_adapted(void *h, double *rho, double *Kinf, double *Pinf);                    \
     void P##reset(void *h);                                                                    \
+    void P##set_forced_exit(void *h, int k);                                                   \
     int P##solve(void *h);                                                                     \
     void P##get_solution(void *h, double *x, double *u, int *iter, int *solved, double *res4); \
     void P##get_cache(void *h, double *Kinf, double *Pinf, double *Quu_inv, double *AmBKt);    \

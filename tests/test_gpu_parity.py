@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import tinympc_julia_amd as t
-from tests.util import FP32_TOL, cm, load_golden, nrel, nrel_batch, problem_of
+from tests.util import FP32_TOL, cm, load_golden, nrel, nrel_batch, parity_every_instance, problem_of
 
 pytestmark = pytest.mark.gpu
 
@@ -108,7 +108,7 @@ def test_golden_mpc_warm_start(hip_lib, name):
         st = t.get_status(s)
         assert status == step["status"], f"step {k}"
         assert int(st["iter"][0]) == step["iter"], f"step {k}"
-        _check_instance(sol["states"], sol["controls"], step, prob.nx, prob.nu, prob.N, tol=2e-5)
+        _check_instance(sol["states"], sol["controls"], step, prob.nx, prob.nu, prob.N)
     t.cleanup()
 
 
@@ -127,7 +127,8 @@ def test_golden_mpc_workspace_state(hip_lib):
         for key, r, c in (("d", nu, N - 1), ("y", nu, N - 1), ("z", nu, N - 1), ("g", nx, N), ("v", nx, N)):
             ref = cm(step["state_after"][key], r, c)
             scale = max(np.abs(ref).max(), 1e-2)
-            assert np.abs(ws[key][:, :, 0] - ref).max() <= 5e-5 * scale, f"step {k} {key}"
+            err = np.abs(ws[key][:, :, 0] - ref).max()
+            assert err <= FP32_TOL * scale, f"step {k} {key}: {err / scale:.3e}"
     bs.close()
 
 
@@ -161,6 +162,43 @@ def test_golden_residual_trace(hip_lib, name, iters):
 
 def _oracle_batch(oracle_built, prob, x0, **kw):
     return oracle_built.solve_batch("orc64", prob, x0, **kw)
+
+
+def _plain_oracle(oracle_built, prob, kw, xref=None, uref=None):
+    """factory of cold fp64 oracle solvers for a box-constrained family (shared references applied here)"""
+    def make(b=None):
+        o = oracle_built.CpuSolver("orc64", prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N)
+        o.update_settings(**kw)
+        if prob.has_bounds():
+            o.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        if xref is not None and np.ndim(xref) == 2:
+            o.set_x_ref(xref)
+        if uref is not None and np.ndim(uref) == 2:
+            o.set_u_ref(uref)
+        return o
+    return make
+
+
+def _oracle_loop(make, x0, xref=None, uref=None):
+    """every instance on its own oracle solver (for the configurations solve_batch does not take): dict like solve_batch's"""
+    B = x0.shape[1]
+    out = None
+    for b in range(B):
+        o = make(b)
+        if xref is not None and np.ndim(xref) == 3:
+            o.set_x_ref(xref[:, :, b])
+        if uref is not None and np.ndim(uref) == 3:
+            o.set_u_ref(uref[:, :, b])
+        o.set_x0(x0[:, b])
+        o.solve()
+        r = o.get_solution()
+        if out is None:
+            out = dict(x=np.zeros(r["x"].shape + (B,)), u=np.zeros(r["u"].shape + (B,)), iter=np.zeros(B, dtype=int),
+                       solved=np.zeros(B, dtype=int), res=np.zeros((B, 4)))
+        out["x"][:, :, b], out["u"][:, :, b] = r["x"], r["u"]
+        out["iter"][b], out["solved"][b], out["res"][b] = r["iter"], r["solved"], r["res"]
+        o.close()
+    return out
 
 
 @pytest.mark.parametrize("family,batch", [("cartpole", 1000), ("quadrotor", 300)])
@@ -213,10 +251,9 @@ def test_lanes_per_instance_variants(hip_lib, oracle_built, monkeypatch, family,
         bs.reset()
         bs.solve()
         sol, st = bs.get_solution(), bs.get_status()
-        same = st["iter"] == ref["iter"]
-        assert same.mean() >= 0.97 and np.all(np.abs(st["iter"] - ref["iter"]) <= 1)
-        assert nrel_batch(sol["states"], ref["x"])[same].max() <= FP32_TOL
-        assert nrel_batch(sol["controls"], ref["u"])[same].max() <= FP32_TOL
+        kws = dict(check_termination=1, **kw)
+        parity_every_instance(sol, st, ref, _plain_oracle(oracle_built, prob, kws, xr, ur), x0, kws, prob.rho,
+                              min_same=0.97, tag=f"{family} g{group} {kw}")
     bs.close()
 
 
@@ -232,14 +269,11 @@ def test_tolerance_terminated_batch_vs_oracle(hip_lib, oracle_built):
     status = bs.solve()
     sol, st = bs.get_solution(), bs.get_status()
     assert status == int(np.any(ref["solved"] == 0))
-    same = st["iter"] == ref["iter"]
-    # an instance whose residual sits within fp32 rounding of the tolerance may stop one check
-    # earlier or later; everything else must match exactly
-    assert same.mean() >= 0.97, f"only {same.mean():.3f} of iteration counts agree"
-    assert np.all(np.abs(st["iter"] - ref["iter"]) <= 1)
-    ex, eu = nrel_batch(sol["states"], ref["x"]), nrel_batch(sol["controls"], ref["u"])
-    assert ex[same].max() <= FP32_TOL and eu[same].max() <= FP32_TOL
-    assert np.array_equal(st["solved"][same], ref["solved"][same])
+    # an instance whose residual sits within fp32 rounding of the tolerance may stop one check earlier or later
+    # (SURVEY.md §8c): those are replayed on the oracle with the GPU's decision and compared by solution all the same
+    kws = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1)
+    parity_every_instance(sol, st, ref, _plain_oracle(oracle_built, prob, kws), x0, kws, prob.rho, min_same=0.97,
+                          tag="quadrotor tol 1e-3")
     bs.close()
 
 
@@ -319,17 +353,15 @@ def test_fallback_kernels_vs_oracle(hip_lib, oracle_built, monkeypatch, shape, k
         bs.set_u_ref(uref)
     bs.solve()
     sol, st = bs.get_solution(), bs.get_status()
-    same = st["iter"] == ref["iter"]
-    assert same.mean() >= 0.95 and np.all(np.abs(st["iter"] - ref["iter"]) <= 1)
-    assert nrel_batch(sol["states"], ref["x"])[same].max() <= FP32_TOL
-    assert nrel_batch(sol["controls"], ref["u"])[same].max() <= FP32_TOL
+    kws = dict(check_termination=1, **kw)
+    mk = _plain_oracle(oracle_built, prob, kws, xref, uref)
+    parity_every_instance(sol, st, ref, mk, x0, kws, prob.rho, min_same=0.95, tag=f"{shape} {kernel}")
     # one-shot solves (workspace not kept) take the stream kernel's in-place loop: same answers
     bs.set_warm_start(False)
     bs.solve()
     sol1, st1 = bs.get_solution(), bs.get_status()
     assert np.array_equal(st1["iter"], st["iter"])
-    assert nrel_batch(sol1["states"], ref["x"])[same].max() <= FP32_TOL
-    assert nrel_batch(sol1["controls"], ref["u"])[same].max() <= FP32_TOL
+    parity_every_instance(sol1, st1, ref, mk, x0, kws, prob.rho, min_same=0.95, tag=f"{shape} {kernel} one-shot")
     bs.close()
 
 
@@ -355,10 +387,8 @@ def _random_problem(rng, nx, nu, N, bounded):
 def test_stream_kernel_random_sweep(hip_lib, oracle_built, seed):
     """Every (nx, nu) of the run-time-horizon kernel's grid (25 shapes over the 6 seeds), random horizon, batch,
     family, bounds (finite state bounds or none), reference mode and check interval, against the oracle; then a
-    same problem as a one-shot solve (the in-place loop).  Tolerance 5e-5 norm-relative, written here: random
-    families are worse conditioned than the reference's examples, whose bar stays 1e-5; the sweep is there to catch
-    indexing / masking errors, which show up at 1e-2 and above."""
-    SWEEP_TOL = 5e-5
+    same problem as a one-shot solve (the in-place loop).  Every instance is held to the 1e-5 norm-relative bar."""
+    SWEEP_TOL = FP32_TOL
     rng = np.random.default_rng(1000 + seed)
     grid = [(nx, nu) for nx in (2, 3, 4, 6, 8, 10, 12) for nu in (1, 2, 3, 4) if nu <= nx]
     for nx, nu in grid[seed::6]:
@@ -390,11 +420,9 @@ def test_stream_kernel_random_sweep(hip_lib, oracle_built, seed):
             bs.reset()
             bs.solve()
             sol, st = bs.get_solution(), bs.get_status()
-            same = st["iter"] == ref["iter"]
-            tag = (nx, nu, N, B, mode, ct, warm)
-            assert same.mean() >= 0.9 and np.all(np.abs(st["iter"] - ref["iter"]) <= ct), tag
-            assert nrel_batch(sol["states"], ref["x"])[same].max() <= SWEEP_TOL, tag
-            assert nrel_batch(sol["controls"], ref["u"])[same].max() <= SWEEP_TOL, tag
+            tag = str((nx, nu, N, B, mode, ct, warm))
+            parity_every_instance(sol, st, ref, _plain_oracle(oracle_built, prob, kw, xref, uref), x0, kw, prob.rho,
+                                  xref=xref, uref=uref, tol=SWEEP_TOL, min_same=0.9, tag=tag)
         bs.close()
 
 
@@ -552,13 +580,15 @@ def test_fused_mpc_rollout_vs_golden(hip_lib, name):
         assert int(log["iter"][k, 0]) == step["iter"], f"step {k}"
         assert int(log["solved"][k, 0]) == step["solved"]
         u0 = np.array(step["u"][: prob.nu])
-        assert np.abs(log["u"][:, k, 0] - u0).max() <= 2e-5 * max(1.0, np.abs(np.array(step["u"])).max())
+        eu = np.abs(log["u"][:, k, 0] - u0).max() / max(1.0, np.abs(np.array(step["u"])).max())
+        assert eu <= FP32_TOL, f"step {k}: applied control off by {eu:.3e}"
         if k + 1 < steps:
             xn = np.array(g["steps"][k + 1]["x0"])
-            assert np.abs(log["x"][:, k, 0] - xn).max() <= 2e-5 * max(1.0, np.abs(xn).max())
+            ex = np.abs(log["x"][:, k, 0] - xn).max() / max(1.0, np.abs(xn).max())
+            assert ex <= FP32_TOL, f"step {k}: plant state off by {ex:.3e}"
     # the last solve is what get_solution / get_workspace describe
     sol = bs.get_solution()
-    _check_instance(sol["states"][:, :, 0], sol["controls"][:, :, 0], g["steps"][-1], prob.nx, prob.nu, prob.N, tol=5e-5)
+    _check_instance(sol["states"][:, :, 0], sol["controls"][:, :, 0], g["steps"][-1], prob.nx, prob.nu, prob.N)
     bs.close()
 
 
@@ -578,39 +608,61 @@ def test_fused_mpc_rollout_batch_vs_oracle(hip_lib, oracle_built, family, kernel
     ref_u = np.zeros((prob.nu, steps, B))
     ref_x = np.zeros((prob.nx, steps, B))
     ref_it = np.zeros((steps, B), dtype=int)
-    for b in range(B):
+
+    def oracle_loop(b, forced=None):
+        """the host loop of cartpole_example_mpc.jl:35-51 on the oracle; forced = [(iter, solved)] per step imposes the
+        GPU's termination decisions (CpuSolver.set_forced_exit)"""
         o = oracle_built.CpuSolver("orc64", prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N)
         o.update_settings(**kw)
         o.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
         x = x0[:, b].copy()
         for k in range(steps):
+            if forced is not None:
+                o.set_forced_exit(int(forced[k][0]) if forced[k][1] else -1)
             o.set_x0(x)
             o.solve()
             r = o.get_solution()
             x = prob.A @ x + prob.B @ r["u"][:, 0]
             ref_u[:, k, b], ref_x[:, k, b], ref_it[k, b] = r["u"][:, 0], x, r["iter"]
+        o.close()
+
+    for b in range(B):
+        oracle_loop(b)
     bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
     bs.update_settings(**kw)
     bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
     bs.set_x0(x0)
     log = bs.mpc_rollout(steps)
     assert bs.kernel_name.startswith(kernel)
-    # iteration counts decide the trajectory; allow a rare +-1 near the tolerance, then compare the rest
+    # iteration counts decide the trajectory: a step whose fp32 residual falls on the other side of the tolerance sends
+    # that instance down another (equally valid) closed-loop path.  Those instances are not dropped: the oracle loop is
+    # replayed with the GPU's termination decisions imposed, and every instance is compared at the 1e-5 bar.
     same = np.all(log["iter"] == ref_it, axis=0)
     assert same.mean() >= 0.9
-    assert np.abs(log["u"][:, :, same] - ref_u[:, :, same]).max() <= 3e-5 * np.abs(ref_u).max()
-    assert np.abs(log["x"][:, :, same] - ref_x[:, :, same]).max() <= 3e-5 * np.abs(ref_x).max()
+    for b in np.nonzero(~same)[0]:
+        assert np.abs(log["iter"][:, b] - ref_it[:, b]).max() <= 1
+        oracle_loop(b, [(log["iter"][k, b], log["solved"][k, b]) for k in range(steps)])
+        assert np.array_equal(ref_it[:, b], log["iter"][:, b])
+    eu = np.abs(log["u"] - ref_u).max(axis=(0, 1)) / np.abs(ref_u).max(axis=(0, 1))
+    exx = np.abs(log["x"] - ref_x).max(axis=(0, 1)) / np.abs(ref_x).max(axis=(0, 1))
+    assert eu.max() <= FP32_TOL, f"applied controls: worst {eu.max():.3e} (instance {eu.argmax()})"
+    assert exx.max() <= FP32_TOL, f"plant states: worst {exx.max():.3e} (instance {exx.argmax()})"
     # same thing as `steps` separate launches with the host applying the model in between
     bs2 = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
     bs2.update_settings(**kw)
     bs2.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
     x = x0.copy()
+    u2, it2 = np.zeros_like(log["u"]), np.zeros_like(log["iter"])
     for k in range(steps):
         bs2.set_x0(x)
         bs2.solve()
-        u0 = bs2.get_solution()["controls"][:, 0, :]
-        x = prob.A @ x + prob.B @ u0
-        assert np.abs(u0 - log["u"][:, k, :])[:, same].max() <= 3e-5 * np.abs(ref_u).max()
+        u2[:, k, :] = bs2.get_solution()["controls"][:, 0, :]
+        it2[k] = bs2.get_status()["iter"]
+        x = prob.A @ x + prob.B @ u2[:, k, :]
+    agree = np.all(it2 == log["iter"], axis=0)             # the host loop rounds the plant state to fp32 every step
+    assert agree.mean() >= 0.9
+    e2 = np.abs(u2 - log["u"]).max(axis=(0, 1)) / np.abs(ref_u).max(axis=(0, 1))
+    assert e2[agree].max() <= FP32_TOL, f"host-stepped loop vs fused loop: {e2[agree].max():.3e}"
     # generic-path shapes refuse the fused loop instead of silently doing something else
     pg = t.problems.cartpole(15, u_bound=0.5)   # stream / generic path: plain solves only
     bg = t.BatchSolver(pg.A, pg.B, pg.Q, pg.R, pg.rho, pg.N, batch=2)
@@ -710,11 +762,9 @@ def test_rccl_status_allreduce_one_rank(hip_lib, tmp_path):
 
 # ---------------- UNPINNED extensions: affine dynamics + second-order cones (BASELINE config 4) ----------------
 
-def _oracle_rocket(oracle_built, prob, x0, xr, ur, fdyn, cones, **kw):
-    B = x0.shape[1]
-    X, U = np.zeros((prob.nx, prob.N, B)), np.zeros((prob.nu, prob.N - 1, B))
-    it, so = np.zeros(B, dtype=int), np.zeros(B, dtype=int)
-    for b in range(B):
+def _rocket_oracle(oracle_built, prob, xr, ur, fdyn, cones, kw):
+    """factory of cold oracle solvers for the rocket with its affine term / cones switched on or off"""
+    def make(b=None):
         o = oracle_built.CpuSolver("orc64", prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N)
         o.update_settings(**kw)
         o.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
@@ -724,11 +774,13 @@ def _oracle_rocket(oracle_built, prob, x0, xr, ur, fdyn, cones, **kw):
             o.set_cone_constraints([0], [3], [0.25], [0], [3], [0.5])
         o.set_x_ref(xr)
         o.set_u_ref(ur)
-        o.set_x0(x0[:, b])
-        o.solve()
-        r = o.get_solution()
-        X[:, :, b], U[:, :, b], it[b], so[b] = r["x"], r["u"], r["iter"], r["solved"]
-    return X, U, it, so
+        return o
+    return make
+
+
+def _oracle_rocket(oracle_built, prob, x0, xr, ur, fdyn, cones, **kw):
+    r = _oracle_loop(_rocket_oracle(oracle_built, prob, xr, ur, fdyn, cones, kw), x0)
+    return r["x"], r["u"], r["iter"], r["solved"]
 
 
 @pytest.mark.parametrize("N,fdyn,cones,kernel", [(10, True, False, "stream4<6,3>"), (10, True, True, "stream4<6,3>"),
@@ -745,7 +797,8 @@ def test_rocket_fdyn_cones_vs_oracle(hip_lib, oracle_built, monkeypatch, N, fdyn
     x0 = t.problems.rocket_x0(B, seed=2)
     xr, ur = t.problems.rocket_refs(N)
     kw = dict(abs_pri_tol=2e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1)   # rocket_landing_constraints.jl:61-62
-    X, U, it, so = _oracle_rocket(oracle_built, prob, x0, xr, ur, fdyn, cones, **kw)
+    mk = _rocket_oracle(oracle_built, prob, xr, ur, fdyn, cones, kw)
+    ref = _oracle_loop(mk, x0)
     bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
     bs.update_settings(**kw)
     bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
@@ -759,10 +812,7 @@ def test_rocket_fdyn_cones_vs_oracle(hip_lib, oracle_built, monkeypatch, N, fdyn
     bs.set_x0(x0)
     bs.solve()
     sol, st = bs.get_solution(), bs.get_status()
-    same = st["iter"] == it
-    assert same.mean() >= 0.9 and np.all(np.abs(st["iter"] - it) <= 1)
-    assert nrel_batch(sol["states"], X)[same].max() <= FP32_TOL
-    assert nrel_batch(sol["controls"], U)[same].max() <= FP32_TOL
+    parity_every_instance(sol, st, ref, mk, x0, kw, prob.rho, tag=f"rocket N={N} fdyn={fdyn} cones={cones} {kernel}")
     # warm start of the cone pairs persists too: a second solve continues from the stored state
     bs.solve()
     st2 = bs.get_status()
@@ -772,8 +822,7 @@ def test_rocket_fdyn_cones_vs_oracle(hip_lib, oracle_built, monkeypatch, N, fdyn
     bs.solve()
     sol1, st1 = bs.get_solution(), bs.get_status()
     assert np.array_equal(st1["iter"], st["iter"])
-    assert nrel_batch(sol1["states"], X)[same].max() <= FP32_TOL
-    assert nrel_batch(sol1["controls"], U)[same].max() <= FP32_TOL
+    parity_every_instance(sol1, st1, ref, mk, x0, kw, prob.rho, tag=f"rocket N={N} one-shot {kernel}")
     bs.close()
 
 
@@ -831,9 +880,7 @@ def test_linear_constraints_vs_oracle(hip_lib, oracle_built, monkeypatch, case, 
     prob, x0, refs, fdyn, cones, Ax, bx, Au, bu = _lin_case(case)
     B = x0.shape[1]
     kw = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=120, check_termination=1)
-    X, U = np.zeros((prob.nx, prob.N, B)), np.zeros((prob.nu, prob.N - 1, B))
-    it = np.zeros(B, dtype=int)
-    for b in range(B):
+    def mk(b=None):
         o = oracle_built.CpuSolver("orc64", prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N)
         o.update_settings(**kw)
         o.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
@@ -845,10 +892,9 @@ def test_linear_constraints_vs_oracle(hip_lib, oracle_built, monkeypatch, case, 
         if refs is not None:
             o.set_x_ref(refs[0])
             o.set_u_ref(refs[1])
-        o.set_x0(x0[:, b])
-        o.solve()
-        r = o.get_solution()
-        X[:, :, b], U[:, :, b], it[b] = r["x"], r["u"], r["iter"]
+        return o
+    ref = _oracle_loop(mk, x0)
+    X, U, it = ref["x"], ref["u"], ref["iter"]
     bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
     bs.update_settings(**kw)
     bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
@@ -864,10 +910,7 @@ def test_linear_constraints_vs_oracle(hip_lib, oracle_built, monkeypatch, case, 
     bs.set_x0(x0)
     bs.solve()
     sol, st = bs.get_solution(), bs.get_status()
-    same = st["iter"] == it
-    assert same.mean() >= 0.9 and np.all(np.abs(st["iter"] - it) <= 1)
-    assert nrel_batch(sol["states"], X)[same].max() <= FP32_TOL
-    assert nrel_batch(sol["controls"], U)[same].max() <= FP32_TOL
+    parity_every_instance(sol, st, ref, mk, x0, kw, prob.rho, tag=f"linear {case} {kernel}")
     assert len(set(it.tolist())) >= 1 and (np.einsum("ij,jkb->ikb", Au, U) - bu[:, None, None]).max() > -0.05  # rows matter
     # the linear pairs persist too: a warm second solve continues from the stored state
     bs.solve()
@@ -878,8 +921,7 @@ def test_linear_constraints_vs_oracle(hip_lib, oracle_built, monkeypatch, case, 
     bs.solve()
     sol1, st1 = bs.get_solution(), bs.get_status()
     assert np.array_equal(st1["iter"], st["iter"])
-    assert nrel_batch(sol1["states"], X)[same].max() <= FP32_TOL
-    assert nrel_batch(sol1["controls"], U)[same].max() <= FP32_TOL
+    parity_every_instance(sol1, st1, ref, mk, x0, kw, prob.rho, tag=f"linear {case} {kernel} one-shot")
     with pytest.raises(t.TinyMPCError):
         bs.set_linear_constraints(np.zeros((1, prob.nx)), [1.0], np.zeros((0, prob.nu)), [])   # an all-zero row
     with pytest.raises(t.TinyMPCError):
@@ -891,9 +933,8 @@ def test_linear_constraints_vs_oracle(hip_lib, oracle_built, monkeypatch, case, 
 def test_stream_extensions_random_sweep(hip_lib, oracle_built, seed):
     """Cones that start anywhere and straddle lane boundaries (up to two per side, dimensions 2..4), dense linear
     rows, an affine term, on shapes whose rows split unevenly over the four lanes — against the fp64 restatement
-    (UNPINNED with respect to the reference, like every cone / linear / fdyn test).  Tolerance as in
-    test_stream_kernel_random_sweep."""
-    SWEEP_TOL = 5e-5
+    (UNPINNED with respect to the reference, like every cone / linear / fdyn test).  Every instance at the 1e-5 bar."""
+    SWEEP_TOL = FP32_TOL
     rng = np.random.default_rng(7000 + seed)
     nx, nu = [(8, 3), (10, 4), (6, 2), (12, 4)][seed]
     N, B = int(rng.integers(4, 18)), int(rng.integers(3, 40))
@@ -908,9 +949,7 @@ def test_stream_extensions_random_sweep(hip_lib, oracle_built, seed):
     Au, bu = rng.standard_normal((2, nu)), rng.uniform(0.2, 0.5, 2)
     x0 = np.asfortranarray(rng.uniform(-0.5, 0.5, (nx, B)))
     kw = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=50, check_termination=1)
-    X, U = np.zeros((nx, N, B)), np.zeros((nu, N - 1, B))
-    it = np.zeros(B, dtype=int)
-    for b in range(B):
+    def mk(b=None):
         o = oracle_built.CpuSolver("orc64", prob.A, prob.B, prob.Q, prob.R, prob.rho, N)
         o.update_settings(**kw)
         o.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
@@ -918,10 +957,8 @@ def test_stream_extensions_random_sweep(hip_lib, oracle_built, seed):
         o.set_cone_constraints([c[0] for c in cu], [c[1] for c in cu], [c[2] for c in cu],
                                [c[0] for c in cx], [c[1] for c in cx], [c[2] for c in cx])
         o.set_linear_constraints(Ax, bx, Au, bu)
-        o.set_x0(x0[:, b])
-        o.solve()
-        r = o.get_solution()
-        X[:, :, b], U[:, :, b], it[b] = r["x"], r["u"], r["iter"]
+        return o
+    ref = _oracle_loop(mk, x0)
     bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, N, batch=B)
     bs.update_settings(**kw)
     bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
@@ -936,10 +973,7 @@ def test_stream_extensions_random_sweep(hip_lib, oracle_built, seed):
         bs.reset()
         bs.solve()
         sol, st = bs.get_solution(), bs.get_status()
-        same = st["iter"] == it
-        assert same.mean() >= 0.9 and np.all(np.abs(st["iter"] - it) <= 1), (nx, nu, N, B, warm)
-        assert nrel_batch(sol["states"], X)[same].max() <= SWEEP_TOL, (nx, nu, N, B, warm)
-        assert nrel_batch(sol["controls"], U)[same].max() <= SWEEP_TOL, (nx, nu, N, B, warm)
+        parity_every_instance(sol, st, ref, mk, x0, kw, prob.rho, tol=SWEEP_TOL, tag=str((nx, nu, N, B, warm)))
     bs.close()
 
 
@@ -958,19 +992,15 @@ def test_families_with_cones_linear_and_fdyn(hip_lib, oracle_built):
     Ax, bx, Au, bu = rng.standard_normal((2, nx)), rng.uniform(0.5, 1.5, 2), rng.standard_normal((2, nu)), rng.uniform(0.2, 0.5, 2)
     x0 = np.asfortranarray(rng.uniform(-0.5, 0.5, (nx, B)))
     kw = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=50, check_termination=1)
-    X, U = np.zeros((nx, N, B)), np.zeros((nu, N - 1, B))
-    it = np.zeros(B, dtype=int)
-    for b in range(B):
+    def mk(b):
         o = oracle_built.CpuSolver("orc64", A[:, :, b], Bm[:, :, b], Q[:, :, b], R[:, :, b], float(rho[b]), N)
         o.update_settings(**kw)
         o.set_bound_constraints(base.x_min, base.x_max, base.u_min, base.u_max)
         o.set_fdyn(fd)
         o.set_cone_constraints([0], [3], [0.5], [2], [3], [0.7])
         o.set_linear_constraints(Ax, bx, Au, bu)
-        o.set_x0(x0[:, b])
-        o.solve()
-        r = o.get_solution()
-        X[:, :, b], U[:, :, b], it[b] = r["x"], r["u"], r["iter"]
+        return o
+    ref = _oracle_loop(mk, x0)
     bs = t.BatchSolver.from_families(A, Bm, Q, R, rho, N)
     bs.update_settings(**kw)
     bs.set_bound_constraints(base.x_min, base.x_max, base.u_min, base.u_max)
@@ -984,9 +1014,7 @@ def test_families_with_cones_linear_and_fdyn(hip_lib, oracle_built):
         bs.reset()
         bs.solve()
         sol, st = bs.get_solution(), bs.get_status()
-        same = st["iter"] == it
-        assert same.mean() >= 0.9 and np.all(np.abs(st["iter"] - it) <= 1), warm
-        assert nrel_batch(sol["states"], X)[same].max() <= 5e-5 and nrel_batch(sol["controls"], U)[same].max() <= 5e-5, warm
+        parity_every_instance(sol, st, ref, mk, x0, kw, float(rho.max()), tag=f"families + extensions, warm={warm}")
     bs.close()
 
 
@@ -1077,11 +1105,9 @@ def test_config5_shard_tolerance_terminated(hip_lib, oracle_built):
     sol, st = bs.get_solution(), bs.get_status()
     assert status == int(np.any(ref["solved"] == 0))
     assert np.all((st["iter"] % 10 == 0))
-    same = st["iter"] == ref["iter"]
-    assert same.mean() >= 0.995, same.mean()
-    assert np.all(np.abs(st["iter"] - ref["iter"]) <= 10)
-    assert nrel_batch(sol["states"], ref["x"])[same].max() <= FP32_TOL
-    assert nrel_batch(sol["controls"], ref["u"])[same].max() <= FP32_TOL
+    frac = parity_every_instance(sol, st, ref, _plain_oracle(oracle_built, prob, kw), x0, kw, prob.rho, min_same=0.995,
+                                 tag="config 5 shard")
+    print(f"config 5 shard: {frac:.5f} of the iteration counts agree; the rest replayed on the oracle")
     bs.close()
 
 
@@ -1124,8 +1150,8 @@ def test_chunked_solve_with_compaction_is_the_same_solve(hip_lib, oracle_built, 
             assert np.array_equal(a[i][k], c[i][k]), k
     assert len(set(a[2]["iter"].tolist())) > 3            # the instances really stop at different iterations
     ref = _oracle_batch(oracle_built, prob, x0, **kw)
-    same = a[2]["iter"] == ref["iter"]
-    assert same.mean() >= 0.97 and nrel_batch(c[1]["controls"], ref["u"])[same].max() <= FP32_TOL
+    parity_every_instance(c[1], c[2], ref, _plain_oracle(oracle_built, prob, kw), x0, kw, prob.rho, min_same=0.97,
+                          tag=f"chunked {family}")
 
 
 @pytest.mark.parametrize("case", ["quadrotor30_fixed", "quadrotor30_tol", "quadrotor20_tol", "quadrotor30_refs_bounds",
@@ -1162,12 +1188,9 @@ def test_matrix_core_kernel_vs_oracle(hip_lib, oracle_built, monkeypatch, case):
     assert bs.kernel_name == f"mfma<{prob.nx},{prob.nu},{N}>"
     sol, st = bs.get_solution(), bs.get_status()
     same = st["iter"] == ref["iter"]
-    assert same.mean() >= 0.97 and np.all(np.abs(st["iter"] - ref["iter"]) <= kw["check_termination"])
-    assert np.array_equal(st["solved"][same], ref["solved"][same]) and status == int(np.any(st["solved"] == 0))
-    # the synthetic tight state bounds make that case ill-conditioned (the fp32 CPU loop is off by 2e-4 on it): 5e-5 there
-    tol = 5e-5 if "bounds" in case else FP32_TOL
-    assert nrel_batch(sol["states"], ref["x"])[same].max() <= tol
-    assert nrel_batch(sol["controls"], ref["u"])[same].max() <= tol
+    assert status == int(np.any(st["solved"] == 0))
+    parity_every_instance(sol, st, ref, _plain_oracle(oracle_built, prob, kw, xref, uref), x0, kw, prob.rho, xref=xref,
+                          uref=uref, min_same=0.97, tag=case)
     assert np.abs(st["residuals"][same] - ref["res"][same]).max() <= 1e-4 * max(1.0, np.abs(ref["res"]).max())
     # and the quad kernel, forced onto the same one-shot solve, agrees with it far inside that tolerance
     monkeypatch.setenv("TINYMPC_HIP_NO_MFMA", "1")
@@ -1235,16 +1258,12 @@ def test_per_instance_families_vs_oracle(hip_lib, oracle_built):
     rho = rng.uniform(0.5, 3.0, B)
     x0 = t.problems.cartpole_x0(B, seed=5)
     kw = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1)
-    X, U = np.zeros((4, N, B)), np.zeros((1, N - 1, B))
-    it = np.zeros(B, dtype=int)
-    for b in range(B):
+    def mk(b):
         o = oracle_built.CpuSolver("orc64", A[:, :, b], Bm[:, :, b], Q[:, :, b], R[:, :, b], float(rho[b]), N)
         o.update_settings(**kw)
         o.set_bound_constraints(base.x_min, base.x_max, base.u_min, base.u_max)
-        o.set_x0(x0[:, b])
-        o.solve()
-        r = o.get_solution()
-        X[:, :, b], U[:, :, b], it[b] = r["x"], r["u"], r["iter"]
+        return o
+    ref = _oracle_loop(mk, x0)
     bs = t.BatchSolver.from_families(A, Bm, Q, R, rho, N)
     assert bs.kernel_name == "stream4<4,1>"
     bs.update_settings(**kw)
@@ -1252,10 +1271,7 @@ def test_per_instance_families_vs_oracle(hip_lib, oracle_built):
     bs.set_x0(x0)
     bs.solve()
     sol, st = bs.get_solution(), bs.get_status()
-    same = st["iter"] == it
-    assert same.mean() >= 0.95 and np.all(np.abs(st["iter"] - it) <= 1)
-    assert nrel_batch(sol["states"], X)[same].max() <= FP32_TOL
-    assert nrel_batch(sol["controls"], U)[same].max() <= FP32_TOL
+    parity_every_instance(sol, st, ref, mk, x0, kw, float(rho.max()), min_same=0.95, tag="per-instance families")
     assert len(set(st["iter"].tolist())) > 3          # the families really differ
     bs.close()
     # all families equal == the single-family solver (different kernels, same answers to rounding)
@@ -1430,7 +1446,7 @@ def test_matrix_core_workspace_variant_vs_oracle(hip_lib, oracle_built, case):
         o.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
         orcs.append(o)
     x = x0.copy()
-    converged_steps = 0
+    converged_steps = replayed = 0
     for k in range(steps):
         if case == "state_bounds_then_off" and k == 2:   # bounds off, duals stay: g is still needed
             bs.update_settings(en_state_bound=0, en_input_bound=1, **kw)
@@ -1444,20 +1460,32 @@ def test_matrix_core_workspace_variant_vs_oracle(hip_lib, oracle_built, case):
         for b in range(B):
             o = orcs[b]
             o.set_x0(x[:, b])
+            pre = o.get_state()
             o.solve()
-            r, sv = o.get_solution(), o.get_state()
+            r = o.get_solution()
             assert abs(int(st["iter"][b]) - r["iter"]) <= 1
-            if int(st["iter"][b]) != r["iter"]:           # a residual within rounding of the tolerance: skip, resync below
-                o.set_state(*[ws[key][:, :, b] for key in ("d", "y", "g", "v", "z")])
-            else:
-                converged_steps += r["solved"]
-                assert nrel(sol["states"][:, :, b], r["x"]) <= 2e-5 and nrel(sol["controls"][:, :, b], r["u"]) <= 2e-5
-                for key in ("d", "y", "g", "v", "z"):
-                    scale = max(np.abs(sv[key]).max(), 1e-2)
-                    assert np.abs(ws[key][:, :, b] - sv[key]).max() <= 5e-5 * scale, (k, b, key)
+            if int(st["iter"][b]) != r["iter"]:
+                # a residual within rounding of the tolerance: the oracle repeats the solve from the same workspace with
+                # the GPU's termination decision imposed, and is compared like every other instance
+                o.set_state(*[pre[key] for key in ("d", "y", "g", "v", "z")])
+                o.set_forced_exit(int(st["iter"][b]) if st["solved"][b] else -1)
+                o.solve()
+                o.set_forced_exit(0)
+                r = o.get_solution()
+                assert r["iter"] == st["iter"][b]
+                replayed += 1
+            sv = o.get_state()
+            converged_steps += r["solved"]
+            ex_, eu_ = nrel(sol["states"][:, :, b], r["x"]), nrel(sol["controls"][:, :, b], r["u"])
+            assert ex_ <= FP32_TOL and eu_ <= FP32_TOL, f"step {k} instance {b}: x {ex_:.3e} u {eu_:.3e}"
+            for key in ("d", "y", "g", "v", "z"):
+                scale = max(np.abs(sv[key]).max(), 1e-2)
+                e_ = np.abs(ws[key][:, :, b] - sv[key]).max() / scale
+                assert e_ <= FP32_TOL, f"step {k} instance {b} workspace {key}: {e_:.3e}"
             xn[:, b] = prob.A @ x[:, b] + prob.B @ r["u"][:, 0]
         x = xn
     assert converged_steps >= B                           # the converged-exit path is exercised
+    assert replayed <= 0.03 * B * steps
     gmax = np.abs(bs.get_workspace()["g"]).max()
     if case == "input_bounds":
         assert gmax == 0.0

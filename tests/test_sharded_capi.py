@@ -77,7 +77,7 @@ def test_sharded_equals_single_device(hip_lib, devices, backend, tol, max_iter):
             ws1 = one.get_workspace()
             ws = sh.get_workspace()
             assert all(np.array_equal(ws[k], ws1[k]) for k in ws)
-        one.solve()                                           # keep the single-device solver in step (warm start)
+            one.solve()                                       # the single-device solver's second (warm-started) solve
     s1b, sb = one.get_solution(), sh.get_solution()
     assert np.array_equal(sb["controls"], s1b["controls"])
     # async form: enqueue, then wait
