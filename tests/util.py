@@ -64,7 +64,7 @@ def _ratio(res, pri_tol, dua_tol):
 
 
 def parity_every_instance(sol, st, ref, make_oracle, x0, settings, rho, xref=None, uref=None, tol=FP32_TOL,
-                          min_same=0.9, tag=""):
+                          min_same=0.9, tag="", tol_each=None):
     """EVERY instance is compared by solution at `tol` ("compare converged runs by solution, not by iter").
 
     Where the GPU's iteration count equals the oracle's the oracle's solution is the reference.  Where it differs — the
@@ -78,6 +78,7 @@ def parity_every_instance(sol, st, ref, make_oracle, x0, settings, rho, xref=Non
           through admm.cpp:181-205) and the GPU's x, u must match THAT within `tol`.
     ref: dict(x (nx,N,B), u (nu,N-1,B), iter (B,), res (B,4)); make_oracle(b) -> a cold, fully configured CpuSolver for
     instance b (settings, bounds, shared references, extensions; b matters for per-instance families only); per-instance references are given here as 3-D xref / uref.
+    tol_each: per-instance limits (B,) for the final comparison where a test derives one (default: `tol` for all).
     Returns the fraction of instances whose iteration count agreed."""
     it_g, so_g = np.asarray(st["iter"]), np.asarray(st["solved"])
     it_r = np.asarray(ref["iter"])
@@ -111,8 +112,10 @@ def parity_every_instance(sol, st, ref, make_oracle, x0, settings, rho, xref=Non
         X[:, :, b], U[:, :, b] = r["x"], r["u"]
         o.close()
     ex, eu = nrel_batch(sol["states"], X), nrel_batch(sol["controls"], U)
-    assert ex.max() <= tol, f"{tag}: x worst {ex.max():.3e} at instance {ex.argmax()} (iter {it_g[ex.argmax()]})"
-    assert eu.max() <= tol, f"{tag}: u worst {eu.max():.3e} at instance {eu.argmax()} (iter {it_g[eu.argmax()]})"
+    lim = np.broadcast_to(np.asarray(tol_each if tol_each is not None else tol, dtype=np.float64), ex.shape)
+    wx, wu = int(np.argmax(ex / lim)), int(np.argmax(eu / lim))
+    assert ex[wx] <= lim[wx], f"{tag}: x of instance {wx} off by {ex[wx]:.3e} (limit {lim[wx]:.1e}, iter {it_g[wx]})"
+    assert eu[wu] <= lim[wu], f"{tag}: u of instance {wu} off by {eu[wu]:.3e} (limit {lim[wu]:.1e}, iter {it_g[wu]})"
     if "solved" in ref:
         same = it_g == it_r
         assert np.array_equal(so_g[same], np.asarray(ref["solved"])[same]), tag

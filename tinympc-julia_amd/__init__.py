@@ -20,15 +20,59 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtinympc_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tinympc_hip.h")
 
 
+STAMP_PATH = os.path.join(_HERE, "lib", "build_stamp.json")
+
+
+def source_hash():
+    """sha256 over the library's sources (csrc/*, include/tinympc_hip.h): what the built .so is stamped with"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")) +
+                   glob.glob(os.path.join(_HERE, "csrc", "*.cpp")) + [os.path.join(_HERE, "csrc", "Makefile"), HEADER_PATH])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def build(jobs=8, verbose=False):
-    """Compile csrc/ for gfx950 with hipcc into lib/libtinympc_hip.so (cross-compiles without a GPU)."""
+    """Compile csrc/ for gfx950 with hipcc into lib/libtinympc_hip.so (cross-compiles without a GPU).  `make` is
+    incremental (seconds when nothing changed); the result is stamped with the hash of the sources it was built from,
+    the wall time of the make and the compiler version (lib/build_stamp.json)."""
+    import json
+    import time
     cmd = ["make", "-C", os.path.join(_HERE, "csrc"), f"-j{jobs}"]
     if not verbose:
         cmd.insert(1, "-s")
+    before = os.path.getmtime(LIB_PATH) if os.path.isfile(LIB_PATH) else None
+    t0 = time.time()
     subprocess.check_call(cmd)
+    secs = time.time() - t0
     if not os.path.isfile(LIB_PATH):
         raise RuntimeError(f"build did not produce {LIB_PATH}")
+    relinked = before is None or os.path.getmtime(LIB_PATH) != before
+    if relinked or not os.path.isfile(STAMP_PATH):
+        try:
+            ver = subprocess.run(["/opt/rocm/bin/hipcc", "--version"], capture_output=True, text=True).stdout.splitlines()
+        except Exception:
+            ver = []
+        json.dump({"source_sha256": source_hash(), "make_seconds": round(secs, 1), "jobs": jobs,
+                   "from_scratch": before is None, "hipcc_version": [l for l in ver if l.strip()][:3],
+                   "built_at": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
+                   "host_cpus": os.cpu_count()}, open(STAMP_PATH, "w"), indent=1)
     return LIB_PATH
+
+
+def ensure_built(jobs=8):
+    """The library, rebuilt from source whenever it is missing or was built from other sources than the ones present
+    (hash in lib/build_stamp.json — file times do not survive a repository snapshot)."""
+    import json
+    try:
+        fresh = os.path.isfile(LIB_PATH) and json.load(open(STAMP_PATH))["source_sha256"] == source_hash()
+    except Exception:
+        fresh = False
+    return LIB_PATH if fresh else build(jobs)
 
 
 from . import problems  # noqa: E402,F401
