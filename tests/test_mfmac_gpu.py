@@ -1,0 +1,191 @@
+"""The LDS-resident matrix-core kernel (csrc/admm_mfmac.hip.h, "mfmac<6,3>"): one-shot solves with box bounds, the affine
+dynamics term and second-order cones — BASELINE config 4's path — against the fp64 oracle, every instance by solution
+(tests/util.parity_every_instance), and against the run-time-horizon stream kernel it replaces for these solves.
+Cones / fdyn are the UNPINNED extensions (no reference source): the oracle itself is pinned for them by
+tests/test_independent_optimum.py and tests/test_extensions_cpu.py."""
+import numpy as np
+import pytest
+
+import tinympc_julia_amd as t
+from tests.util import FP32_TOL, nrel_batch, parity_every_instance
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(oracle_built, prob, kw, xr, ur, fdyn, cones):
+    def make(b=None):
+        o = oracle_built.CpuSolver("orc64", prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N)
+        o.update_settings(**kw)
+        o.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        if fdyn is not None:
+            o.set_fdyn(fdyn)
+        if cones is not None:
+            o.set_cone_constraints(*cones)
+        if xr is not None:
+            o.set_x_ref(xr)
+            o.set_u_ref(ur)
+        return o
+    return make
+
+
+def _loop(make, x0):
+    B = x0.shape[1]
+    out = None
+    for b in range(B):
+        o = make(b)
+        o.set_x0(x0[:, b])
+        o.solve()
+        r = o.get_solution()
+        if out is None:
+            out = dict(x=np.zeros(r["x"].shape + (B,)), u=np.zeros(r["u"].shape + (B,)), iter=np.zeros(B, dtype=int),
+                       solved=np.zeros(B, dtype=int), res=np.zeros((B, 4)))
+        out["x"][:, :, b], out["u"][:, :, b] = r["x"], r["u"]
+        out["iter"][b], out["solved"][b], out["res"][b] = r["iter"], r["solved"], r["res"]
+        o.close()
+    return out
+
+
+def _solver(prob, B, kw, xr, ur, fdyn, cones):
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+    bs.update_settings(**kw)
+    bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    if fdyn is not None:
+        bs.set_fdyn(fdyn)
+    if cones is not None:
+        bs.set_cone_constraints(*cones)
+    bs.set_warm_start(False)                               # one-shot: cold start, workspace not kept
+    if xr is not None:
+        bs.set_x_ref(xr)
+        bs.set_u_ref(ur)
+    return bs
+
+
+ROCKET_CONES = ([0], [3], [0.25], [0], [3], [0.5])          # inputs first (bindings.cpp:453-459)
+SETTINGS = {
+    "fixed60": dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=60, check_termination=1),
+    "tol": dict(abs_pri_tol=2e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1),   # rocket_landing_constraints.jl:61-62
+    "tol_ct10": dict(abs_pri_tol=2e-3, abs_dua_tol=1e-3, max_iter=95, check_termination=10),
+    "fixed_ct7": dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=45, check_termination=7),   # last check at 42, three more iterations
+    "nocheck": dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=30, check_termination=0),
+}
+
+
+@pytest.mark.parametrize("N", [10, 50, 23, 2])
+@pytest.mark.parametrize("mode", ["fdyn+cones", "fdyn", "cones"])
+@pytest.mark.parametrize("setting", list(SETTINGS))
+def test_mfmac_rocket_vs_oracle(hip_lib, oracle_built, N, mode, setting):
+    if N in (23, 2) and (mode != "fdyn+cones" or setting not in ("fixed60", "tol")):
+        pytest.skip("the odd horizons run the two main settings only")
+    B = 37                                                  # ragged: two full wavefronts of 16 and one of 5
+    kw = SETTINGS[setting]
+    prob = t.problems.rocket(N)
+    x0 = t.problems.rocket_x0(B, seed=2)
+    xr, ur = t.problems.rocket_refs(N)
+    fdyn = prob.fdyn if "fdyn" in mode else None
+    cones = ROCKET_CONES if "cones" in mode else None
+    mk = _oracle(oracle_built, prob, kw, xr, ur, fdyn, cones)
+    ref = _loop(mk, x0)
+    bs = _solver(prob, B, kw, xr, ur, fdyn, cones)
+    bs.set_x0(x0)
+    status = bs.solve()
+    assert bs.kernel_name == "mfmac<6,3>"
+    sol, st = bs.get_solution(), bs.get_status()
+    assert status == int(np.any(st["solved"] == 0))
+    parity_every_instance(sol, st, ref, mk, x0, kw, prob.rho, tag=f"N={N} {mode} {setting}")
+    same = st["iter"] == ref["iter"]
+    if kw["check_termination"] > 0:
+        assert np.allclose(st["residuals"][same], ref["res"][same], rtol=1e-2, atol=2e-5), \
+            np.abs(st["residuals"][same] - ref["res"][same]).max()
+    # a second solve of the same inputs returns the same bits (nothing of the first one survives)
+    bs.solve()
+    assert np.array_equal(bs.get_solution()["controls"], sol["controls"])
+    assert np.array_equal(bs.get_status()["iter"], st["iter"])
+    bs.close()
+
+
+@pytest.mark.parametrize("setting", ["fixed60", "tol"])
+def test_mfmac_equals_stream_kernel(hip_lib, monkeypatch, setting):
+    """same solve on the HBM-streaming kernel it replaces: same arithmetic, different storage and mat-vec grouping"""
+    N, B = 50, 70
+    kw = SETTINGS[setting]
+    prob = t.problems.rocket(N)
+    x0 = t.problems.rocket_x0(B, seed=12)
+    xr, ur = t.problems.rocket_refs(N)
+    outs = []
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("TINYMPC_HIP_NO_MFMAC", env)
+        bs = _solver(prob, B, kw, xr, ur, prob.fdyn, ROCKET_CONES)
+        bs.set_x0(x0)
+        bs.solve()
+        outs.append((bs.kernel_name, bs.get_solution(), bs.get_status()))
+        bs.close()
+    assert outs[0][0] == "mfmac<6,3>" and outs[1][0] == "stream4<6,3>"
+    same = outs[0][2]["iter"] == outs[1][2]["iter"]
+    assert same.mean() >= 0.95
+    assert nrel_batch(outs[0][1]["states"], outs[1][1]["states"])[same].max() <= 3e-6
+    assert nrel_batch(outs[0][1]["controls"], outs[1][1]["controls"])[same].max() <= 3e-6
+
+
+@pytest.mark.parametrize("case", ["cones_across_groups", "two_state_cones_knot_bounds", "zero_refs_box_only"])
+def test_mfmac_general_cones_and_bounds(hip_lib, oracle_built, monkeypatch, case):
+    """cones whose rows sit in different lane groups and slots (rows 2..5 = slot 0 of groups 2, 3 and slot 1 of groups
+    0, 1), two cones on the state side, a 2-row input cone; bounds that depend on the knot; no references"""
+    rng = np.random.default_rng({"cones_across_groups": 3, "two_state_cones_knot_bounds": 4, "zero_refs_box_only": 5}[case])
+    nx, nu, N, B = 6, 3, 17, 29
+    A = np.eye(nx) + 0.15 * rng.standard_normal((nx, nx)) / np.sqrt(nx)
+    A *= 0.97 / np.abs(np.linalg.eigvals(A)).max()
+    prob = t.problems.Problem("rand", A, 0.5 * rng.standard_normal((nx, nu)), np.diag(rng.uniform(0.5, 5.0, nx)),
+                              np.diag(rng.uniform(0.5, 3.0, nu)), float(rng.uniform(0.5, 2.0)), N)
+    prob.x_min, prob.x_max = -rng.uniform(0.8, 2.0, (nx, 1)) * np.ones((1, N)), rng.uniform(0.8, 2.0, (nx, 1)) * np.ones((1, N))
+    prob.u_min, prob.u_max = -rng.uniform(0.2, 0.6, (nu, 1)) * np.ones((1, N - 1)), rng.uniform(0.2, 0.6, (nu, 1)) * np.ones((1, N - 1))
+    fdyn = 0.02 * rng.standard_normal(nx)
+    xr, ur = 0.2 * rng.standard_normal((nx, N)), 0.1 * rng.standard_normal((nu, N - 1))
+    cones = None
+    if case == "cones_across_groups":
+        cones = ([1], [2], [0.8], [2], [4], [0.9])          # input rows 1..2; state rows 2..5
+    elif case == "two_state_cones_knot_bounds":
+        cones = ([0], [3], [0.5], [0, 3], [3, 3], [0.6, 1.2])
+        prob.x_min[:, N // 2:] -= 0.3                        # per-knot bounds: the pack keeps every knot
+        prob.u_max[:, ::2] += 0.1
+    else:
+        monkeypatch.setenv("TINYMPC_HIP_MFMAC_ALL", "1")    # box-only one-shot solve of a run-time-horizon shape
+        fdyn, xr, ur = None, None, None
+    kw = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=50, check_termination=1)
+    x0 = np.asfortranarray(rng.uniform(-0.5, 0.5, (nx, B)))
+    mk = _oracle(oracle_built, prob, kw, xr, ur, fdyn, cones)
+    ref = _loop(mk, x0)
+    bs = _solver(prob, B, kw, xr, ur, fdyn, cones)
+    bs.set_x0(x0)
+    bs.solve()
+    assert bs.kernel_name == "mfmac<6,3>"
+    sol, st = bs.get_solution(), bs.get_status()
+    parity_every_instance(sol, st, ref, mk, x0, kw, prob.rho, tag=case)
+    assert len(set(st["iter"].tolist())) > 1 or case == "zero_refs_box_only"
+    bs.close()
+
+
+def test_mfmac_is_not_used_where_it_does_not_apply(hip_lib):
+    """warm-started / workspace-keeping solves, per-instance references and linear rows stay on the stream kernel"""
+    prob = t.problems.rocket(20)
+    xr, ur = t.problems.rocket_refs(20)
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=8)
+    bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    bs.set_fdyn(prob.fdyn)
+    bs.set_cone_constraints(*ROCKET_CONES)
+    bs.set_x0(t.problems.rocket_x0(8, seed=1))
+    bs.solve()                                              # default: the workspace persists (reference semantics)
+    assert bs.kernel_name == "stream4<6,3>"
+    bs.set_warm_start(False)
+    bs.solve()
+    assert bs.kernel_name == "mfmac<6,3>"
+    bs.set_x_ref(np.repeat(xr[:, :, None], 8, axis=2))      # per-instance references
+    bs.set_u_ref(np.repeat(ur[:, :, None], 8, axis=2))
+    bs.solve()
+    assert bs.kernel_name == "stream4<6,3>"
+    bs.set_x_ref(xr)
+    bs.set_u_ref(ur)
+    bs.set_linear_constraints(np.array([[0.0, 0.0, 0.0, 0.0, 0.0, -1.0]]), [2.5], np.zeros((0, 3)), [])
+    bs.solve()
+    assert bs.kernel_name == "stream4<6,3>"
+    bs.close()

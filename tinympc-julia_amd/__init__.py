@@ -52,7 +52,11 @@ def build(jobs=8, verbose=False):
     if not os.path.isfile(LIB_PATH):
         raise RuntimeError(f"build did not produce {LIB_PATH}")
     relinked = before is None or os.path.getmtime(LIB_PATH) != before
-    if relinked or not os.path.isfile(STAMP_PATH):
+    try:
+        stale = json.load(open(STAMP_PATH))["source_sha256"] != source_hash()
+    except Exception:
+        stale = True
+    if relinked or stale:
         try:
             ver = subprocess.run(["/opt/rocm/bin/hipcc", "--version"], capture_output=True, text=True).stdout.splitlines()
         except Exception:

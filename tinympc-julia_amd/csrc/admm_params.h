@@ -81,6 +81,8 @@ struct AdmmParams {
                                          // persists between solves like the reference's cache
     // ---- stream kernel only: one problem family PER INSTANCE ----
     const float *het_aux;                // [nx + nu + 1][batch]: diag(Q)+rho, diag(R)+rho, rho of each instance
+    // ---- mfmac kernel only: 0 = the bounds pack holds one knot's bounds (they do not depend on the knot) ----
+    int bounds_stride;
 };
 
 #ifdef __HIPCC__

@@ -56,6 +56,16 @@ const KernelEntry *select_quad_kernel(int nx, int nu, int N, int batch) {
     return nullptr;
 }
 
+const ConeEntry *mfmac_entry_6_3();
+
+// LDS-resident matrix-core kernel (admm_mfmac.hip.h): instantiated for the rocket's shape
+const ConeEntry *find_cone_kernel(int nx, int nu) {
+    static const ConeEntry *const table[] = {mfmac_entry_6_3()};
+    for (const ConeEntry *e : table)
+        if (e->nx == nx && e->nu == nu) return e;
+    return nullptr;
+}
+
 const StreamEntry *stream4_entry_2_1();
 const StreamEntry *stream4_entry_2_2();
 const StreamEntry *stream4_entry_3_1();

@@ -40,6 +40,19 @@ struct StreamEntry {
     hipError_t (*launch)(const AdmmParams &, int precision, int ext, bool het, hipStream_t);  // ext: 0 | 1 fdyn, cones | 2 + linear
 };
 const StreamEntry *find_stream_kernel(int nx, int nu);
+// One (nx, nu) instantiation of the LDS-resident matrix-core kernel with a run-time horizon (admm_mfmac.hip.h):
+// one-shot solves with box bounds, the affine term and cones.
+struct ConeEntry {
+    int nx, nu;
+    const char *name;
+    void (*build_coef)(const Solver &, std::vector<unsigned char> &);
+    void (*build_bounds)(const Solver &, std::vector<float> &);
+    size_t (*lds_bytes)(const Solver &);        // per workgroup (one wavefront = 16 instances)
+    size_t (*scratch_floats)(const Solver &);   // for the whole batch
+    bool (*bounds_vary)(const Solver &);
+    hipError_t (*launch)(const AdmmParams &, bool ext, size_t lds, hipStream_t);
+};
+const ConeEntry *find_cone_kernel(int nx, int nu);
 hipError_t launch_generic(const AdmmParams &, int precision, hipStream_t);
 void build_generic_coef(const Solver &, std::vector<unsigned char> &);
 void build_generic_bounds(const Solver &, std::vector<float> &);
@@ -105,7 +118,8 @@ struct Solver {
     bool packs_dirty = true;
     bool state_bounds_active = false;  // any finite (|b| < 1e17) enabled state bound
     const KernelEntry *ke = nullptr;  // specialised quad kernel, or
-    const StreamEntry *se = nullptr;  // run-time-horizon stream kernel, or (both null) the generic kernel
+    const StreamEntry *se = nullptr;  // run-time-horizon stream kernel, or
+    const ConeEntry *ce = nullptr;    // LDS-resident matrix-core kernel (one-shot solves), or (all null) the generic kernel
     std::string kernel_name;
     // device buffers
     unsigned char *d_coef = nullptr;

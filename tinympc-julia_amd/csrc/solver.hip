@@ -341,10 +341,27 @@ int Solver::select_kernel(bool rollout) {
         set_error("per-instance families need a stream-kernel instantiation for (nx, nu) (nx in {2,3,4,6,8,10,12}, nu <= 4)");
         return -1;
     }
-    if (k != ke || s2 != se) packs_dirty = true;
+    // one-shot solves (cold start, workspace not kept) with the affine term and / or cones: the LDS-resident matrix-core
+    // kernel of the shape (TINYMPC_HIP_NO_MFMAC: tuning / test aid).  TINYMPC_HIP_MFMAC_ALL=1 also sends box-only
+    // one-shot solves of the shape there.
+    const ConeEntry *c2 = nullptr;
+    const bool plain_ok = std::getenv("TINYMPC_HIP_MFMAC_ALL") != nullptr;
+    if ((s2 || (k && plain_ok)) && !warm_start && chunk_iters == 0 && !rollout && precision == 0 && !hetero && !lin_active() &&
+        !st.adaptive_rho && (has_fdyn || cones_active() || plain_ok) && xref_kind < 2 && uref_kind < 2 &&
+        !(refs_device_owned && ref_mode == REF_PER_INSTANCE) && !std::getenv("TINYMPC_HIP_NO_MFMAC") && !genv &&
+        !std::getenv("TINYMPC_HIP_NO_MFMA")) {
+        c2 = find_cone_kernel(nx, nu);
+        if (c2 && c2->lds_bytes(*this) > 160 * 1024 - 1024) c2 = nullptr;   // horizon too long for one wavefront's LDS
+        if (c2) {
+            k = nullptr;
+            s2 = nullptr;
+        }
+    }
+    if (k != ke || s2 != se || c2 != ce) packs_dirty = true;
     ke = k;
     se = s2;
-    kernel_name = ke ? ke->name : (se ? se->name : "generic");
+    ce = c2;
+    kernel_name = ke ? ke->name : (se ? se->name : (ce ? ce->name : "generic"));
     return 0;
 }
 
@@ -467,6 +484,9 @@ int Solver::upload_packs() {
     if (ke) {
         ke->build_coef(*this, coef);
         ke->build_bounds(*this, bnd);
+    } else if (ce) {
+        ce->build_coef(*this, coef);
+        ce->build_bounds(*this, bnd);
     } else if (se) {
         se->build_coef(*this, coef);
         se->build_bounds(*this, bnd);
@@ -694,6 +714,7 @@ int Solver::ensure_extension_buffers() {
     const size_t sets = (size_t)constraint_sets();
     size_t need = Bn * ((2 + 3 * sets) * EX + (3 + 3 * sets) * EU);  // generic kernel: admm_generic.hip.h
     if (se) need = std::max(need, Bn * se->scratch_floats(N, (int)sets));
+    if (ce) need = ce->scratch_floats(*this);
     if (scratch_cap < need) {
         if (dev_alloc(d_scratch, need)) return -1;
         scratch_cap = need;
@@ -918,7 +939,8 @@ int Solver::launch_pass(hipStream_t stream, int mpc_steps, const int *idx, int n
     P.szl = d_szl;
     // the quad and stream kernels keep the status block clean themselves (fold_status); the generic kernel
     // accumulates straight into it
-    if (!ke && !se) HIP_TRY(hipMemsetAsync(d_gstat, 0, GSTAT_WORDS * sizeof(uint32_t), stream));
+    P.bounds_stride = (ce && ce->bounds_vary(*this)) ? 1 : 0;
+    if (!ke && !se && !ce) HIP_TRY(hipMemsetAsync(d_gstat, 0, GSTAT_WORDS * sizeof(uint32_t), stream));
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (profiling) {
         if (ev_ring.empty()) {
@@ -934,8 +956,9 @@ int Solver::launch_pass(hipStream_t stream, int mpc_steps, const int *idx, int n
     if (state_bounds_active && save) g_maybe_nonzero = true;
     const bool carry_g = state_bounds_active || (ke && ke->G == 16 && g_maybe_nonzero);
     HIP_TRY(ke ? ke->launch(P, precision, carry_g, stream)
-               : (se ? se->launch(P, precision, lin_active() ? 2 : ((has_fdyn || cones_active()) ? 1 : 0), hetero, stream)
-                     : launch_generic(P, precision, stream)));
+               : (ce ? ce->launch(P, cones_active(), ce->lds_bytes(*this), stream)
+                     : (se ? se->launch(P, precision, lin_active() ? 2 : ((has_fdyn || cones_active()) ? 1 : 0), hetero, stream)
+                           : launch_generic(P, precision, stream))));
     if (profiling) {
         HIP_TRY(hipEventRecord(ev1, stream));
         launches += 1;
