@@ -1083,7 +1083,7 @@ def test_config4_full_size_properties(hip_lib, oracle_built):
     ref = _oracle_loop(_rocket_oracle(oracle_built, prob, xr, ur, True, True, kw), base)
     assert nrel_batch(sol["states"][:, :, :D], ref["x"]).max() <= FP32_TOL
     assert nrel_batch(sol["controls"][:, :, :D], ref["u"]).max() <= FP32_TOL
-    assert np.allclose(bs.get_status()["residuals"][:D], ref["res"], rtol=1e-2, atol=2e-5)
+    assert np.allclose(bs.get_status()["residuals"][:D], ref["res"], rtol=1e-2, atol=5e-5)   # a few fp32 ulp of |u| ~ 100
     U = sol["controls"].reshape(3, N - 1, B // D, D)
     X = sol["states"].reshape(6, N, B // D, D)
     assert np.all(np.isfinite(U)) and np.all(np.isfinite(X))

@@ -6,8 +6,8 @@
 // instances that are being iterated need their state on chip, and a one-shot solve needs little of it:
 //   per knot and row   one dual per constraint set (g | y, gc | yc),
 //                      ONE fused array handed from the forward to the backward sweep: sum over sets of (slack - dual),
-//                      which for input rows shares its slot with the feed-forward d (d_k is written by the backward
-//                      sweep exactly where su_k was read, and read by the forward sweep before su_k is written)
+//                      which for input rows shares its slot with the feed-forward term (t_k = B'p + r is written by the
+//                      backward sweep exactly where su_k was read, and read by the forward sweep before su_k is written)
 // = 24 floats per knot for the rocket (6 state rows, 3 of them in a cone, 3 input rows in a cone): 4.7 KB per instance
 // at N = 50, so 16 instances — one wavefront — take 75 KB of LDS and a CU holds two wavefronts' worth.  Nothing of it
 // ever goes to HBM: traffic is x0 in, the solution out, plus (see "residuals") the previous slack around a check.
@@ -18,10 +18,12 @@
 // D[4 v + l / 16][l % 16], experiments/mfma_probe.hip) lane group g carries in its three "slots"
 //     slot 0: x_g      slot 1: x_{4+g}      slot 2: u_g
 // and a product's result registers are the next product's B operands as they stand: no cross-lane move on the chain.
-//     forward : c = {f, nd};  c += M_u nd;  c += M_x0 x[0];  c += M_x1 x[1]      -> c[0..1] = x+,  c[2] = u = -Kinf x - d
-//               (M = [A - B Kinf, B; -Kinf, 0], nd = -d; the product with nd does not wait for x)
-//     backward: c = {q + APf, r + BPf};  c += N_u r;  c += N_x0 p[0];  c += N_x1 p[1]   -> c[0..1] = p-,  c[2] = B'p + r
-//               (N = [AmBKt, -Kinf'; B', 0]);  d = Quu_inv c[2] is one more product, off the chain
+//     forward : c = {f, 0};  c += M_t t;  c += M_x0 x[0];  c += M_x1 x[1]        -> c[0..1] = x+,  c[2] = u = -Kinf x - d
+//               (M = [A - B Kinf, -B Quu_inv; -Kinf, -Quu_inv] applied to [x; t]: the feed-forward d = Quu_inv t of
+//               admm.cpp:17 is never formed, t = B'p + r is what the backward sweep leaves; the product with t does not
+//               wait for x)
+//     backward: c = {q + APf, r + BPf};  c += N_u r;  c += N_x0 p[0];  c += N_x1 p[1]   -> c[0..1] = p-,  c[2] = t
+//               (N = [AmBKt, -Kinf'; B', 0])
 // The x slots of position k hold knot k + 1 (the rollout produces x_{k+1} together with u_k), so both sweeps index the
 // state with ONE wave-uniform position; the backward sweep reads position i for q_{i+1} (used at once) and r_i (used one
 // stage later).  Knot 0 of the state side (x0 is given) is handled once per iteration outside the loop.
@@ -41,6 +43,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "admm_params.h"
 #include "admm_mfma.hip.h"
 
@@ -51,7 +55,7 @@ struct ConeShape {
     static_assert(NX >= 1 && NX <= 8 && NU >= 1 && NU <= 4, "mfmac kernel: nx <= 8, nu <= 4");
     static constexpr int XS = NX > 4 ? 2 : 1;  // state slots in use
     // fp64 operand fields, [field][64 lanes]
-    enum { F_MF0 = 0, F_MF1, F_MF2, F_MB0, F_MB1, F_MB2, F_MQ, F_FD0, F_FD1, F_APF0, F_APF1, F_BPF, NF };
+    enum { F_MF0 = 0, F_MF1, F_MF2, F_MB0, F_MB1, F_MB2, F_FD0, F_FD1, F_APF0, F_APF1, F_BPF, NF };
     static constexpr int NROW = NX + NU;
     // fp32 pack: `nk` knots of [lo(NROW) hi(NROW)] (state rows of knot k, input rows of knot k; nk = 1 when the bounds do
     // not depend on the knot, AdmmParams::bounds_stride = 0), then Qd[NX] Rd[NU], then -inf, +inf pads
@@ -59,22 +63,36 @@ struct ConeShape {
     // LDS state, per position (a knot's worth of the 16 instances): [A1: NROW rows][A3: NROW rows][A2: rows that lie in
     // a cone] x 16 instances, + one zero pad cell per lane for the slots a lane does not own
     static constexpr int pos_len(int cone_rows) { return 16 * (2 * NROW + cone_rows); }
+    static constexpr int PAD_LEN = 64 + 16 * NROW;  // a lane's pad cell and its A3 twin (A3_DISP further on)
     static constexpr size_t lds_bytes(int N, int nk, int cone_rows) {
-        return sizeof(float) * ((size_t)pos_len(cone_rows) * (N - 1) + 64 + bounds_len(nk) + (((size_t)NROW * N + 1) & ~(size_t)1)) +
+        return sizeof(float) * ((size_t)pos_len(cone_rows) * (N - 1) + PAD_LEN + bounds_len(nk) + (((size_t)NROW * N + 2) & ~(size_t)1)) +
                sizeof(double) * 8;
     }
     // HBM scratch per wavefront (floats): cone slack of the iteration before a check, [pos 0..N-1][slot][lane]
     static constexpr size_t scratch_floats(int N) { return (size_t)N * 3 * 64; }
 };
 
-// sum over the four lanes (16 apart) of an instance
+// sum over the four lanes (16 apart) of an instance, on the VALU: v_permlane16_swap exchanges the odd 16-lane rows of
+// its first operand with the even rows of its second, v_permlane32_swap the upper 32 lanes with the lower 32, so with
+// both operands equal the two results add up to the pair sums in every lane (no LDS round trip as with ds_bpermute)
 __device__ __forceinline__ float mfc_inst_sum(float v) {
+#ifdef TMPC_MFMAC_SHFL
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
     return v;
+#endif
+    // (inline asm: through __builtin_amdgcn_permlane16_swap the compiler of this image loses the second result when
+    // both are consumed by one add — it emits v_add v0, v0, v0 — experiments/permlane_probe.hip.  The s_nop covers the
+    // VALU-write -> permlane-read hazard the compiler would otherwise pad for.)
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    a += b;
+    b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
 }
 
-template <int NX, int NU, int REFS, bool EXT>
+template <int NX, int NU, int REFS, bool EXT, bool BV>
 __global__ __launch_bounds__(64) void admm_mfmac_kernel(const AdmmParams P) {
     using S = ConeShape<NX, NU>;
     constexpr int XS = S::XS, NROW = S::NROW;
@@ -95,12 +113,12 @@ __global__ __launch_bounds__(64) void admm_mfmac_kernel(const AdmmParams P) {
     int cone_rows = 0;
     for (int rho = 0; rho < NROW; ++rho) cone_rows += in_cone(rho) ? 1 : 0;
     const int PLEN = S::pos_len(cone_rows);
-    const int nk = P.bounds_stride ? N : 1;
+    const int nk = BV ? N : 1;   // BV: the bounds depend on the knot (per-knot pack in LDS), else one knot's worth in registers
     float *s_state = reinterpret_cast<float *>(s_raw_c);
-    float *s_pad = s_state + (size_t)PLEN * (N - 1);
-    float *s_bnd = s_pad + 64;
-    float *s_ref = s_bnd + S::bounds_len(nk);
-    double *s_pterm = reinterpret_cast<double *>(s_ref + (((size_t)NROW * N + 1) & ~(size_t)1));
+    float *s_pad = s_state + (size_t)PLEN * (N - 1);          // S::PAD_LEN zeros: what lanes without a row read and write
+    float *s_bnd = s_pad + S::PAD_LEN;
+    float *s_ref = s_bnd + S::bounds_len(nk);                 // [N][NROW] and one zero cell behind
+    double *s_pterm = reinterpret_cast<double *>(s_ref + (((size_t)NROW * N + 2) & ~(size_t)1));
     __shared__ uint4 s_cmask[8 * 4];  // [cone][lane group]: x head bits, x axis bits, u head bit, u axis bit (bit = slot)
 
     const int l = threadIdx.x, g = l >> 4, j = l & 15;
@@ -114,12 +132,15 @@ __global__ __launch_bounds__(64) void admm_mfmac_kernel(const AdmmParams P) {
 
     // ---- stage constants ----
     for (int i = l; i < S::bounds_len(nk); i += 64) s_bnd[i] = P.bounds[i];
-    const float *Qd = s_bnd + 2 * NROW * nk, *Rd = Qd + NX;
     if constexpr (REFS == REF_SHARED) {
         // -(Xref .* Q~), -(Uref .* R~) as update_linear_cost forms them (admm.cpp:77-80), per knot
-        for (int i = l; i < NROW * N; i += 64) {
+        for (int i = l; i < NROW * N + 1; i += 64) {
             const int k = i / NROW, r = i % NROW;
             float v = 0.f;
+            if (i == NROW * N) {
+                s_ref[i] = 0.f;
+                continue;
+            }
             if (r < NX) v = -(P.xref[k * NX + r] * P.bounds[2 * NROW * nk + r]);
             else if (k < N - 1) v = -(P.uref[k * NU + (r - NX)] * P.bounds[2 * NROW * nk + r]);
             s_ref[i] = v;
@@ -156,42 +177,79 @@ __global__ __launch_bounds__(64) void admm_mfmac_kernel(const AdmmParams P) {
         }
     }
     // cold start = the zero workspace tiny_setup leaves (tiny_api.cpp:73-88)
-    for (int i = l; i < PLEN * (N - 1) + 64; i += 64) s_state[i] = 0.f;
+    for (int i = l; i < PLEN * (N - 1) + S::PAD_LEN; i += 64) s_state[i] = 0.f;
     __syncthreads();
 
     const bool soc_x = ncx > 0, soc_u = ncu > 0;
+    auto cone_scale = [&](float a2, float axv, float mu, float &sc, float &ax_new) {
+        // The public solver's cone "projection" (restated in oracle/: a <= -mu t -> 0; a <= mu t -> s; else
+        // 1/2 (1 + mu t / a) (w, a / mu)), from the head norm^2 and the axis value summed over the instance's lanes:
+        // the factor for the head rows and the new axis value
+        const float an = __builtin_amdgcn_sqrtf(a2), u0 = axv * mu;
+        const bool zero = an <= -u0, keep = !zero && an <= u0;
+        const float half = 0.5f * (1.f + u0 * __builtin_amdgcn_rcpf(an));
+        sc = zero ? 0.f : (keep ? 1.f : half);
+        ax_new = zero ? 0.f : (keep ? axv : half * (an * __builtin_amdgcn_rcpf(mu)));
+    };
     const float rho = P.rho;
-    const float qd0 = ok0 ? Qd[row0] : 0.f, qd1 = ok1 ? Qd[row1] : 0.f, rd2 = ok2 ? Rd[row2] : 0.f;
-    (void)qd0, (void)qd1, (void)rd2;
-    // bounds of this lane's rows at knot k: s_bnd[k * 2 NROW + row] (lo), [+ NROW] (hi); rows that do not exist -> pads
-    const int PAD_LO = 2 * NROW * nk + NROW, PAD_HI = PAD_LO + 1, BST = P.bounds_stride ? 2 * NROW : 0;
+    // ---- bounds of this lane's rows: registers when they do not depend on the knot, else the LDS pack per knot ----
+    const int PAD_LO = 2 * NROW * nk + NROW, PAD_HI = PAD_LO + 1;
     if (l == 0) {
         s_bnd[PAD_LO] = -__builtin_inff();
         s_bnd[PAD_HI] = __builtin_inff();
     }
     __syncthreads();
-    const int bx0 = ok0 ? row0 : -1, bx1 = ok1 ? row1 : -1, bu2 = ok2 ? NX + row2 : -1;
-    auto lo_of = [&](int k, int br) -> float { return br < 0 ? s_bnd[PAD_LO] : s_bnd[k * BST + br]; };
-    auto hi_of = [&](int k, int br) -> float { return br < 0 ? s_bnd[PAD_HI] : s_bnd[k * BST + NROW + br]; };
-    // state accessors: element (array, slot) of position `pos` for this lane; slots the lane does not own (and cone duals
-    // of rows outside every cone) go to the lane's pad cell, which holds an exact zero for the whole solve
-    int s_off[3][3], s_str[3][3];
-    {
-        const int rhox[3] = {row0, row1, NX + row2};      // row index in the stacked [x; u] numbering
-        const bool okr[3] = {ok0, ok1, ok2};
+    const int bidx[3] = {ok0 ? row0 : -1, ok1 ? row1 : -1, ok2 ? NX + row2 : -1};
+    float lo_c[3], hi_c[3];
 #pragma unroll
-        for (int sl = 0; sl < 3; ++sl) {
-            int crow = 0;
-            for (int r2 = 0; r2 < rhox[sl] && r2 < NROW; ++r2) crow += in_cone(r2) ? 1 : 0;
-            const bool cone = okr[sl] && in_cone(rhox[sl]);
-            s_off[0][sl] = okr[sl] ? rhox[sl] * 16 + j : PLEN * (N - 1) + l;
-            s_off[2][sl] = okr[sl] ? (NROW + rhox[sl]) * 16 + j : PLEN * (N - 1) + l;
-            s_off[1][sl] = cone ? (2 * NROW + crow) * 16 + j : PLEN * (N - 1) + l;
-            s_str[0][sl] = s_str[2][sl] = okr[sl] ? PLEN : 0;
-            s_str[1][sl] = cone ? PLEN : 0;
-        }
+    for (int sl = 0; sl < 3; ++sl) {
+        lo_c[sl] = bidx[sl] < 0 ? -__builtin_inff() : s_bnd[bidx[sl]];
+        hi_c[sl] = bidx[sl] < 0 ? __builtin_inff() : s_bnd[NROW + bidx[sl]];
     }
-    auto S_ = [&](int pos, int arr, int sl) -> float & { return s_state[pos * s_str[arr][sl] + s_off[arr][sl]]; };
+    // (rows a lane does not own read the +-inf pads: one unconditional LDS read, no lane masks)
+    const int bl[3] = {bidx[0] < 0 ? PAD_LO : bidx[0], bidx[1] < 0 ? PAD_LO : bidx[1], bidx[2] < 0 ? PAD_LO : bidx[2]};
+    const int bh[3] = {bidx[0] < 0 ? PAD_HI : NROW + bidx[0], bidx[1] < 0 ? PAD_HI : NROW + bidx[1], bidx[2] < 0 ? PAD_HI : NROW + bidx[2]};
+    const int bs3[3] = {bidx[0] < 0 ? 0 : 2 * NROW, bidx[1] < 0 ? 0 : 2 * NROW, bidx[2] < 0 ? 0 : 2 * NROW};
+    auto lo_of = [&](int k, int sl) -> float {
+        if constexpr (BV) return s_bnd[k * bs3[sl] + bl[sl]];
+        else return lo_c[sl];
+    };
+    auto hi_of = [&](int k, int sl) -> float {
+        if constexpr (BV) return s_bnd[k * bs3[sl] + bh[sl]];
+        else return hi_c[sl];
+    };
+
+    // ---- LDS state addressing ----
+    // Position block: [A1: NROW rows][A3: NROW rows][A2: cone rows] x 16 instances.  With slot rows g, 4 + g, NX + g the
+    // element of (row, instance j) sits at row * 16 + j = (row base of the slot) * 16 + l: ONE per-lane address per slot
+    // serves A1 and A3 (compile-time displacement between them); lanes that do not own the slot's row point at the pad
+    // (stride 0), which holds exact zeros for the whole solve: a missing row's values are zeros that stay zeros.
+    constexpr int A3_DISP = NROW * 16;                         // floats from A1 to A3 of the same row
+    typedef float __attribute__((address_space(3))) lds_f;
+    lds_f *const sbase = (lds_f *)s_state;
+    const int rbase[3] = {0, 64, NX * 16};                     // slot row base * 16 (slot 1: rows 4 + g)
+    const bool okr[3] = {ok0, ok1, ok2};
+    lds_f *a_ptr[3], *c_ptr[3];                                // A1 of position 0 (A3 = + A3_DISP), and A2
+    int a_str[3], c_str[3];                                    // floats per position: PLEN, or 0 for the pad
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl) {
+        const int rho_ = sl == 0 ? row0 : (sl == 1 ? row1 : NX + row2);
+        int crow = 0;
+        for (int r2 = 0; r2 < rho_ && r2 < NROW; ++r2) crow += in_cone(r2) ? 1 : 0;
+        const bool cone = okr[sl] && in_cone(rho_);
+        a_ptr[sl] = sbase + (okr[sl] ? rbase[sl] + l : PLEN * (N - 1) + l);
+        a_str[sl] = okr[sl] ? PLEN : 0;
+        c_ptr[sl] = sbase + (cone ? (2 * NROW + crow) * 16 + j : PLEN * (N - 1) + l);
+        c_str[sl] = cone ? PLEN : 0;
+    }
+    // the affine term rides in the products: K index 11 (slot 2 of lane group 3, a row no shape uses: nu <= 3 there, else
+    // it is added on the VALU) carries the constant 1 and the operand columns f / APf, BPf
+    constexpr bool ONE_COL = NU <= 3;
+    const bool one_lane = ONE_COL && g == 3;
+    // reference pack [knot][row]: rows the lane does not own read the zero cell behind it
+    const int rf_off[3] = {ok0 ? row0 : NROW * N, ok1 ? row1 : NROW * N, ok2 ? NX + row2 : NROW * N};
+    const int rf_str[3] = {ok0 ? NROW : 0, ok1 ? NROW : 0, ok2 ? NROW : 0};
+    (void)rf_off, (void)rf_str;
     // HBM scratch of this wavefront: cone slack kept around a check
     float *const scr = P.scratch + (size_t)blockIdx.x * S::scratch_floats(N) + l;
     auto SCR = [&](int pos, int sl) -> float & { return scr[((size_t)pos * 3 + sl) * 64]; };
@@ -207,41 +265,69 @@ __global__ __launch_bounds__(64) void admm_mfmac_kernel(const AdmmParams P) {
     const bool can_converge = P.abs_pri_tol > 0.f && P.abs_dua_tol > 0.f;
     const int last_check_it = ct > 0 ? (P.max_iter / ct) * ct : 0;
 
-    // One projection pass over the cone set of a side.  v[]: this lane's slots of the side (x: 2, u: 1), in place.
-    auto project_x = [&](float (&v)[2]) {
-        for (int c = 0; c < ncx; ++c) {
+    // membership of this lane's slots in the first two cones of each side, as 0 / 1 weights, and their mu (registers);
+    // further cones (the C-ABI takes up to 8 per side) go through the LDS table
+    float hxw[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, axw[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, huw[2] = {0.f, 0.f}, auw[2] = {0.f, 0.f};
+    float mux[2] = {1.f, 1.f}, muu[2] = {1.f, 1.f};
+    if constexpr (EXT) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
             const uint4 mk = s_cmask[c * 4 + g];
-            float a2 = 0.f, axv = 0.f;
+            if (c < ncx) {
+                mux[c] = P.cx[c];
 #pragma unroll
-            for (int sl = 0; sl < 2; ++sl) {
-                if ((mk.x >> sl) & 1u) a2 = fmaf(v[sl], v[sl], a2);
-                if ((mk.y >> sl) & 1u) axv = v[sl];
+                for (int sl = 0; sl < 2; ++sl) hxw[c][sl] = (float)((mk.x >> sl) & 1u), axw[c][sl] = (float)((mk.y >> sl) & 1u);
             }
-            a2 = mfc_inst_sum(a2);
-            axv = mfc_inst_sum(axv);
-            const float mu = P.cx[c], an = sqrtf(a2), u0 = axv * mu;
-            const bool zero = an <= -u0, keep = !zero && an <= u0;
-            const float sc = zero ? 0.f : (keep ? 1.f : 0.5f * (1.f + u0 / an));
-            const float ax_new = zero ? 0.f : (keep ? axv : sc * (an / mu));
+            if (c < ncu) {
+                muu[c] = P.cu[c];
+                huw[c] = (float)(mk.z & 1u), auw[c] = (float)(mk.w & 1u);
+            }
+        }
+    }
+    auto cone_apply = [&](float v, float hw, float aw, float sc, float ax_new) -> float {
+        v = hw != 0.f ? v * sc : v;
+        return aw != 0.f ? ax_new : v;
+    };
+    auto project_x = [&](float (&v)[2]) {
 #pragma unroll
-            for (int sl = 0; sl < 2; ++sl) {
-                if ((mk.x >> sl) & 1u) v[sl] *= sc;
-                if ((mk.y >> sl) & 1u) v[sl] = ax_new;
+        for (int c = 0; c < 2; ++c) {
+            if (c < ncx) {
+                float a2 = mfc_inst_sum(fmaf(hxw[c][0] * v[0], v[0], hxw[c][1] * v[1] * v[1]));
+                float axv = mfc_inst_sum(fmaf(axw[c][0], v[0], axw[c][1] * v[1]));
+                float sc, ax_new;
+                cone_scale(a2, axv, mux[c], sc, ax_new);
+                v[0] = cone_apply(v[0], hxw[c][0], axw[c][0], sc, ax_new);
+                v[1] = cone_apply(v[1], hxw[c][1], axw[c][1], sc, ax_new);
             }
+        }
+        for (int c = 2; c < ncx; ++c) {
+            const uint4 mk = s_cmask[c * 4 + g];
+            const float h0 = (float)(mk.x & 1u), h1 = (float)((mk.x >> 1) & 1u), x0_ = (float)(mk.y & 1u), x1_ = (float)((mk.y >> 1) & 1u);
+            float a2 = mfc_inst_sum(fmaf(h0 * v[0], v[0], h1 * v[1] * v[1]));
+            float axv = mfc_inst_sum(fmaf(x0_, v[0], x1_ * v[1]));
+            float sc, ax_new;
+            cone_scale(a2, axv, P.cx[c], sc, ax_new);
+            v[0] = cone_apply(v[0], h0, x0_, sc, ax_new);
+            v[1] = cone_apply(v[1], h1, x1_, sc, ax_new);
         }
     };
     auto project_u = [&](float &v) {
-        for (int c = 0; c < ncu; ++c) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if (c < ncu) {
+                float a2 = mfc_inst_sum(huw[c] * v * v), axv = mfc_inst_sum(auw[c] * v);
+                float sc, ax_new;
+                cone_scale(a2, axv, muu[c], sc, ax_new);
+                v = cone_apply(v, huw[c], auw[c], sc, ax_new);
+            }
+        }
+        for (int c = 2; c < ncu; ++c) {
             const uint4 mk = s_cmask[c * 4 + g];
-            float a2 = (mk.z & 1u) ? v * v : 0.f, axv = (mk.w & 1u) ? v : 0.f;
-            a2 = mfc_inst_sum(a2);
-            axv = mfc_inst_sum(axv);
-            const float mu = P.cu[c], an = sqrtf(a2), u0 = axv * mu;
-            const bool zero = an <= -u0, keep = !zero && an <= u0;
-            const float sc = zero ? 0.f : (keep ? 1.f : 0.5f * (1.f + u0 / an));
-            const float ax_new = zero ? 0.f : (keep ? axv : sc * (an / mu));
-            if (mk.z & 1u) v *= sc;
-            if (mk.w & 1u) v = ax_new;
+            const float h = (float)(mk.z & 1u), a = (float)(mk.w & 1u);
+            float a2 = mfc_inst_sum(h * v * v), axv = mfc_inst_sum(a * v);
+            float sc, ax_new;
+            cone_scale(a2, axv, P.cu[c], sc, ax_new);
+            v = cone_apply(v, h, a, sc, ax_new);
         }
     };
 
@@ -258,124 +344,167 @@ __global__ __launch_bounds__(64) void admm_mfmac_kernel(const AdmmParams P) {
         float pri_x = 0.f, dua_x = 0.f, pri_u = 0.f, dua_u = 0.f;
 
         // state side of one knot: slack / dual of both sets for this lane's two state slots.  xv: the knot's state (fp64),
-        // kn: knot index, A1 / A2: duals in, out through the references; returns the fused (slack - dual) sum per slot.
-        auto state_knot = [&](const double (&xv)[2], int kn, int spos, float (&a1)[2], float (&a2)[2], float (&sx)[2]) {
+        // kn: knot index, a1 / a2: duals in and out; returns the fused (slack - dual) sum per slot.
+        auto state_knot = [&](auto full_tag, const double (&xv)[2], int kn, int spos, float (&a1)[2], float (&a2)[2], float (&sx)[2]) {
+            constexpr bool FULL = decltype(full_tag)::value;
             float xf[2], vn[2], vc[2];
-            const int brow[2] = {bx0, bx1};
-            const bool okr[2] = {ok0, ok1};
 #pragma unroll
-            for (int sl = 0; sl < XS; ++sl) {
-                xf[sl] = (float)xv[sl];
-                vn[sl] = fminf(hi_of(kn, brow[sl]), fmaxf(lo_of(kn, brow[sl]), xf[sl] + a1[sl]));   // admm.cpp:52-56
-                a1[sl] = (a1[sl] + xf[sl]) - vn[sl];                                                // admm.cpp:68
+            for (int sl = 0; sl < 2; ++sl) {
+                xf[sl] = sl < XS ? (float)xv[sl] : 0.f;
+                vn[sl] = __builtin_amdgcn_fmed3f(xf[sl] + a1[sl], lo_of(kn, sl), hi_of(kn, sl));   // admm.cpp:52-56
+                a1[sl] = (a1[sl] + xf[sl]) - vn[sl];                                               // admm.cpp:68
                 sx[sl] = vn[sl] - a1[sl];
             }
-            if constexpr (XS == 1) xf[1] = vn[1] = vc[1] = sx[1] = 0.f;
-            if (need_res) {
+            if constexpr (FULL) {
+                if (need_res) {
 #pragma unroll
-                for (int sl = 0; sl < XS; ++sl) {
-                    float old = 0.f;
-                    if (read_old && active && okr[sl]) old = P.xout[b * EX + (long)kn * NX + (sl ? row1 : row0)];
-                    pri_x = fmaxf(pri_x, fabsf(xf[sl] - vn[sl]));
-                    dua_x = fmaxf(dua_x, fabsf(old - vn[sl]));
+                    for (int sl = 0; sl < XS; ++sl) {
+                        float old = 0.f;
+                        if (read_old && active && okr[sl]) old = P.xout[b * EX + (long)kn * NX + (sl ? row1 : row0)];
+                        pri_x = fmaxf(pri_x, fabsf(xf[sl] - vn[sl]));
+                        dua_x = fmaxf(dua_x, fabsf(old - vn[sl]));
+                    }
                 }
-            }
-            if (write_sol && wr) {
+                if (write_sol && wr) {
 #pragma unroll
-                for (int sl = 0; sl < XS; ++sl)
-                    if (okr[sl]) P.xout[b * EX + (long)kn * NX + (sl ? row1 : row0)] = vn[sl];
+                    for (int sl = 0; sl < XS; ++sl)
+                        if (okr[sl]) P.xout[b * EX + (long)kn * NX + (sl ? row1 : row0)] = vn[sl];
+                }
             }
             if constexpr (EXT) {
                 if (soc_x) {
 #pragma unroll
-                    for (int sl = 0; sl < 2; ++sl) vc[sl] = sl < XS ? xf[sl] + a2[sl] : 0.f;
+                    for (int sl = 0; sl < 2; ++sl) vc[sl] = xf[sl] + a2[sl];
                     project_x(vc);
 #pragma unroll
-                    for (int sl = 0; sl < XS; ++sl) {
+                    for (int sl = 0; sl < 2; ++sl) {
                         a2[sl] = (a2[sl] + xf[sl]) - vc[sl];
                         sx[sl] += vc[sl] - a2[sl];
                     }
-                    if (need_res) {
+                    if constexpr (FULL) {
+                        if (need_res) {
 #pragma unroll
-                        for (int sl = 0; sl < XS; ++sl) {
-                            const float old = read_old ? SCR(spos, sl) : 0.f;
-                            pri_x = fmaxf(pri_x, fabsf(xf[sl] - vc[sl]));
-                            dua_x = fmaxf(dua_x, fabsf(old - vc[sl]));
+                            for (int sl = 0; sl < XS; ++sl) {
+                                const float old = read_old ? SCR(spos, sl) : 0.f;
+                                pri_x = fmaxf(pri_x, fabsf(xf[sl] - vc[sl]));
+                                dua_x = fmaxf(dua_x, fabsf(old - vc[sl]));
+                            }
                         }
-                    }
-                    if (write_old) {
+                        if (write_old) {
 #pragma unroll
-                        for (int sl = 0; sl < XS; ++sl) SCR(spos, sl) = vc[sl];
+                            for (int sl = 0; sl < XS; ++sl) SCR(spos, sl) = vc[sl];
+                        }
                     }
                 }
             }
         };
 
         // ================= fused forward sweep (admm.cpp:25-69, :93-96) =================
+        // FULL: an iteration that evaluates residuals, or writes its slack out (the solution, or the "previous slack" of
+        // the check that follows); every other iteration runs the copy of the sweep without any of that
+        lds_f *pa[3] = {a_ptr[0], a_ptr[1], a_ptr[2]};
+        auto forward_sweep = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
         {
             float sx0[2];
-            state_knot(x0r, 0, N - 1, g0, gc0, sx0);      // knot 0: its fused value feeds nothing (q_0 only enters p_0)
+            state_knot(full_tag, x0r, 0, N - 1, g0, gc0, sx0);      // knot 0: its fused value feeds nothing (q_0 only enters p_0)
         }
-        double x[2] = {x0r[0], x0r[1]};
-        // operands of position 0
-        float nA1x[2], nA2x[2], nA1u, nA2u, nd_f;
-        nA1x[0] = S_(0, 0, 0), nA1x[1] = S_(0, 0, 1), nA1u = S_(0, 0, 2);
-        nA2x[0] = S_(0, 1, 0), nA2x[1] = S_(0, 1, 1), nA2u = S_(0, 1, 2);
-        nd_f = S_(0, 2, 2);
+        lds_f *pc[3] = {c_ptr[0], c_ptr[1], c_ptr[2]};
+        // x+ = (A - B Kinf) x - B Quu_inv t + f,  u = -Kinf x - Quu_inv t  with t = B'p + r kept by the backward sweep
+        // (d = Quu_inv t of admm.cpp:17 is never formed on its own: Quu_inv rides in the forward operand, f in the
+        // column of the constant 1).  The chain starts from the constant-zero accumulator; the product with t does
+        // not wait for x.
+        auto chain_fwd = [&](double xa, double xb, float t) -> mf_d4 {
+            mf_d4 c = {0.0, 0.0, 0.0, 0.0};
+            c = mf_mma(cf[S::F_MF2], (double)(one_lane ? 1.f : t), c);
+            c = mf_mma(cf[S::F_MF0], xa, c);
+            if constexpr (XS == 2) c = mf_mma(cf[S::F_MF1], xb, c);
+            if constexpr (!ONE_COL) c[0] += cf[S::F_FD0], c[1] += cf[S::F_FD1];
+            return c;
+        };
+        // Software pipeline: the products of knot k + 1 need nothing of knot k but x_{k+1}, so they are issued BEFORE
+        // the slack / dual work of knot k and run on the matrix core underneath it (one wavefront per SIMD: nothing else
+        // would hide them).
+        float nA1[3], nA2[3];
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl) {
+            nA1[sl] = *pa[sl];
+            nA2[sl] = EXT ? *pc[sl] : 0.f;
+        }
+        mf_d4 c = chain_fwd(x0r[0], x0r[1], pa[2][A3_DISP]);
+        float t_next = N > 2 ? pa[2][A3_DISP + a_str[2]] : 0.f;                  // t of position 1
         for (int k = 0; k < N - 1; ++k) {
-            float a1x[2] = {nA1x[0], nA1x[1]}, a2x[2] = {nA2x[0], nA2x[1]};
-            float a1u = nA1u, a2u = nA2u;
-            const double nd = -(double)nd_f;
-            mf_d4 c = {cf[S::F_FD0], cf[S::F_FD1], nd, 0.0};
-            c = mf_mma(cf[S::F_MF2], nd, c);                                     // [B; 0] (-d): does not wait for x
-            c = mf_mma(cf[S::F_MF0], x[0], c);                                   // + [A - B Kinf; -Kinf] x
-            if constexpr (XS == 2) c = mf_mma(cf[S::F_MF1], x[1], c);
-            if (k + 1 < N - 1) {                                                 // next position's operands, while the products run
-                nA1x[0] = S_(k + 1, 0, 0), nA1x[1] = S_(k + 1, 0, 1), nA1u = S_(k + 1, 0, 2);
-                nA2x[0] = S_(k + 1, 1, 0), nA2x[1] = S_(k + 1, 1, 1), nA2u = S_(k + 1, 1, 2);
-                nd_f = S_(k + 1, 2, 2);
+            float a1x[2] = {nA1[0], nA1[1]}, a2x[2] = {nA2[0], nA2[1]};
+            float a1u = nA1[2], a2u = nA2[2];
+            lds_f *const wa[3] = {pa[0], pa[1], pa[2]}, *const wc[3] = {pc[0], pc[1], pc[2]};
+#pragma unroll
+            for (int sl = 0; sl < 3; ++sl) {
+                pa[sl] += a_str[sl];
+                pc[sl] += c_str[sl];
             }
-            x[0] = c[0], x[1] = c[1];
+            const double x[2] = {c[0], c[1]};
+            const float uf = (float)c[2];
+            mf_d4 cn = c;
+            if (k + 1 < N - 1) {
+                cn = chain_fwd(x[0], x[1], t_next);                              // knot k + 1, under the work below
+#pragma unroll
+                for (int sl = 0; sl < 3; ++sl) {                                 // and its operands
+                    nA1[sl] = *pa[sl];
+                    nA2[sl] = EXT ? *pc[sl] : 0.f;
+                }
+                if (k + 2 < N - 1) t_next = pa[2][A3_DISP + a_str[2]];
+            }
             // input row of knot k
             {
-                const float uf = (float)c[2];
-                float zn = fminf(hi_of(k, bu2), fmaxf(lo_of(k, bu2), uf + a1u));
+                const float zn = __builtin_amdgcn_fmed3f(uf + a1u, lo_of(k, 2), hi_of(k, 2));
                 a1u = (a1u + uf) - zn;
                 float su = zn - a1u;
-                if (need_res) {
-                    float old = 0.f;
-                    if (read_old && active && ok2) old = P.uout[b * EU + (long)k * NU + row2];
-                    pri_u = fmaxf(pri_u, fabsf(uf - zn));
-                    dua_u = fmaxf(dua_u, fabsf(old - zn));
+                if constexpr (FULL) {
+                    if (need_res) {
+                        float old = 0.f;
+                        if (read_old && active && ok2) old = P.uout[b * EU + (long)k * NU + row2];
+                        pri_u = fmaxf(pri_u, fabsf(uf - zn));
+                        dua_u = fmaxf(dua_u, fabsf(old - zn));
+                    }
+                    if (write_sol && wr && ok2) P.uout[b * EU + (long)k * NU + row2] = zn;
                 }
-                if (write_sol && wr && ok2) P.uout[b * EU + (long)k * NU + row2] = zn;
                 if constexpr (EXT) {
                     if (soc_u) {
                         float zc = uf + a2u;
                         project_u(zc);
                         a2u = (a2u + uf) - zc;
                         su += zc - a2u;
-                        if (need_res) {
-                            const float old = read_old ? SCR(k, 2) : 0.f;
-                            pri_u = fmaxf(pri_u, fabsf(uf - zc));
-                            dua_u = fmaxf(dua_u, fabsf(old - zc));
+                        if constexpr (FULL) {
+                            if (need_res) {
+                                const float old = read_old ? SCR(k, 2) : 0.f;
+                                pri_u = fmaxf(pri_u, fabsf(uf - zc));
+                                dua_u = fmaxf(dua_u, fabsf(old - zc));
+                            }
+                            if (write_old) SCR(k, 2) = zc;
                         }
-                        if (write_old) SCR(k, 2) = zc;
+                        *wc[2] = a2u;
                     }
                 }
-                S_(k, 0, 2) = a1u;
-                S_(k, 1, 2) = a2u;
-                S_(k, 2, 2) = su;
+                *wa[2] = a1u;
+                wa[2][A3_DISP] = su;
             }
             // state rows of knot k + 1
             {
                 float sx[2];
-                state_knot(x, k + 1, k, a1x, a2x, sx);
-                S_(k, 0, 0) = a1x[0], S_(k, 0, 1) = a1x[1];
-                S_(k, 1, 0) = a2x[0], S_(k, 1, 1) = a2x[1];
-                S_(k, 2, 0) = sx[0], S_(k, 2, 1) = sx[1];
+                state_knot(full_tag, x, k + 1, k, a1x, a2x, sx);
+#pragma unroll
+                for (int sl = 0; sl < XS; ++sl) {
+                    *wa[sl] = a1x[sl];
+                    wa[sl][A3_DISP] = sx[sl];
+                    if constexpr (EXT)
+                        if (soc_x) *wc[sl] = a2x[sl];
+                }
             }
+            c = cn;
         }
+        };
+        if (need_res || write_sol) forward_sweep(std::true_type{});
+        else forward_sweep(std::false_type{});
         it += 1;
         if (need_res) {
             const float r0 = mf_inst_max(pri_x), r1 = mf_inst_max(dua_x) * rho, r2 = mf_inst_max(pri_u),
@@ -393,6 +522,10 @@ __global__ __launch_bounds__(64) void admm_mfmac_kernel(const AdmmParams P) {
         }
         if (last || !__builtin_amdgcn_ballot_w64(active && !conv)) break;
         // ================= fused backward sweep (admm.cpp:75-83, :13-20) =================
+        // position addresses at N - 2 (the forward sweep left them one past it)
+        lds_f *qa[3];
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl) qa[sl] = pa[sl] - a_str[sl] + A3_DISP;
         double p[2], r_held;
         {
             const int pos = N - 2;
@@ -401,32 +534,36 @@ __global__ __launch_bounds__(64) void admm_mfmac_kernel(const AdmmParams P) {
                 pt0 = ok0 ? s_pterm[row0] : 0.0;
                 pt1 = ok1 ? s_pterm[row1] : 0.0;
             }
-            p[0] = pt0 - (double)(rho * S_(pos, 2, 0));                          // admm.cpp:81-82
-            p[1] = pt1 - (double)(rho * S_(pos, 2, 1));
+            p[0] = pt0 - (double)(rho * *qa[0]);                                 // admm.cpp:81-82
+            p[1] = pt1 - (double)(rho * *qa[1]);
             float rr = 0.f;
-            if constexpr (REFS == REF_SHARED) rr = ok2 ? s_ref[pos * NROW + NX + row2] : 0.f;
-            r_held = (double)(rr - rho * S_(pos, 2, 2));                         // admm.cpp:77-78
+            if constexpr (REFS == REF_SHARED) rr = s_ref[pos * rf_str[2] + rf_off[2]];
+            r_held = (double)(rr - rho * *qa[2]);                                // admm.cpp:77-78
         }
         for (int i2 = N - 3; i2 >= -1; --i2) {
-            const int kk = i2 + 1;                                               // the knot this stage produces p and d of
+            const int kk = i2 + 1;                                               // the knot this stage produces p and t of
+            lds_f *const ta = qa[2];                                             // where t_kk goes: position kk, input slot
             float q0 = 0.f, q1 = 0.f, rn = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
             if (i2 >= 0) {
-                s0 = S_(i2, 2, 0), s1 = S_(i2, 2, 1), s2 = S_(i2, 2, 2);
+#pragma unroll
+                for (int sl = 0; sl < 3; ++sl) qa[sl] -= a_str[sl];
+                s0 = *qa[0], s1 = *qa[1], s2 = *qa[2];
                 if constexpr (REFS == REF_SHARED) {
-                    q0 = ok0 ? s_ref[kk * NROW + row0] : 0.f;
-                    q1 = ok1 ? s_ref[kk * NROW + row1] : 0.f;
-                    rn = ok2 ? s_ref[i2 * NROW + NX + row2] : 0.f;
+                    q0 = s_ref[kk * rf_str[0] + rf_off[0]];
+                    q1 = s_ref[kk * rf_str[1] + rf_off[1]];
+                    rn = s_ref[i2 * rf_str[2] + rf_off[2]];
                 }
             }
-            mf_d4 c = {(double)(q0 - rho * s0) + cf[S::F_APF0], (double)(q1 - rho * s1) + cf[S::F_APF1],
-                       r_held + cf[S::F_BPF], 0.0};
-            c = mf_mma(cf[S::F_MB2], r_held, c);                                 // [-Kinf^T; 0] r: does not wait for p
+            // p- = q + AmBKt p - Kinf' r (+ AmBKt Pinf f),  t = B'p + r (+ B' Pinf f): the affine constants in the
+            // column of the constant 1 (or, nu = 4, added on the VALU)
+            const double rop = one_lane ? 1.0 : r_held;
+            mf_d4 c = {(double)(q0 - rho * s0), (double)(q1 - rho * s1), r_held, 0.0};
+            if constexpr (!ONE_COL) c[0] += cf[S::F_APF0], c[1] += cf[S::F_APF1], c[2] += cf[S::F_BPF];
+            c = mf_mma(cf[S::F_MB2], rop, c);                                    // [-Kinf^T; 0] r: does not wait for p
             c = mf_mma(cf[S::F_MB0], p[0], c);                                   // + [AmBKt; B^T] p
             if constexpr (XS == 2) c = mf_mma(cf[S::F_MB1], p[1], c);
             p[0] = c[0], p[1] = c[1];
-            mf_d4 dq = {0.0, 0.0, 0.0, 0.0};
-            dq = mf_mma(cf[S::F_MQ], c[2], dq);                                  // d = Quu_inv (B^T p + r), off the chain
-            S_(kk, 2, 2) = (float)dq[2];
+            *ta = (float)c[2];
             r_held = (double)(rn - rho * s2);
         }
     }

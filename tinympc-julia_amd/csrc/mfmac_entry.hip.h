@@ -68,23 +68,26 @@ void build_mfmac_coef(const Solver &sv, std::vector<unsigned char> &out) {
         const int m = l % 16, kq = l / 16;
         for (int s = 0; s < 3; ++s) {
             const int kc = 4 * s + kq;
-            double mf = 0.0, mb = 0.0, mq = 0.0;
+            double mf = 0.0, mb = 0.0;
             if (is_x(m) && is_x(kc)) {
                 mf = sv.A(m, kc);                       // (A - B Kinf)[m][kc], from A, B, Kinf themselves (set_cache_terms may
                 for (int a = 0; a < NU; ++a) mf -= sv.B(m, a) * c.Kinf(a, kc);   // hand in an AmBKt that differs)
                 mb = c.AmBKt(m, kc);
             } else if (is_x(m) && is_u(kc)) {
-                mf = sv.B(m, kc - 8);                   // + B (-d)
+                for (int a = 0; a < NU; ++a) mf -= sv.B(m, a) * c.Quu_inv(a, kc - 8);   // - B Quu_inv t
                 mb = -c.Kinf(kc - 8, m);                // - Kinf^T r
             } else if (is_u(m) && is_x(kc)) {
-                mf = -c.Kinf(m - 8, kc);                // u = -Kinf x (- d through the accumulator's start value)
+                mf = -c.Kinf(m - 8, kc);                // u = -Kinf x ...
                 mb = sv.B(kc, m - 8);                   // B^T p (+ r through the accumulator's start value)
             } else if (is_u(m) && is_u(kc)) {
-                mq = c.Quu_inv(m - 8, kc - 8);
+                mf = -c.Quu_inv(m - 8, kc - 8);         // ... - Quu_inv t
+            } else if (kc == 11 && NU <= 3 && sv.has_fdyn) {
+                // K index 11 carries the constant 1: the affine terms f | AmBKt Pinf f, B' Pinf f
+                if (is_x(m)) mf = sv.fdyn[m], mb = APf[m];
+                else if (is_u(m)) mb = BPf[m - 8];
             }
             o[(S::F_MF0 + s) * 64 + l] = mf;
             o[(S::F_MB0 + s) * 64 + l] = mb;
-            if (s == 2) o[S::F_MQ * 64 + l] = mq;
         }
         // per-lane constants of the lane's slots (state lane roles: group g = l / 16)
         const int g = l / 16;
@@ -137,17 +140,22 @@ size_t mfmac_scratch_floats(const Solver &sv) {
 template <int NX, int NU>
 hipError_t launch_mfmac(const AdmmParams &P, bool ext, size_t lds, hipStream_t stream) {
     const int grid = (P.batch + 15) / 16;
-#define TMPC_MFMAC_LAUNCH(REFS_, EXT_)                                                                              \
+#define TMPC_MFMAC_LAUNCH(REFS_, EXT_, BV_)                                                                         \
     do {                                                                                                            \
-        (void)hipFuncSetAttribute((const void *)admm_mfmac_kernel<NX, NU, REFS_, EXT_>,                             \
+        (void)hipFuncSetAttribute((const void *)admm_mfmac_kernel<NX, NU, REFS_, EXT_, BV_>,                        \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
-        hipLaunchKernelGGL((admm_mfmac_kernel<NX, NU, REFS_, EXT_>), dim3(grid), dim3(64), lds, stream, P);         \
+        hipLaunchKernelGGL((admm_mfmac_kernel<NX, NU, REFS_, EXT_, BV_>), dim3(grid), dim3(64), lds, stream, P);    \
+    } while (0)
+#define TMPC_MFMAC_LAUNCH_BV(REFS_, EXT_)                                                                          \
+    do {                                                                                                            \
+        if (P.bounds_stride) TMPC_MFMAC_LAUNCH(REFS_, EXT_, true); else TMPC_MFMAC_LAUNCH(REFS_, EXT_, false);      \
     } while (0)
     if (P.ref_mode == REF_ZERO) {
-        if (ext) TMPC_MFMAC_LAUNCH(REF_ZERO, true); else TMPC_MFMAC_LAUNCH(REF_ZERO, false);
+        if (ext) TMPC_MFMAC_LAUNCH_BV(REF_ZERO, true); else TMPC_MFMAC_LAUNCH_BV(REF_ZERO, false);
     } else {
-        if (ext) TMPC_MFMAC_LAUNCH(REF_SHARED, true); else TMPC_MFMAC_LAUNCH(REF_SHARED, false);
+        if (ext) TMPC_MFMAC_LAUNCH_BV(REF_SHARED, true); else TMPC_MFMAC_LAUNCH_BV(REF_SHARED, false);
     }
+#undef TMPC_MFMAC_LAUNCH_BV
 #undef TMPC_MFMAC_LAUNCH
     return hipGetLastError();
 }
