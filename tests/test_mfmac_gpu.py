@@ -129,11 +129,11 @@ def test_mfmac_equals_stream_kernel(hip_lib, monkeypatch, setting):
     assert nrel_batch(outs[0][1]["controls"], outs[1][1]["controls"])[same].max() <= 3e-6
 
 
-@pytest.mark.parametrize("case", ["cones_across_groups", "two_state_cones_knot_bounds", "zero_refs_box_only"])
+@pytest.mark.parametrize("case", ["cones_across_groups", "state_cone_knot_bounds", "zero_refs_box_only"])
 def test_mfmac_general_cones_and_bounds(hip_lib, oracle_built, monkeypatch, case):
     """cones whose rows sit in different lane groups and slots (rows 2..5 = slot 0 of groups 2, 3 and slot 1 of groups
-    0, 1), two cones on the state side, a 2-row input cone; bounds that depend on the knot; no references"""
-    rng = np.random.default_rng({"cones_across_groups": 3, "two_state_cones_knot_bounds": 4, "zero_refs_box_only": 5}[case])
+    0, 1), a cone on one side only, a 2-row input cone; bounds that depend on the knot; no references"""
+    rng = np.random.default_rng({"cones_across_groups": 3, "state_cone_knot_bounds": 4, "zero_refs_box_only": 5}[case])
     nx, nu, N, B = 6, 3, 17, 29
     A = np.eye(nx) + 0.15 * rng.standard_normal((nx, nx)) / np.sqrt(nx)
     A *= 0.97 / np.abs(np.linalg.eigvals(A)).max()
@@ -146,8 +146,8 @@ def test_mfmac_general_cones_and_bounds(hip_lib, oracle_built, monkeypatch, case
     cones = None
     if case == "cones_across_groups":
         cones = ([1], [2], [0.8], [2], [4], [0.9])          # input rows 1..2; state rows 2..5
-    elif case == "two_state_cones_knot_bounds":
-        cones = ([0], [3], [0.5], [0, 3], [3, 3], [0.6, 1.2])
+    elif case == "state_cone_knot_bounds":
+        cones = ([], [], [], [3], [3], [1.2])               # a cone on the state side only, rows 3..5
         prob.x_min[:, N // 2:] -= 0.3                        # per-knot bounds: the pack keeps every knot
         prob.u_max[:, ::2] += 0.1
     else:
@@ -187,6 +187,14 @@ def test_mfmac_is_not_used_where_it_does_not_apply(hip_lib):
     bs.set_x_ref(xr)
     bs.set_u_ref(ur)
     bs.set_linear_constraints(np.array([[0.0, 0.0, 0.0, 0.0, 0.0, -1.0]]), [2.5], np.zeros((0, 3)), [])
+    bs.solve()
+    assert bs.kernel_name == "stream4<6,3>"
+    bs.close()
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=8)   # two cones on a side
+    bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    bs.set_cone_constraints([0], [3], [0.25], [0, 3], [3, 3], [0.5, 1.5])
+    bs.set_warm_start(False)
+    bs.set_x0(t.problems.rocket_x0(8, seed=1))
     bs.solve()
     assert bs.kernel_name == "stream4<6,3>"
     bs.close()

@@ -50,6 +50,10 @@
 
 namespace tmpc {
 
+#ifndef TMPC_MFMAC_VALU_PER_GAP
+#define TMPC_MFMAC_VALU_PER_GAP 16  // VALU instructions the scheduler is asked to place behind each product of a chain
+#endif
+
 template <int NX, int NU>
 struct ConeShape {
     static_assert(NX >= 1 && NX <= 8 && NU >= 1 && NU <= 4, "mfmac kernel: nx <= 8, nu <= 4");
@@ -65,8 +69,8 @@ struct ConeShape {
     static constexpr int pos_len(int cone_rows) { return 16 * (2 * NROW + cone_rows); }
     static constexpr int PAD_LEN = 64 + 16 * NROW;  // a lane's pad cell and its A3 twin (A3_DISP further on)
     static constexpr size_t lds_bytes(int N, int nk, int cone_rows) {
-        return sizeof(float) * ((size_t)pos_len(cone_rows) * (N - 1) + PAD_LEN + bounds_len(nk) + (((size_t)NROW * N + 2) & ~(size_t)1)) +
-               sizeof(double) * 8;
+        return sizeof(float) * ((size_t)pos_len(cone_rows) * (N - 1) + PAD_LEN + bounds_len(nk) + (((size_t)NROW * N + 2) & ~(size_t)1) +
+                               256 + 200) + sizeof(double) * 8;   // ... + hand-over ring + residual / flag exchange
     }
     // HBM scratch per wavefront (floats): cone slack of the iteration before a check, [pos 0..N-1][slot][lane]
     static constexpr size_t scratch_floats(int N) { return (size_t)N * 3 * 64; }
@@ -85,20 +89,25 @@ __device__ __forceinline__ float mfc_inst_sum(float v) {
     // both are consumed by one add — it emits v_add v0, v0, v0 — experiments/permlane_probe.hip.  The s_nop covers the
     // VALU-write -> permlane-read hazard the compiler would otherwise pad for.)
     float a = v, b = v;
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     a += b;
     b = a;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     return a + b;
 }
 
-template <int NX, int NU, int REFS, bool EXT, bool BV>
-__global__ __launch_bounds__(64) void admm_mfmac_kernel(const AdmmParams P) {
+// CX / CU: one second-order cone on the state / input side (0: none).  More than one cone per side stays on the stream
+// kernel: with the cone count a compile-time constant the knot loops are straight-line code the scheduler can interleave
+// with the matrix products.
+template <int NX, int NU, int REFS, int CX, int CU, bool BV>
+__global__ __launch_bounds__(128) void admm_mfmac_kernel(const AdmmParams P) {
     using S = ConeShape<NX, NU>;
     constexpr int XS = S::XS, NROW = S::NROW;
+    constexpr bool EXT = CX + CU > 0;
+    static_assert(CX >= 0 && CX <= 1 && CU >= 0 && CU <= 1, "at most one cone per side");
     extern __shared__ __align__(16) unsigned char s_raw_c[];
     const int N = P.N;
-    const int ncx = EXT ? P.ncx : 0, ncu = EXT ? P.ncu : 0;
+    constexpr int ncx = CX, ncu = CU;
     // rows that lie in some cone get a cone dual of their own (A2); every other row's stays identically zero
     auto in_cone = [&](int rho) -> bool {
         if (rho < NX) {
@@ -119,9 +128,11 @@ __global__ __launch_bounds__(64) void admm_mfmac_kernel(const AdmmParams P) {
     float *s_bnd = s_pad + S::PAD_LEN;
     float *s_ref = s_bnd + S::bounds_len(nk);                 // [N][NROW] and one zero cell behind
     double *s_pterm = reinterpret_cast<double *>(s_ref + (((size_t)NROW * N + 2) & ~(size_t)1));
+    float *s_ring = reinterpret_cast<float *>(s_pterm + 8);   // [2 entries][2 state slots][64 lanes]: x_{k+1}, wave 0 -> wave 1
+    float *s_xchg = s_ring + 256;                             // pri_x[64] dua_x[64] (wave 1 -> 0), conv[64], any_left (wave 0 -> 1)
     __shared__ uint4 s_cmask[8 * 4];  // [cone][lane group]: x head bits, x axis bits, u head bit, u axis bit (bit = slot)
 
-    const int l = threadIdx.x, g = l >> 4, j = l & 15;
+    const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, g = l >> 4, j = l & 15;
     const long slot_id = (long)blockIdx.x * 16 + j;
     const bool active = slot_id < P.batch;
     const long b = active ? slot_id : 0;
@@ -131,10 +142,10 @@ __global__ __launch_bounds__(64) void admm_mfmac_kernel(const AdmmParams P) {
     const bool ok0 = row0 < NX, ok1 = row1 < NX, ok2 = row2 < NU;
 
     // ---- stage constants ----
-    for (int i = l; i < S::bounds_len(nk); i += 64) s_bnd[i] = P.bounds[i];
+    for (int i = tid; i < S::bounds_len(nk); i += 128) s_bnd[i] = P.bounds[i];
     if constexpr (REFS == REF_SHARED) {
         // -(Xref .* Q~), -(Uref .* R~) as update_linear_cost forms them (admm.cpp:77-80), per knot
-        for (int i = l; i < NROW * N + 1; i += 64) {
+        for (int i = tid; i < NROW * N + 1; i += 128) {
             const int k = i / NROW, r = i % NROW;
             float v = 0.f;
             if (i == NROW * N) {
@@ -153,15 +164,15 @@ __global__ __launch_bounds__(64) void admm_mfmac_kernel(const AdmmParams P) {
     if constexpr (REFS == REF_SHARED) {
         // terminal cost: -(Xref_{N-1}' Pinf)' (admm.cpp:81-82); Pinf follows the lane fields, row-major [NX][NX]
         const double *Pinf = gc64 + S::NF * 64;
-        if (l < NX) {
+        if (tid < NX) {
             double acc = 0.0;
             for (int c = 0; c < NX; ++c) acc = fma(Pinf[c * NX + l], (double)P.xref[(N - 1) * NX + c], acc);  // (Pinf^T xref)[l]
             s_pterm[l] = -acc;
         }
     }
     if constexpr (EXT) {
-        if (l < 32) {
-            const int c = l >> 2, gg = l & 3;
+        if (tid < 32) {
+            const int c = tid >> 2, gg = tid & 3;
             unsigned hx = 0u, ax = 0u, hu = 0u, au = 0u;
             if (c < ncx)
                 for (int sl = 0; sl < 2; ++sl) {
@@ -173,15 +184,15 @@ __global__ __launch_bounds__(64) void admm_mfmac_kernel(const AdmmParams P) {
                 if (gg < NU && gg >= P.Acu[c] && gg < P.Acu[c] + P.qcu[c] - 1) hu = 1u;
                 if (gg < NU && gg == P.Acu[c] + P.qcu[c] - 1) au = 1u;
             }
-            s_cmask[l] = make_uint4(hx, ax, hu, au);
+            s_cmask[tid] = make_uint4(hx, ax, hu, au);
         }
     }
     // cold start = the zero workspace tiny_setup leaves (tiny_api.cpp:73-88)
-    for (int i = l; i < PLEN * (N - 1) + S::PAD_LEN; i += 64) s_state[i] = 0.f;
+    for (int i = tid; i < PLEN * (N - 1) + S::PAD_LEN; i += 128) s_state[i] = 0.f;
     __syncthreads();
 
-    const bool soc_x = ncx > 0, soc_u = ncu > 0;
-    auto cone_scale = [&](float a2, float axv, float mu, float &sc, float &ax_new) {
+    constexpr bool soc_x = CX > 0, soc_u = CU > 0;
+    auto cone_scale = [&](float a2, float axv, float mu, float rmu, float &sc, float &ax_new) {
         // The public solver's cone "projection" (restated in oracle/: a <= -mu t -> 0; a <= mu t -> s; else
         // 1/2 (1 + mu t / a) (w, a / mu)), from the head norm^2 and the axis value summed over the instance's lanes:
         // the factor for the head rows and the new axis value
@@ -189,12 +200,12 @@ __global__ __launch_bounds__(64) void admm_mfmac_kernel(const AdmmParams P) {
         const bool zero = an <= -u0, keep = !zero && an <= u0;
         const float half = 0.5f * (1.f + u0 * __builtin_amdgcn_rcpf(an));
         sc = zero ? 0.f : (keep ? 1.f : half);
-        ax_new = zero ? 0.f : (keep ? axv : half * (an * __builtin_amdgcn_rcpf(mu)));
+        ax_new = zero ? 0.f : (keep ? axv : half * (an * rmu));
     };
     const float rho = P.rho;
     // ---- bounds of this lane's rows: registers when they do not depend on the knot, else the LDS pack per knot ----
     const int PAD_LO = 2 * NROW * nk + NROW, PAD_HI = PAD_LO + 1;
-    if (l == 0) {
+    if (tid == 0) {
         s_bnd[PAD_LO] = -__builtin_inff();
         s_bnd[PAD_HI] = __builtin_inff();
     }
@@ -265,23 +276,18 @@ __global__ __launch_bounds__(64) void admm_mfmac_kernel(const AdmmParams P) {
     const bool can_converge = P.abs_pri_tol > 0.f && P.abs_dua_tol > 0.f;
     const int last_check_it = ct > 0 ? (P.max_iter / ct) * ct : 0;
 
-    // membership of this lane's slots in the first two cones of each side, as 0 / 1 weights, and their mu (registers);
-    // further cones (the C-ABI takes up to 8 per side) go through the LDS table
-    float hxw[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, axw[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, huw[2] = {0.f, 0.f}, auw[2] = {0.f, 0.f};
-    float mux[2] = {1.f, 1.f}, muu[2] = {1.f, 1.f};
+    // membership of this lane's slots in the side's cone, as 0 / 1 weights, and mu, 1 / mu (registers)
+    float hxw[2] = {0.f, 0.f}, axw[2] = {0.f, 0.f}, huw = 0.f, auw = 0.f, mux = 1.f, muu = 1.f, rmux = 1.f, rmuu = 1.f;
     if constexpr (EXT) {
+        const uint4 mk = s_cmask[g];
+        if constexpr (CX > 0) {
+            mux = P.cx[0], rmux = 1.f / P.cx[0];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const uint4 mk = s_cmask[c * 4 + g];
-            if (c < ncx) {
-                mux[c] = P.cx[c];
-#pragma unroll
-                for (int sl = 0; sl < 2; ++sl) hxw[c][sl] = (float)((mk.x >> sl) & 1u), axw[c][sl] = (float)((mk.y >> sl) & 1u);
-            }
-            if (c < ncu) {
-                muu[c] = P.cu[c];
-                huw[c] = (float)(mk.z & 1u), auw[c] = (float)(mk.w & 1u);
-            }
+            for (int sl = 0; sl < 2; ++sl) hxw[sl] = (float)((mk.x >> sl) & 1u), axw[sl] = (float)((mk.y >> sl) & 1u);
+        }
+        if constexpr (CU > 0) {
+            muu = P.cu[0], rmuu = 1.f / P.cu[0];
+            huw = (float)(mk.z & 1u), auw = (float)(mk.w & 1u);
         }
     }
     auto cone_apply = [&](float v, float hw, float aw, float sc, float ax_new) -> float {
@@ -289,48 +295,31 @@ __global__ __launch_bounds__(64) void admm_mfmac_kernel(const AdmmParams P) {
         return aw != 0.f ? ax_new : v;
     };
     auto project_x = [&](float (&v)[2]) {
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            if (c < ncx) {
-                float a2 = mfc_inst_sum(fmaf(hxw[c][0] * v[0], v[0], hxw[c][1] * v[1] * v[1]));
-                float axv = mfc_inst_sum(fmaf(axw[c][0], v[0], axw[c][1] * v[1]));
-                float sc, ax_new;
-                cone_scale(a2, axv, mux[c], sc, ax_new);
-                v[0] = cone_apply(v[0], hxw[c][0], axw[c][0], sc, ax_new);
-                v[1] = cone_apply(v[1], hxw[c][1], axw[c][1], sc, ax_new);
-            }
-        }
-        for (int c = 2; c < ncx; ++c) {
-            const uint4 mk = s_cmask[c * 4 + g];
-            const float h0 = (float)(mk.x & 1u), h1 = (float)((mk.x >> 1) & 1u), x0_ = (float)(mk.y & 1u), x1_ = (float)((mk.y >> 1) & 1u);
-            float a2 = mfc_inst_sum(fmaf(h0 * v[0], v[0], h1 * v[1] * v[1]));
-            float axv = mfc_inst_sum(fmaf(x0_, v[0], x1_ * v[1]));
-            float sc, ax_new;
-            cone_scale(a2, axv, P.cx[c], sc, ax_new);
-            v[0] = cone_apply(v[0], h0, x0_, sc, ax_new);
-            v[1] = cone_apply(v[1], h1, x1_, sc, ax_new);
-        }
+        const float a2 = mfc_inst_sum(fmaf(hxw[0] * v[0], v[0], hxw[1] * v[1] * v[1]));
+        const float axv = mfc_inst_sum(fmaf(axw[0], v[0], axw[1] * v[1]));
+        float sc, ax_new;
+        cone_scale(a2, axv, mux, rmux, sc, ax_new);
+        v[0] = cone_apply(v[0], hxw[0], axw[0], sc, ax_new);
+        v[1] = cone_apply(v[1], hxw[1], axw[1], sc, ax_new);
     };
     auto project_u = [&](float &v) {
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            if (c < ncu) {
-                float a2 = mfc_inst_sum(huw[c] * v * v), axv = mfc_inst_sum(auw[c] * v);
-                float sc, ax_new;
-                cone_scale(a2, axv, muu[c], sc, ax_new);
-                v = cone_apply(v, huw[c], auw[c], sc, ax_new);
-            }
-        }
-        for (int c = 2; c < ncu; ++c) {
-            const uint4 mk = s_cmask[c * 4 + g];
-            const float h = (float)(mk.z & 1u), a = (float)(mk.w & 1u);
-            float a2 = mfc_inst_sum(h * v * v), axv = mfc_inst_sum(a * v);
-            float sc, ax_new;
-            cone_scale(a2, axv, P.cu[c], sc, ax_new);
-            v = cone_apply(v, h, a, sc, ax_new);
-        }
+        const float a2 = mfc_inst_sum(huw * v * v), axv = mfc_inst_sum(auw * v);
+        float sc, ax_new;
+        cone_scale(a2, axv, muu, rmuu, sc, ax_new);
+        v = cone_apply(v, huw, auw, sc, ax_new);
     };
 
+    // ---- two wavefronts per 16 instances ----
+    // A CU's LDS holds two tiles' state, so only two of its four SIMDs would carry a wavefront — and a lone wavefront
+    // issues a VALU instruction every 4 cycles whatever it does.  The slack / dual work of a knot is independent of the
+    // rollout that feeds it, so each tile gets a second wavefront on another SIMD:
+    //   wave 0 ("chain"): the matrix products of both sweeps and the input side (u rows) of the forward sweep;
+    //   wave 1 ("state"): the state side (x rows, their box and cone sets) of the forward sweep.
+    // Wave 0 hands x_{k+1} over through a two-entry ring in LDS, one workgroup barrier per knot (wave 1 runs one knot
+    // behind); the backward sweep is wave 0's alone.  Residual maxima and the per-instance convergence flags cross the
+    // same way on the iterations that check.
+    int any_left = 1;                                          // some instance of the tile still iterates (both waves agree)
+    const int dbg = P.mpc_steps;   // TIMING EXPERIMENTS ONLY (TINYMPC_HIP_MFMAC_DEBUG): 1 no backward sweep, 2 no state work, 4 no input work
     for (int i = 0; i < P.max_iter; ++i) {
         const int itn = i + 1;
         const bool check = ct > 0 && itn % ct == 0;
@@ -341,38 +330,39 @@ __global__ __launch_bounds__(64) void admm_mfmac_kernel(const AdmmParams P) {
         const bool write_sol = write_old || need_res || last;   // box slack -> xout / uout
         const bool read_old = need_res && itn > 1;               // the zero workspace before the first iteration
         const bool wr = active && !conv;                         // a converged instance's outputs are frozen
+        const bool full = need_res || write_sol;
         float pri_x = 0.f, dua_x = 0.f, pri_u = 0.f, dua_u = 0.f;
+        lds_f *pa[3] = {a_ptr[0], a_ptr[1], a_ptr[2]};
 
-        // state side of one knot: slack / dual of both sets for this lane's two state slots.  xv: the knot's state (fp64),
-        // kn: knot index, a1 / a2: duals in and out; returns the fused (slack - dual) sum per slot.
-        auto state_knot = [&](auto full_tag, const double (&xv)[2], int kn, int spos, float (&a1)[2], float (&a2)[2], float (&sx)[2]) {
-            constexpr bool FULL = decltype(full_tag)::value;
-            float xf[2], vn[2], vc[2];
+        if (wave == 1) {
+            // ================= state side of the forward sweep (admm.cpp:43-59, :65-69, :93-96) =================
+            // slack / dual of both sets for this lane's two state slots at knot kn (position spos of the cone scratch)
+            auto state_knot = [&](auto full_tag, const float (&xf)[2], int kn, int spos, float (&a1)[2], float (&a2)[2], float (&sx)[2]) {
+                constexpr bool FULL = decltype(full_tag)::value;
+                float vn[2], vc[2];
 #pragma unroll
-            for (int sl = 0; sl < 2; ++sl) {
-                xf[sl] = sl < XS ? (float)xv[sl] : 0.f;
-                vn[sl] = __builtin_amdgcn_fmed3f(xf[sl] + a1[sl], lo_of(kn, sl), hi_of(kn, sl));   // admm.cpp:52-56
-                a1[sl] = (a1[sl] + xf[sl]) - vn[sl];                                               // admm.cpp:68
-                sx[sl] = vn[sl] - a1[sl];
-            }
-            if constexpr (FULL) {
-                if (need_res) {
+                for (int sl = 0; sl < 2; ++sl) {
+                    vn[sl] = __builtin_amdgcn_fmed3f(xf[sl] + a1[sl], lo_of(kn, sl), hi_of(kn, sl));   // admm.cpp:52-56
+                    a1[sl] = (a1[sl] + xf[sl]) - vn[sl];                                               // admm.cpp:68
+                    sx[sl] = vn[sl] - a1[sl];
+                }
+                if constexpr (FULL) {
+                    if (need_res) {
 #pragma unroll
-                    for (int sl = 0; sl < XS; ++sl) {
-                        float old = 0.f;
-                        if (read_old && active && okr[sl]) old = P.xout[b * EX + (long)kn * NX + (sl ? row1 : row0)];
-                        pri_x = fmaxf(pri_x, fabsf(xf[sl] - vn[sl]));
-                        dua_x = fmaxf(dua_x, fabsf(old - vn[sl]));
+                        for (int sl = 0; sl < XS; ++sl) {
+                            float old = 0.f;
+                            if (read_old && active && okr[sl]) old = P.xout[b * EX + (long)kn * NX + (sl ? row1 : row0)];
+                            pri_x = fmaxf(pri_x, fabsf(xf[sl] - vn[sl]));
+                            dua_x = fmaxf(dua_x, fabsf(old - vn[sl]));
+                        }
+                    }
+                    if (write_sol && wr) {
+#pragma unroll
+                        for (int sl = 0; sl < XS; ++sl)
+                            if (okr[sl]) P.xout[b * EX + (long)kn * NX + (sl ? row1 : row0)] = vn[sl];
                     }
                 }
-                if (write_sol && wr) {
-#pragma unroll
-                    for (int sl = 0; sl < XS; ++sl)
-                        if (okr[sl]) P.xout[b * EX + (long)kn * NX + (sl ? row1 : row0)] = vn[sl];
-                }
-            }
-            if constexpr (EXT) {
-                if (soc_x) {
+                if constexpr (soc_x) {
 #pragma unroll
                     for (int sl = 0; sl < 2; ++sl) vc[sl] = xf[sl] + a2[sl];
                     project_x(vc);
@@ -396,20 +386,60 @@ __global__ __launch_bounds__(64) void admm_mfmac_kernel(const AdmmParams P) {
                         }
                     }
                 }
+            };
+            auto state_sweep = [&](auto full_tag) {
+                {
+                    const float xf0[2] = {(float)x0r[0], XS == 2 ? (float)x0r[1] : 0.f};
+                    float sx0[2];
+                    state_knot(full_tag, xf0, 0, N - 1, g0, gc0, sx0);   // knot 0: its fused value feeds nothing (q_0 only enters p_0)
+                }
+                lds_f *pc[2] = {c_ptr[0], c_ptr[1]};
+                float nA1[2] = {*pa[0], *pa[1]}, nA2[2] = {soc_x ? *pc[0] : 0.f, soc_x ? *pc[1] : 0.f};
+                for (int k = 0; k < N - 1; ++k) {
+                    float a1x[2] = {nA1[0], nA1[1]}, a2x[2] = {nA2[0], nA2[1]};
+                    lds_f *const wa[2] = {pa[0], pa[1]}, *const wc[2] = {pc[0], pc[1]};
+#pragma unroll
+                    for (int sl = 0; sl < 2; ++sl) {
+                        pa[sl] += a_str[sl];
+                        pc[sl] += c_str[sl];
+                    }
+                    if (k + 1 < N - 1) {                                         // next position's duals, before the wait
+#pragma unroll
+                        for (int sl = 0; sl < 2; ++sl) {
+                            nA1[sl] = *pa[sl];
+                            nA2[sl] = soc_x ? *pc[sl] : 0.f;
+                        }
+                    }
+                    __syncthreads();                                             // x_{k+1} is in ring entry k & 1
+                    const float xf[2] = {s_ring[(k & 1) * 128 + l], XS == 2 ? s_ring[(k & 1) * 128 + 64 + l] : 0.f};
+                    float sx[2] = {0.f, 0.f};
+                    if (!(dbg & 2)) state_knot(full_tag, xf, k + 1, k, a1x, a2x, sx);
+#pragma unroll
+                    for (int sl = 0; sl < XS; ++sl) {
+                        *wa[sl] = a1x[sl];
+                        wa[sl][A3_DISP] = sx[sl];
+                        if constexpr (soc_x) *wc[sl] = a2x[sl];
+                    }
+                }
+            };
+            if (full) state_sweep(std::true_type{});
+            else state_sweep(std::false_type{});
+            if (need_res) {                                                      // hand the state side's maxima to wave 0
+                s_xchg[l] = mf_inst_max(pri_x);
+                s_xchg[64 + l] = mf_inst_max(dua_x);
             }
-        };
-
-        // ================= fused forward sweep (admm.cpp:25-69, :93-96) =================
-        // FULL: an iteration that evaluates residuals, or writes its slack out (the solution, or the "previous slack" of
-        // the check that follows); every other iteration runs the copy of the sweep without any of that
-        lds_f *pa[3] = {a_ptr[0], a_ptr[1], a_ptr[2]};
-        auto forward_sweep = [&](auto full_tag) {
-        constexpr bool FULL = decltype(full_tag)::value;
-        {
-            float sx0[2];
-            state_knot(full_tag, x0r, 0, N - 1, g0, gc0, sx0);      // knot 0: its fused value feeds nothing (q_0 only enters p_0)
+            __syncthreads();                                                     // end of the forward sweep
+            if (need_res) {
+                __syncthreads();                                                 // wave 0 has decided
+                conv = (int)s_xchg[128 + l];
+                any_left = (int)s_xchg[192];
+            }
+            it += 1;
+            if (last || !any_left) break;
+            continue;                                                            // the backward sweep is wave 0's
         }
-        lds_f *pc[3] = {c_ptr[0], c_ptr[1], c_ptr[2]};
+
+        // ================= wave 0: rollout and input side of the forward sweep (admm.cpp:25-35, :43-69, :93-96) =================
         // x+ = (A - B Kinf) x - B Quu_inv t + f,  u = -Kinf x - Quu_inv t  with t = B'p + r kept by the backward sweep
         // (d = Quu_inv t of admm.cpp:17 is never formed on its own: Quu_inv rides in the forward operand, f in the
         // column of the constant 1).  The chain starts from the constant-zero accumulator; the product with t does
@@ -422,40 +452,35 @@ __global__ __launch_bounds__(64) void admm_mfmac_kernel(const AdmmParams P) {
             if constexpr (!ONE_COL) c[0] += cf[S::F_FD0], c[1] += cf[S::F_FD1];
             return c;
         };
-        // Software pipeline: the products of knot k + 1 need nothing of knot k but x_{k+1}, so they are issued BEFORE
-        // the slack / dual work of knot k and run on the matrix core underneath it (one wavefront per SIMD: nothing else
-        // would hide them).
-        float nA1[3], nA2[3];
-#pragma unroll
-        for (int sl = 0; sl < 3; ++sl) {
-            nA1[sl] = *pa[sl];
-            nA2[sl] = EXT ? *pc[sl] : 0.f;
-        }
-        mf_d4 c = chain_fwd(x0r[0], x0r[1], pa[2][A3_DISP]);
-        float t_next = N > 2 ? pa[2][A3_DISP + a_str[2]] : 0.f;                  // t of position 1
-        for (int k = 0; k < N - 1; ++k) {
-            float a1x[2] = {nA1[0], nA1[1]}, a2x[2] = {nA2[0], nA2[1]};
-            float a1u = nA1[2], a2u = nA2[2];
-            lds_f *const wa[3] = {pa[0], pa[1], pa[2]}, *const wc[3] = {pc[0], pc[1], pc[2]};
-#pragma unroll
-            for (int sl = 0; sl < 3; ++sl) {
-                pa[sl] += a_str[sl];
-                pc[sl] += c_str[sl];
-            }
-            const double x[2] = {c[0], c[1]};
-            const float uf = (float)c[2];
-            mf_d4 cn = c;
-            if (k + 1 < N - 1) {
-                cn = chain_fwd(x[0], x[1], t_next);                              // knot k + 1, under the work below
-#pragma unroll
-                for (int sl = 0; sl < 3; ++sl) {                                 // and its operands
-                    nA1[sl] = *pa[sl];
-                    nA2[sl] = EXT ? *pc[sl] : 0.f;
+        auto input_sweep = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            lds_f *pc2 = c_ptr[2];
+            float nA1u = *pa[2], nA2u = soc_u ? *pc2 : 0.f;
+            mf_d4 c = chain_fwd(x0r[0], x0r[1], pa[2][A3_DISP]);
+            float t_next = N > 2 ? pa[2][A3_DISP + a_str[2]] : 0.f;              // t of position 1
+            for (int k = 0; k < N - 1; ++k) {
+                float a1u = nA1u, a2u = nA2u;
+                lds_f *const wa2 = pa[2], *const wc2 = pc2;
+                pa[2] += a_str[2];
+                pc2 += c_str[2];
+                const double x[2] = {c[0], c[1]};
+                const float uf = (float)c[2];
+                s_ring[(k & 1) * 128 + l] = (float)x[0];                         // x_{k+1} for the state-side wavefront
+                if constexpr (XS == 2) s_ring[(k & 1) * 128 + 64 + l] = (float)x[1];
+                __syncthreads();
+                // the products of knot k + 1 need nothing of knot k but x_{k+1}: issued before the slack / dual work of
+                // knot k, they run on the matrix core underneath it
+                mf_d4 cn = c;
+                if (k + 1 < N - 1) {
+                    cn = chain_fwd(x[0], x[1], t_next);
+                    nA1u = *pa[2];
+                    nA2u = soc_u ? *pc2 : 0.f;
+                    if (k + 2 < N - 1) t_next = pa[2][A3_DISP + a_str[2]];
                 }
-                if (k + 2 < N - 1) t_next = pa[2][A3_DISP + a_str[2]];
-            }
-            // input row of knot k
-            {
+                if (dbg & 4) {
+                    c = cn;
+                    continue;
+                }
                 const float zn = __builtin_amdgcn_fmed3f(uf + a1u, lo_of(k, 2), hi_of(k, 2));
                 a1u = (a1u + uf) - zn;
                 float su = zn - a1u;
@@ -468,47 +493,32 @@ __global__ __launch_bounds__(64) void admm_mfmac_kernel(const AdmmParams P) {
                     }
                     if (write_sol && wr && ok2) P.uout[b * EU + (long)k * NU + row2] = zn;
                 }
-                if constexpr (EXT) {
-                    if (soc_u) {
-                        float zc = uf + a2u;
-                        project_u(zc);
-                        a2u = (a2u + uf) - zc;
-                        su += zc - a2u;
-                        if constexpr (FULL) {
-                            if (need_res) {
-                                const float old = read_old ? SCR(k, 2) : 0.f;
-                                pri_u = fmaxf(pri_u, fabsf(uf - zc));
-                                dua_u = fmaxf(dua_u, fabsf(old - zc));
-                            }
-                            if (write_old) SCR(k, 2) = zc;
+                if constexpr (soc_u) {
+                    float zc = uf + a2u;
+                    project_u(zc);
+                    a2u = (a2u + uf) - zc;
+                    su += zc - a2u;
+                    if constexpr (FULL) {
+                        if (need_res) {
+                            const float old = read_old ? SCR(k, 2) : 0.f;
+                            pri_u = fmaxf(pri_u, fabsf(uf - zc));
+                            dua_u = fmaxf(dua_u, fabsf(old - zc));
                         }
-                        *wc[2] = a2u;
+                        if (write_old) SCR(k, 2) = zc;
                     }
+                    *wc2 = a2u;
                 }
-                *wa[2] = a1u;
-                wa[2][A3_DISP] = su;
+                *wa2 = a1u;
+                wa2[A3_DISP] = su;
+                c = cn;
             }
-            // state rows of knot k + 1
-            {
-                float sx[2];
-                state_knot(full_tag, x, k + 1, k, a1x, a2x, sx);
-#pragma unroll
-                for (int sl = 0; sl < XS; ++sl) {
-                    *wa[sl] = a1x[sl];
-                    wa[sl][A3_DISP] = sx[sl];
-                    if constexpr (EXT)
-                        if (soc_x) *wc[sl] = a2x[sl];
-                }
-            }
-            c = cn;
-        }
         };
-        if (need_res || write_sol) forward_sweep(std::true_type{});
-        else forward_sweep(std::false_type{});
+        if (full) input_sweep(std::true_type{});
+        else input_sweep(std::false_type{});
+        __syncthreads();                                                         // end of the forward sweep: wave 1's s is in LDS
         it += 1;
         if (need_res) {
-            const float r0 = mf_inst_max(pri_x), r1 = mf_inst_max(dua_x) * rho, r2 = mf_inst_max(pri_u),
-                        r3 = mf_inst_max(dua_u) * rho;
+            const float r0 = s_xchg[l], r1 = s_xchg[64 + l] * rho, r2 = mf_inst_max(pri_u), r3 = mf_inst_max(dua_u) * rho;
             if (!conv) {
                 res0 = r0, res1 = r1, res2 = r2, res3 = r3;
                 if (res0 < P.abs_pri_tol && res2 < P.abs_pri_tol && res1 < P.abs_dua_tol && res3 < P.abs_dua_tol) {
@@ -519,13 +529,19 @@ __global__ __launch_bounds__(64) void admm_mfmac_kernel(const AdmmParams P) {
                     }
                 }
             }
+            any_left = __builtin_amdgcn_ballot_w64(active && !conv) != 0ull;
+            s_xchg[128 + l] = (float)conv;
+            if (l == 0) s_xchg[192] = (float)any_left;
+            __syncthreads();
         }
-        if (last || !__builtin_amdgcn_ballot_w64(active && !conv)) break;
-        // ================= fused backward sweep (admm.cpp:75-83, :13-20) =================
-        // position addresses at N - 2 (the forward sweep left them one past it)
+        if (last || !any_left) break;
+        if (dbg & 1) continue;
+        // ================= fused backward sweep (admm.cpp:75-83, :13-20), wave 0 =================
+        // position addresses at N - 2: the input slot's was advanced by the sweep above, the state slots' are computed
         lds_f *qa[3];
-#pragma unroll
-        for (int sl = 0; sl < 3; ++sl) qa[sl] = pa[sl] - a_str[sl] + A3_DISP;
+        qa[0] = a_ptr[0] + (N - 2) * a_str[0] + A3_DISP;
+        qa[1] = a_ptr[1] + (N - 2) * a_str[1] + A3_DISP;
+        qa[2] = pa[2] - a_str[2] + A3_DISP;
         double p[2], r_held;
         {
             const int pos = N - 2;
@@ -540,46 +556,57 @@ __global__ __launch_bounds__(64) void admm_mfmac_kernel(const AdmmParams P) {
             if constexpr (REFS == REF_SHARED) rr = s_ref[pos * rf_str[2] + rf_off[2]];
             r_held = (double)(rr - rho * *qa[2]);                                // admm.cpp:77-78
         }
-        for (int i2 = N - 3; i2 >= -1; --i2) {
-            const int kk = i2 + 1;                                               // the knot this stage produces p and t of
-            lds_f *const ta = qa[2];                                             // where t_kk goes: position kk, input slot
-            float q0 = 0.f, q1 = 0.f, rn = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
-            if (i2 >= 0) {
+        // operands of a stage (position i2: s of the state slots -> q_{i2+1}, su of the input slot -> r_{i2}) are read one
+        // stage ahead, under the previous stage's products
+        auto stage_operands = [&](int i2, float (&sv)[3], float (&rf)[3]) {
 #pragma unroll
-                for (int sl = 0; sl < 3; ++sl) qa[sl] -= a_str[sl];
-                s0 = *qa[0], s1 = *qa[1], s2 = *qa[2];
-                if constexpr (REFS == REF_SHARED) {
-                    q0 = s_ref[kk * rf_str[0] + rf_off[0]];
-                    q1 = s_ref[kk * rf_str[1] + rf_off[1]];
-                    rn = s_ref[i2 * rf_str[2] + rf_off[2]];
-                }
+            for (int sl = 0; sl < 3; ++sl) {
+                qa[sl] -= a_str[sl];
+                sv[sl] = *qa[sl];
             }
-            // p- = q + AmBKt p - Kinf' r (+ AmBKt Pinf f),  t = B'p + r (+ B' Pinf f): the affine constants in the
-            // column of the constant 1 (or, nu = 4, added on the VALU)
+            if constexpr (REFS == REF_SHARED) {
+                rf[0] = s_ref[(i2 + 1) * rf_str[0] + rf_off[0]];
+                rf[1] = s_ref[(i2 + 1) * rf_str[1] + rf_off[1]];
+                rf[2] = s_ref[i2 * rf_str[2] + rf_off[2]];
+            } else {
+                rf[0] = rf[1] = rf[2] = 0.f;
+            }
+        };
+        float sv[3] = {0.f, 0.f, 0.f}, rf[3] = {0.f, 0.f, 0.f};
+        lds_f *ta = qa[2];                                                       // where t of the stage's knot goes
+        if (N >= 3) stage_operands(N - 3, sv, rf);
+        for (int i2 = N - 3; i2 >= -1; --i2) {
+            // the stage produces p and t of knot kk = i2 + 1:  p- = q + AmBKt p - Kinf' r (+ AmBKt Pinf f),
+            // t = B'p + r (+ B' Pinf f); the affine constants ride in the column of the constant 1 (nu = 4: added here)
             const double rop = one_lane ? 1.0 : r_held;
-            mf_d4 c = {(double)(q0 - rho * s0), (double)(q1 - rho * s1), r_held, 0.0};
+            mf_d4 c = {(double)(rf[0] - rho * sv[0]), (double)(rf[1] - rho * sv[1]), r_held, 0.0};
+            if (i2 < 0) c[0] = c[1] = 0.0;                                       // q_0 enters p_0 only, which nothing reads
             if constexpr (!ONE_COL) c[0] += cf[S::F_APF0], c[1] += cf[S::F_APF1], c[2] += cf[S::F_BPF];
             c = mf_mma(cf[S::F_MB2], rop, c);                                    // [-Kinf^T; 0] r: does not wait for p
             c = mf_mma(cf[S::F_MB0], p[0], c);                                   // + [AmBKt; B^T] p
             if constexpr (XS == 2) c = mf_mma(cf[S::F_MB1], p[1], c);
+            lds_f *const tw = ta;
+            ta = qa[2];
+            r_held = (double)(rf[2] - rho * sv[2]);                              // r of knot i2, for the next stage
+            if (i2 >= 1) stage_operands(i2 - 1, sv, rf);
             p[0] = c[0], p[1] = c[1];
-            *ta = (float)c[2];
-            r_held = (double)(rn - rho * s2);
+            *tw = (float)c[2];
         }
     }
 
-    if (active && !conv && g == 0) {
+    if (wave == 0 && active && !conv && g == 0) {
         P.iter[b] = P.iter_offset + it;
         P.solved[b] = 0;
     }
-    if (active && g == 0) {
+    if (wave == 0 && active && g == 0) {
         P.res[b * 4 + 0] = res0;
         P.res[b * 4 + 1] = res1;
         P.res[b * 4 + 2] = res2;
         P.res[b * 4 + 3] = res3;
     }
     {
-        float m0 = active ? res0 : 0.f, m1 = active ? res1 : 0.f, m2 = active ? res2 : 0.f, m3 = active ? res3 : 0.f;
+        const bool rep = active && wave == 0;                // the state-side wavefront reports nothing
+        float m0 = rep ? res0 : 0.f, m1 = rep ? res1 : 0.f, m2 = rep ? res2 : 0.f, m3 = rep ? res3 : 0.f;
 #pragma unroll
         for (int off = 1; off < 16; off <<= 1) {
             m0 = fmaxf(m0, __shfl_xor(m0, off, 64));
@@ -587,8 +614,8 @@ __global__ __launch_bounds__(64) void admm_mfmac_kernel(const AdmmParams P) {
             m2 = fmaxf(m2, __shfl_xor(m2, off, 64));
             m3 = fmaxf(m3, __shfl_xor(m3, off, 64));
         }
-        const unsigned long long unsolved = __builtin_amdgcn_ballot_w64(active && !conv && g == 0);
-        fold_status(P, m0, m1, m2, m3, __popcll(unsolved), l);
+        const unsigned long long unsolved = __builtin_amdgcn_ballot_w64(rep && !conv && g == 0);
+        fold_status(P, m0, m1, m2, m3, __popcll(unsolved), tid);
     }
 }
 

@@ -1,6 +1,7 @@
 // Host-side pack builders + launcher for one (nx, nu) instantiation of the LDS-resident matrix-core kernel
 // (admm_mfmac.hip.h).
 #pragma once
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -138,23 +139,30 @@ size_t mfmac_scratch_floats(const Solver &sv) {
 }
 
 template <int NX, int NU>
-hipError_t launch_mfmac(const AdmmParams &P, bool ext, size_t lds, hipStream_t stream) {
+hipError_t launch_mfmac(const AdmmParams &P_, bool ext, size_t lds, hipStream_t stream) {
+    AdmmParams P = P_;
+    P.mpc_steps = std::getenv("TINYMPC_HIP_MFMAC_DEBUG") ? std::atoi(std::getenv("TINYMPC_HIP_MFMAC_DEBUG")) : 0;   // timing experiments
     const int grid = (P.batch + 15) / 16;
-#define TMPC_MFMAC_LAUNCH(REFS_, EXT_, BV_)                                                                         \
-    do {                                                                                                            \
-        (void)hipFuncSetAttribute((const void *)admm_mfmac_kernel<NX, NU, REFS_, EXT_, BV_>,                        \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
-        hipLaunchKernelGGL((admm_mfmac_kernel<NX, NU, REFS_, EXT_, BV_>), dim3(grid), dim3(64), lds, stream, P);    \
+#define TMPC_MFMAC_LAUNCH(REFS_, CX_, CU_, BV_)                                                                       \
+    do {                                                                                                              \
+        (void)hipFuncSetAttribute((const void *)admm_mfmac_kernel<NX, NU, REFS_, CX_, CU_, BV_>,                      \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
+        hipLaunchKernelGGL((admm_mfmac_kernel<NX, NU, REFS_, CX_, CU_, BV_>), dim3(grid), dim3(128), lds, stream, P);  \
     } while (0)
-#define TMPC_MFMAC_LAUNCH_BV(REFS_, EXT_)                                                                          \
-    do {                                                                                                            \
-        if (P.bounds_stride) TMPC_MFMAC_LAUNCH(REFS_, EXT_, true); else TMPC_MFMAC_LAUNCH(REFS_, EXT_, false);      \
+#define TMPC_MFMAC_LAUNCH_BV(REFS_, CX_, CU_)                                                                         \
+    do {                                                                                                              \
+        if (P.bounds_stride) TMPC_MFMAC_LAUNCH(REFS_, CX_, CU_, true); else TMPC_MFMAC_LAUNCH(REFS_, CX_, CU_, false); \
     } while (0)
-    if (P.ref_mode == REF_ZERO) {
-        if (ext) TMPC_MFMAC_LAUNCH_BV(REF_ZERO, true); else TMPC_MFMAC_LAUNCH_BV(REF_ZERO, false);
-    } else {
-        if (ext) TMPC_MFMAC_LAUNCH_BV(REF_SHARED, true); else TMPC_MFMAC_LAUNCH_BV(REF_SHARED, false);
-    }
+#define TMPC_MFMAC_LAUNCH_C(REFS_)                                                         \
+    do {                                                                                   \
+        if (P.ncx > 0 && P.ncu > 0) TMPC_MFMAC_LAUNCH_BV(REFS_, 1, 1);                     \
+        else if (P.ncx > 0) TMPC_MFMAC_LAUNCH_BV(REFS_, 1, 0);                             \
+        else if (P.ncu > 0) TMPC_MFMAC_LAUNCH_BV(REFS_, 0, 1);                             \
+        else TMPC_MFMAC_LAUNCH_BV(REFS_, 0, 0);                                            \
+    } while (0)
+    (void)ext;
+    if (P.ref_mode == REF_ZERO) TMPC_MFMAC_LAUNCH_C(REF_ZERO); else TMPC_MFMAC_LAUNCH_C(REF_SHARED);
+#undef TMPC_MFMAC_LAUNCH_C
 #undef TMPC_MFMAC_LAUNCH_BV
 #undef TMPC_MFMAC_LAUNCH
     return hipGetLastError();

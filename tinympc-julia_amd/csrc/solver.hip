@@ -352,6 +352,7 @@ int Solver::select_kernel(bool rollout) {
         !std::getenv("TINYMPC_HIP_NO_MFMA")) {
         c2 = find_cone_kernel(nx, nu);
         if (c2 && c2->lds_bytes(*this) > 160 * 1024 - 1024) c2 = nullptr;   // horizon too long for one wavefront's LDS
+        if ((st.en_state_soc && ncx > 1) || (st.en_input_soc && ncu > 1)) c2 = nullptr;   // one cone per side
         if (c2) {
             k = nullptr;
             s2 = nullptr;
