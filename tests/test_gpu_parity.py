@@ -1077,7 +1077,7 @@ def test_config4_full_size_properties(hip_lib, oracle_built):
     bs.set_u_ref(ur)
     bs.set_x0(x0)
     assert bs.solve() == 1
-    assert bs.kernel_name == "mfmac<6,3>"
+    assert bs.kernel_name == "mfmar<6,3,50>"
     sol = bs.get_solution()
     kw = dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=100, check_termination=1)
     ref = _oracle_loop(_rocket_oracle(oracle_built, prob, xr, ur, True, True, kw), base)

@@ -1,5 +1,7 @@
-"""The LDS-resident matrix-core kernel (csrc/admm_mfmac.hip.h, "mfmac<6,3>"): one-shot solves with box bounds, the affine
-dynamics term and second-order cones — BASELINE config 4's path — against the fp64 oracle, every instance by solution
+"""The matrix-core kernels for one-shot solves with box bounds, the affine dynamics term and second-order cones —
+BASELINE config 4's path: the LDS-resident one with a run-time horizon (csrc/admm_mfmac.hip.h, "mfmac<6,3>") and the
+register-resident one with the horizon compiled in (csrc/admm_mfmar.hip.h, "mfmar<6,3,50>", what config 4 itself runs
+on) — against the fp64 oracle, every instance by solution
 (tests/util.parity_every_instance), and against the run-time-horizon stream kernel it replaces for these solves.
 Cones / fdyn are the UNPINNED extensions (no reference source): the oracle itself is pinned for them by
 tests/test_independent_optimum.py and tests/test_extensions_cpu.py."""
@@ -70,12 +72,20 @@ SETTINGS = {
 }
 
 
-@pytest.mark.parametrize("N", [10, 50, 23, 2])
+def _kernel_for(N, lds_only=False):
+    return "mfmar<6,3,50>" if N == 50 and not lds_only else "mfmac<6,3>"
+
+
+@pytest.mark.parametrize("N", [10, 50, -50, 23, 2])
 @pytest.mark.parametrize("mode", ["fdyn+cones", "fdyn", "cones"])
 @pytest.mark.parametrize("setting", list(SETTINGS))
-def test_mfmac_rocket_vs_oracle(hip_lib, oracle_built, N, mode, setting):
-    if N in (23, 2) and (mode != "fdyn+cones" or setting not in ("fixed60", "tol")):
-        pytest.skip("the odd horizons run the two main settings only")
+def test_mfmac_rocket_vs_oracle(hip_lib, oracle_built, monkeypatch, N, mode, setting):
+    if N in (23, 2, -50) and (mode != "fdyn+cones" or setting not in ("fixed60", "tol")):
+        pytest.skip("the odd horizons (and the LDS kernel at N = 50) run the two main settings only")
+    lds_only = N < 0                                        # -50: N = 50 on the run-time-horizon kernel
+    N = abs(N)
+    if lds_only:
+        monkeypatch.setenv("TINYMPC_HIP_NO_MFMAR", "1")
     B = 37                                                  # ragged: two full wavefronts of 16 and one of 5
     kw = SETTINGS[setting]
     prob = t.problems.rocket(N)
@@ -88,7 +98,7 @@ def test_mfmac_rocket_vs_oracle(hip_lib, oracle_built, N, mode, setting):
     bs = _solver(prob, B, kw, xr, ur, fdyn, cones)
     bs.set_x0(x0)
     status = bs.solve()
-    assert bs.kernel_name == "mfmac<6,3>"
+    assert bs.kernel_name == _kernel_for(N, lds_only)
     sol, st = bs.get_solution(), bs.get_status()
     assert status == int(np.any(st["solved"] == 0))
     parity_every_instance(sol, st, ref, mk, x0, kw, prob.rho, tag=f"N={N} {mode} {setting}")
@@ -122,7 +132,7 @@ def test_mfmac_equals_stream_kernel(hip_lib, monkeypatch, setting):
         bs.solve()
         outs.append((bs.kernel_name, bs.get_solution(), bs.get_status()))
         bs.close()
-    assert outs[0][0] == "mfmac<6,3>" and outs[1][0] == "stream4<6,3>"
+    assert outs[0][0] == "mfmar<6,3,50>" and outs[1][0] == "stream4<6,3>"
     same = outs[0][2]["iter"] == outs[1][2]["iter"]
     assert same.mean() >= 0.95
     assert nrel_batch(outs[0][1]["states"], outs[1][1]["states"])[same].max() <= 3e-6
@@ -163,6 +173,36 @@ def test_mfmac_general_cones_and_bounds(hip_lib, oracle_built, monkeypatch, case
     assert bs.kernel_name == "mfmac<6,3>"
     sol, st = bs.get_solution(), bs.get_status()
     parity_every_instance(sol, st, ref, mk, x0, kw, prob.rho, tag=case)
+    bs.close()
+
+
+@pytest.mark.parametrize("case", ["knot_bounds", "zero_refs_input_cone", "state_cone_outside_slot0"])
+def test_mfmar_variants(hip_lib, oracle_built, case):
+    """the compiled-horizon kernel's other instantiations at N = 50: bounds that depend on the knot (LDS pack), no
+    references + a cone on the input side only; a state cone outside rows 0..3 is not its case (-> the LDS kernel)"""
+    N, B = 50, 21
+    prob = t.problems.rocket(N)
+    x0 = t.problems.rocket_x0(B, seed=8)
+    xr, ur = t.problems.rocket_refs(N)
+    kw = dict(abs_pri_tol=2e-3, abs_dua_tol=1e-3, max_iter=80, check_termination=1)
+    cones, fdyn, expect = ROCKET_CONES, prob.fdyn, "mfmar<6,3,50>"
+    if case == "knot_bounds":
+        prob.x_min = prob.x_min.copy()
+        prob.u_max = prob.u_max.copy()
+        prob.x_min[:, N // 2:] -= 0.5
+        prob.u_max[:, ::3] += 1.0
+    elif case == "zero_refs_input_cone":
+        xr, ur, cones = None, None, ([0], [3], [0.25], [], [], [])
+    else:
+        cones = ([0], [3], [0.25], [2], [3], [0.6])         # state rows 2..4: slot 0 and slot 1
+        expect = "mfmac<6,3>"
+    mk = _oracle(oracle_built, prob, kw, xr, ur, fdyn, cones)
+    ref = _loop(mk, x0)
+    bs = _solver(prob, B, kw, xr, ur, fdyn, cones)
+    bs.set_x0(x0)
+    bs.solve()
+    assert bs.kernel_name == expect
+    parity_every_instance(bs.get_solution(), bs.get_status(), ref, mk, x0, kw, prob.rho, tag=case)
     bs.close()
 
 

@@ -50,10 +50,6 @@
 
 namespace tmpc {
 
-#ifndef TMPC_MFMAC_VALU_PER_GAP
-#define TMPC_MFMAC_VALU_PER_GAP 16  // VALU instructions the scheduler is asked to place behind each product of a chain
-#endif
-
 template <int NX, int NU>
 struct ConeShape {
     static_assert(NX >= 1 && NX <= 8 && NU >= 1 && NU <= 4, "mfmac kernel: nx <= 8, nu <= 4");
@@ -80,11 +76,6 @@ struct ConeShape {
 // its first operand with the even rows of its second, v_permlane32_swap the upper 32 lanes with the lower 32, so with
 // both operands equal the two results add up to the pair sums in every lane (no LDS round trip as with ds_bpermute)
 __device__ __forceinline__ float mfc_inst_sum(float v) {
-#ifdef TMPC_MFMAC_SHFL
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
-#endif
     // (inline asm: through __builtin_amdgcn_permlane16_swap the compiler of this image loses the second result when
     // both are consumed by one add — it emits v_add v0, v0, v0 — experiments/permlane_probe.hip.  The s_nop covers the
     // VALU-write -> permlane-read hazard the compiler would otherwise pad for.)
@@ -100,7 +91,7 @@ __device__ __forceinline__ float mfc_inst_sum(float v) {
 // kernel: with the cone count a compile-time constant the knot loops are straight-line code the scheduler can interleave
 // with the matrix products.
 template <int NX, int NU, int REFS, int CX, int CU, bool BV>
-__global__ __launch_bounds__(128) void admm_mfmac_kernel(const AdmmParams P) {
+__global__ __launch_bounds__(192) void admm_mfmac_kernel(const AdmmParams P) {
     using S = ConeShape<NX, NU>;
     constexpr int XS = S::XS, NROW = S::NROW;
     constexpr bool EXT = CX + CU > 0;
@@ -128,8 +119,8 @@ __global__ __launch_bounds__(128) void admm_mfmac_kernel(const AdmmParams P) {
     float *s_bnd = s_pad + S::PAD_LEN;
     float *s_ref = s_bnd + S::bounds_len(nk);                 // [N][NROW] and one zero cell behind
     double *s_pterm = reinterpret_cast<double *>(s_ref + (((size_t)NROW * N + 2) & ~(size_t)1));
-    float *s_ring = reinterpret_cast<float *>(s_pterm + 8);   // [2 entries][2 state slots][64 lanes]: x_{k+1}, wave 0 -> wave 1
-    float *s_xchg = s_ring + 256;                             // pri_x[64] dua_x[64] (wave 1 -> 0), conv[64], any_left (wave 0 -> 1)
+    float *s_ring = reinterpret_cast<float *>(s_pterm + 8);   // pri_u[64] dua_u[64] (wave 2 -> 0)
+    float *s_xchg = s_ring + 256;                             // pri_x[64] dua_x[64] (wave 1 -> 0), conv[64], any_left (wave 0 -> 1, 2), [196] step counter
     __shared__ uint4 s_cmask[8 * 4];  // [cone][lane group]: x head bits, x axis bits, u head bit, u axis bit (bit = slot)
 
     const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, g = l >> 4, j = l & 15;
@@ -142,10 +133,10 @@ __global__ __launch_bounds__(128) void admm_mfmac_kernel(const AdmmParams P) {
     const bool ok0 = row0 < NX, ok1 = row1 < NX, ok2 = row2 < NU;
 
     // ---- stage constants ----
-    for (int i = tid; i < S::bounds_len(nk); i += 128) s_bnd[i] = P.bounds[i];
+    for (int i = tid; i < S::bounds_len(nk); i += 192) s_bnd[i] = P.bounds[i];
     if constexpr (REFS == REF_SHARED) {
         // -(Xref .* Q~), -(Uref .* R~) as update_linear_cost forms them (admm.cpp:77-80), per knot
-        for (int i = tid; i < NROW * N + 1; i += 128) {
+        for (int i = tid; i < NROW * N + 1; i += 192) {
             const int k = i / NROW, r = i % NROW;
             float v = 0.f;
             if (i == NROW * N) {
@@ -188,7 +179,7 @@ __global__ __launch_bounds__(128) void admm_mfmac_kernel(const AdmmParams P) {
         }
     }
     // cold start = the zero workspace tiny_setup leaves (tiny_api.cpp:73-88)
-    for (int i = tid; i < PLEN * (N - 1) + S::PAD_LEN; i += 128) s_state[i] = 0.f;
+    for (int i = tid; i < PLEN * (N - 1) + S::PAD_LEN; i += 192) s_state[i] = 0.f;
     __syncthreads();
 
     constexpr bool soc_x = CX > 0, soc_u = CU > 0;
@@ -208,6 +199,7 @@ __global__ __launch_bounds__(128) void admm_mfmac_kernel(const AdmmParams P) {
     if (tid == 0) {
         s_bnd[PAD_LO] = -__builtin_inff();
         s_bnd[PAD_HI] = __builtin_inff();
+        *reinterpret_cast<int *>(s_xchg + 196) = 0;            // the hand-over step counter
     }
     __syncthreads();
     const int bidx[3] = {ok0 ? row0 : -1, ok1 ? row1 : -1, ok2 ? NX + row2 : -1};
@@ -309,17 +301,35 @@ __global__ __launch_bounds__(128) void admm_mfmac_kernel(const AdmmParams P) {
         v = cone_apply(v, huw, auw, sc, ax_new);
     };
 
-    // ---- two wavefronts per 16 instances ----
-    // A CU's LDS holds two tiles' state, so only two of its four SIMDs would carry a wavefront — and a lone wavefront
-    // issues a VALU instruction every 4 cycles whatever it does.  The slack / dual work of a knot is independent of the
-    // rollout that feeds it, so each tile gets a second wavefront on another SIMD:
-    //   wave 0 ("chain"): the matrix products of both sweeps and the input side (u rows) of the forward sweep;
-    //   wave 1 ("state"): the state side (x rows, their box and cone sets) of the forward sweep.
-    // Wave 0 hands x_{k+1} over through a two-entry ring in LDS, one workgroup barrier per knot (wave 1 runs one knot
-    // behind); the backward sweep is wave 0's alone.  Residual maxima and the per-instance convergence flags cross the
-    // same way on the iterations that check.
-    int any_left = 1;                                          // some instance of the tile still iterates (both waves agree)
-    const int dbg = P.mpc_steps;   // TIMING EXPERIMENTS ONLY (TINYMPC_HIP_MFMAC_DEBUG): 1 no backward sweep, 2 no state work, 4 no input work
+    // ---- three wavefronts per 16 instances ----
+    // A CU's LDS holds two tiles' state at N = 50, so its four SIMDs would carry two wavefronts, each of them stalled
+    // on its own recurrence most of the time.  The slack / dual work of a knot is independent of the rollout that feeds
+    // it, so a tile gets three wavefronts (on different SIMDs):
+    //   wave 0 ("chain"): the matrix products of both sweeps and nothing else on the forward one — each step is
+    //                     products -> x_{k+1}, u_k -> LDS -> next products, ~3 x 64 matrix-core cycles;
+    //   wave 1 ("state"): the state rows' box and cone sets of the forward sweep, one or more knots behind wave 0;
+    //   wave 2 ("input"): the input rows' sets, likewise.
+    // Hand-over: wave 0 stores x_{k+1} / u_k (fp32) into the A3 cells of position k — the cells the consumer overwrites
+    // with its fused slack - dual value, whose previous content (s of the last iteration; t_k, already fed to the
+    // products) is dead — then bumps a monotone step counter in LDS.  LDS executes a wavefront's accesses in order, so
+    // a consumer that has seen the counter reach its step finds the values (volatile accesses keep the compiler's order);
+    // wave 0 never waits for the others inside a sweep.  One workgroup barrier ends the forward sweep (the backward
+    // sweep, wave 0's alone, reads what waves 1 and 2 wrote); residual maxima and the per-instance convergence flags
+    // cross through LDS on the iterations that check.
+    typedef volatile float __attribute__((address_space(3))) lds_vf;
+    typedef volatile int __attribute__((address_space(3))) lds_vi;
+    lds_vi *const s_step = (lds_vi *)reinterpret_cast<int *>(s_xchg + 196);
+    int any_left = 1;                                          // some instance of the tile still iterates (all waves agree)
+#ifdef TMPC_MFMAC_PROBE
+    // timing probe (scripts/mfmac_cycles.py; results are NOT a solution): bit 0 no backward sweep, 1 no state work,
+    // 2 no input work, 3 report s_memtime deltas per knot step in place of the residuals
+    const int dbg = P.mpc_steps;
+    long long T_fwd = 0, T_bar = 0, T_bwd = 0, T_w1 = 0;
+#define TMPC_PROBE(x) x
+#else
+    constexpr int dbg = 0;
+#define TMPC_PROBE(x)
+#endif
     for (int i = 0; i < P.max_iter; ++i) {
         const int itn = i + 1;
         const bool check = ct > 0 && itn % ct == 0;
@@ -331,8 +341,14 @@ __global__ __launch_bounds__(128) void admm_mfmac_kernel(const AdmmParams P) {
         const bool read_old = need_res && itn > 1;               // the zero workspace before the first iteration
         const bool wr = active && !conv;                         // a converged instance's outputs are frozen
         const bool full = need_res || write_sol;
+        const int step0 = i * (N - 1);                           // the step counter's value before this sweep
         float pri_x = 0.f, dua_x = 0.f, pri_u = 0.f, dua_u = 0.f;
         lds_f *pa[3] = {a_ptr[0], a_ptr[1], a_ptr[2]};
+        auto wait_step = [&](int k) {                            // until wave 0 has handed over step k of this sweep
+            TMPC_PROBE(const long long tb0 = (dbg & 8) ? clock64() : 0;)
+            while (*s_step < step0 + k + 1) __builtin_amdgcn_s_sleep(1);
+            TMPC_PROBE(if (dbg & 8) T_w1 += clock64() - tb0;)
+        };
 
         if (wave == 1) {
             // ================= state side of the forward sweep (admm.cpp:43-59, :65-69, :93-96) =================
@@ -410,8 +426,8 @@ __global__ __launch_bounds__(128) void admm_mfmac_kernel(const AdmmParams P) {
                             nA2[sl] = soc_x ? *pc[sl] : 0.f;
                         }
                     }
-                    __syncthreads();                                             // x_{k+1} is in ring entry k & 1
-                    const float xf[2] = {s_ring[(k & 1) * 128 + l], XS == 2 ? s_ring[(k & 1) * 128 + 64 + l] : 0.f};
+                    wait_step(k);                                                // x_{k+1} is in the A3 cells of position k
+                    const float xf[2] = {*(lds_vf *)(wa[0] + A3_DISP), XS == 2 ? *(lds_vf *)(wa[1] + A3_DISP) : 0.f};
                     float sx[2] = {0.f, 0.f};
                     if (!(dbg & 2)) state_knot(full_tag, xf, k + 1, k, a1x, a2x, sx);
 #pragma unroll
@@ -428,6 +444,63 @@ __global__ __launch_bounds__(128) void admm_mfmac_kernel(const AdmmParams P) {
                 s_xchg[l] = mf_inst_max(pri_x);
                 s_xchg[64 + l] = mf_inst_max(dua_x);
             }
+        } else if (wave == 2) {
+            // ================= input side of the forward sweep (admm.cpp:43-51, :60-64, :93-96) =================
+            auto input_sweep = [&](auto full_tag) {
+                constexpr bool FULL = decltype(full_tag)::value;
+                lds_f *pc2 = c_ptr[2];
+                float nA1u = *pa[2], nA2u = soc_u ? *pc2 : 0.f;
+                for (int k = 0; k < N - 1; ++k) {
+                    float a1u = nA1u, a2u = nA2u;
+                    lds_f *const wa2 = pa[2], *const wc2 = pc2;
+                    pa[2] += a_str[2];
+                    pc2 += c_str[2];
+                    if (k + 1 < N - 1) {
+                        nA1u = *pa[2];
+                        nA2u = soc_u ? *pc2 : 0.f;
+                    }
+                    wait_step(k);                                                // u_k is in the A3 cell of position k
+                    const float uf = *(lds_vf *)(wa2 + A3_DISP);
+                    if (dbg & 4) continue;
+                    const float zn = __builtin_amdgcn_fmed3f(uf + a1u, lo_of(k, 2), hi_of(k, 2));
+                    a1u = (a1u + uf) - zn;
+                    float su = zn - a1u;
+                    if constexpr (FULL) {
+                        if (need_res) {
+                            float old = 0.f;
+                            if (read_old && active && ok2) old = P.uout[b * EU + (long)k * NU + row2];
+                            pri_u = fmaxf(pri_u, fabsf(uf - zn));
+                            dua_u = fmaxf(dua_u, fabsf(old - zn));
+                        }
+                        if (write_sol && wr && ok2) P.uout[b * EU + (long)k * NU + row2] = zn;
+                    }
+                    if constexpr (soc_u) {
+                        float zc = uf + a2u;
+                        project_u(zc);
+                        a2u = (a2u + uf) - zc;
+                        su += zc - a2u;
+                        if constexpr (FULL) {
+                            if (need_res) {
+                                const float old = read_old ? SCR(k, 2) : 0.f;
+                                pri_u = fmaxf(pri_u, fabsf(uf - zc));
+                                dua_u = fmaxf(dua_u, fabsf(old - zc));
+                            }
+                            if (write_old) SCR(k, 2) = zc;
+                        }
+                        *wc2 = a2u;
+                    }
+                    *wa2 = a1u;
+                    wa2[A3_DISP] = su;
+                }
+            };
+            if (full) input_sweep(std::true_type{});
+            else input_sweep(std::false_type{});
+            if (need_res) {
+                s_ring[l] = mf_inst_max(pri_u);
+                s_ring[64 + l] = mf_inst_max(dua_u);
+            }
+        }
+        if (wave != 0) {
             __syncthreads();                                                     // end of the forward sweep
             if (need_res) {
                 __syncthreads();                                                 // wave 0 has decided
@@ -439,86 +512,45 @@ __global__ __launch_bounds__(128) void admm_mfmac_kernel(const AdmmParams P) {
             continue;                                                            // the backward sweep is wave 0's
         }
 
-        // ================= wave 0: rollout and input side of the forward sweep (admm.cpp:25-35, :43-69, :93-96) =================
+        // ================= wave 0: the rollout (admm.cpp:25-35) =================
         // x+ = (A - B Kinf) x - B Quu_inv t + f,  u = -Kinf x - Quu_inv t  with t = B'p + r kept by the backward sweep
         // (d = Quu_inv t of admm.cpp:17 is never formed on its own: Quu_inv rides in the forward operand, f in the
-        // column of the constant 1).  The chain starts from the constant-zero accumulator; the product with t does
-        // not wait for x.
-        auto chain_fwd = [&](double xa, double xb, float t) -> mf_d4 {
-            mf_d4 c = {0.0, 0.0, 0.0, 0.0};
-            c = mf_mma(cf[S::F_MF2], (double)(one_lane ? 1.f : t), c);
-            c = mf_mma(cf[S::F_MF0], xa, c);
-            if constexpr (XS == 2) c = mf_mma(cf[S::F_MF1], xb, c);
-            if constexpr (!ONE_COL) c[0] += cf[S::F_FD0], c[1] += cf[S::F_FD1];
-            return c;
-        };
-        auto input_sweep = [&](auto full_tag) {
-            constexpr bool FULL = decltype(full_tag)::value;
-            lds_f *pc2 = c_ptr[2];
-            float nA1u = *pa[2], nA2u = soc_u ? *pc2 : 0.f;
-            mf_d4 c = chain_fwd(x0r[0], x0r[1], pa[2][A3_DISP]);
-            float t_next = N > 2 ? pa[2][A3_DISP + a_str[2]] : 0.f;              // t of position 1
+        // column of the constant 1).  The product with t does not depend on x: the one of step k + 1 is issued behind the
+        // x products of step k and runs while their result is converted and stored.
+        TMPC_PROBE(const long long tf0 = (dbg & 8) ? clock64() : 0;)
+        {
+            auto t_product = [&](float t) -> mf_d4 {
+                mf_d4 c = {0.0, 0.0, 0.0, 0.0};
+                if constexpr (!ONE_COL) c[0] = cf[S::F_FD0], c[1] = cf[S::F_FD1];
+                return mf_mma(cf[S::F_MF2], (double)(one_lane ? 1.f : t), c);
+            };
+            lds_f *ph[3] = {a_ptr[0] + A3_DISP, a_ptr[1] + A3_DISP, a_ptr[2] + A3_DISP};   // hand-over cells of position k
+            mf_d4 cpre = t_product(*ph[2]);
+            float t_next = N > 2 ? ph[2][a_str[2]] : 0.f;                        // t of position 1
+            double xa = x0r[0], xb = x0r[1];
             for (int k = 0; k < N - 1; ++k) {
-                float a1u = nA1u, a2u = nA2u;
-                lds_f *const wa2 = pa[2], *const wc2 = pc2;
-                pa[2] += a_str[2];
-                pc2 += c_str[2];
-                const double x[2] = {c[0], c[1]};
-                const float uf = (float)c[2];
-                s_ring[(k & 1) * 128 + l] = (float)x[0];                         // x_{k+1} for the state-side wavefront
-                if constexpr (XS == 2) s_ring[(k & 1) * 128 + 64 + l] = (float)x[1];
-                __syncthreads();
-                // the products of knot k + 1 need nothing of knot k but x_{k+1}: issued before the slack / dual work of
-                // knot k, they run on the matrix core underneath it
-                mf_d4 cn = c;
+                mf_d4 c = mf_mma(cf[S::F_MF0], xa, cpre);
+                if constexpr (XS == 2) c = mf_mma(cf[S::F_MF1], xb, c);
                 if (k + 1 < N - 1) {
-                    cn = chain_fwd(x[0], x[1], t_next);
-                    nA1u = *pa[2];
-                    nA2u = soc_u ? *pc2 : 0.f;
-                    if (k + 2 < N - 1) t_next = pa[2][A3_DISP + a_str[2]];
+                    cpre = t_product(t_next);
+                    if (k + 2 < N - 1) t_next = ph[2][2 * a_str[2]];
                 }
-                if (dbg & 4) {
-                    c = cn;
-                    continue;
-                }
-                const float zn = __builtin_amdgcn_fmed3f(uf + a1u, lo_of(k, 2), hi_of(k, 2));
-                a1u = (a1u + uf) - zn;
-                float su = zn - a1u;
-                if constexpr (FULL) {
-                    if (need_res) {
-                        float old = 0.f;
-                        if (read_old && active && ok2) old = P.uout[b * EU + (long)k * NU + row2];
-                        pri_u = fmaxf(pri_u, fabsf(uf - zn));
-                        dua_u = fmaxf(dua_u, fabsf(old - zn));
-                    }
-                    if (write_sol && wr && ok2) P.uout[b * EU + (long)k * NU + row2] = zn;
-                }
-                if constexpr (soc_u) {
-                    float zc = uf + a2u;
-                    project_u(zc);
-                    a2u = (a2u + uf) - zc;
-                    su += zc - a2u;
-                    if constexpr (FULL) {
-                        if (need_res) {
-                            const float old = read_old ? SCR(k, 2) : 0.f;
-                            pri_u = fmaxf(pri_u, fabsf(uf - zc));
-                            dua_u = fmaxf(dua_u, fabsf(old - zc));
-                        }
-                        if (write_old) SCR(k, 2) = zc;
-                    }
-                    *wc2 = a2u;
-                }
-                *wa2 = a1u;
-                wa2[A3_DISP] = su;
-                c = cn;
+                xa = c[0], xb = c[1];
+                *(lds_vf *)ph[0] = (float)xa;                                    // x_{k+1} for the state-side wavefront
+                if constexpr (XS == 2) *(lds_vf *)ph[1] = (float)xb;
+                *(lds_vf *)ph[2] = (float)c[2];                                  // u_k for the input-side wavefront (t_k is spent)
+                *s_step = step0 + k + 1;
+#pragma unroll
+                for (int sl = 0; sl < 3; ++sl) ph[sl] += a_str[sl];
             }
-        };
-        if (full) input_sweep(std::true_type{});
-        else input_sweep(std::false_type{});
-        __syncthreads();                                                         // end of the forward sweep: wave 1's s is in LDS
+        }
+        TMPC_PROBE(if (dbg & 8) T_fwd += clock64() - tf0;)
+        TMPC_PROBE(const long long tb0 = (dbg & 8) ? clock64() : 0;)
+        __syncthreads();                                                         // end of the forward sweep: s of every knot is in LDS
+        TMPC_PROBE(if (dbg & 8) T_bar += clock64() - tb0;)
         it += 1;
         if (need_res) {
-            const float r0 = s_xchg[l], r1 = s_xchg[64 + l] * rho, r2 = mf_inst_max(pri_u), r3 = mf_inst_max(dua_u) * rho;
+            const float r0 = s_xchg[l], r1 = s_xchg[64 + l] * rho, r2 = s_ring[l], r3 = s_ring[64 + l] * rho;
             if (!conv) {
                 res0 = r0, res1 = r1, res2 = r2, res3 = r3;
                 if (res0 < P.abs_pri_tol && res2 < P.abs_pri_tol && res1 < P.abs_dua_tol && res3 < P.abs_dua_tol) {
@@ -537,11 +569,12 @@ __global__ __launch_bounds__(128) void admm_mfmac_kernel(const AdmmParams P) {
         if (last || !any_left) break;
         if (dbg & 1) continue;
         // ================= fused backward sweep (admm.cpp:75-83, :13-20), wave 0 =================
-        // position addresses at N - 2: the input slot's was advanced by the sweep above, the state slots' are computed
+        TMPC_PROBE(const long long tq0 = (dbg & 8) ? clock64() : 0;)
+        // position addresses at N - 2
         lds_f *qa[3];
         qa[0] = a_ptr[0] + (N - 2) * a_str[0] + A3_DISP;
         qa[1] = a_ptr[1] + (N - 2) * a_str[1] + A3_DISP;
-        qa[2] = pa[2] - a_str[2] + A3_DISP;
+        qa[2] = a_ptr[2] + (N - 2) * a_str[2] + A3_DISP;
         double p[2], r_held;
         {
             const int pos = N - 2;
@@ -556,8 +589,12 @@ __global__ __launch_bounds__(128) void admm_mfmac_kernel(const AdmmParams P) {
             if constexpr (REFS == REF_SHARED) rr = s_ref[pos * rf_str[2] + rf_off[2]];
             r_held = (double)(rr - rho * *qa[2]);                                // admm.cpp:77-78
         }
-        // operands of a stage (position i2: s of the state slots -> q_{i2+1}, su of the input slot -> r_{i2}) are read one
-        // stage ahead, under the previous stage's products
+        // A stage (position i2) produces p and t of knot i2 + 1:  p- = q + AmBKt p - Kinf' r (+ AmBKt Pinf f),
+        // t = B'p + r (+ B' Pinf f), from q_{i2+1} (s of the state slots at position i2), r_{i2+1} (su of the input slot
+        // one position up, held from the stage before) and the p of the stage before; the affine constants ride in the
+        // column of the constant 1 (nu = 4: added here).  Only the products with p are on the recurrence: a stage's
+        // accumulator start {q, r} and its product with r are formed and issued one stage ahead, behind the previous
+        // stage's p products, from operands read from LDS two stages ahead.
         auto stage_operands = [&](int i2, float (&sv)[3], float (&rf)[3]) {
 #pragma unroll
             for (int sl = 0; sl < 3; ++sl) {
@@ -572,27 +609,48 @@ __global__ __launch_bounds__(128) void admm_mfmac_kernel(const AdmmParams P) {
                 rf[0] = rf[1] = rf[2] = 0.f;
             }
         };
-        float sv[3] = {0.f, 0.f, 0.f}, rf[3] = {0.f, 0.f, 0.f};
-        lds_f *ta = qa[2];                                                       // where t of the stage's knot goes
-        if (N >= 3) stage_operands(N - 3, sv, rf);
-        for (int i2 = N - 3; i2 >= -1; --i2) {
-            // the stage produces p and t of knot kk = i2 + 1:  p- = q + AmBKt p - Kinf' r (+ AmBKt Pinf f),
-            // t = B'p + r (+ B' Pinf f); the affine constants ride in the column of the constant 1 (nu = 4: added here)
-            const double rop = one_lane ? 1.0 : r_held;
-            mf_d4 c = {(double)(rf[0] - rho * sv[0]), (double)(rf[1] - rho * sv[1]), r_held, 0.0};
+        auto stage_start = [&](int i2, const float (&sv)[3], const float (&rf)[3], double r_in) -> mf_d4 {
+            mf_d4 c = {(double)(rf[0] - rho * sv[0]), (double)(rf[1] - rho * sv[1]), r_in, 0.0};
             if (i2 < 0) c[0] = c[1] = 0.0;                                       // q_0 enters p_0 only, which nothing reads
             if constexpr (!ONE_COL) c[0] += cf[S::F_APF0], c[1] += cf[S::F_APF1], c[2] += cf[S::F_BPF];
-            c = mf_mma(cf[S::F_MB2], rop, c);                                    // [-Kinf^T; 0] r: does not wait for p
-            c = mf_mma(cf[S::F_MB0], p[0], c);                                   // + [AmBKt; B^T] p
+            return mf_mma(cf[S::F_MB2], one_lane ? 1.0 : r_in, c);               // [-Kinf^T; 0] r
+        };
+        float sv[3] = {0.f, 0.f, 0.f}, rf[3] = {0.f, 0.f, 0.f};
+        lds_f *tw = a_ptr[2] + (N - 2) * a_str[2] + A3_DISP;                     // where t of the stage's knot goes
+        if (N >= 3) stage_operands(N - 3, sv, rf);
+        mf_d4 cpre = stage_start(N - 3, sv, rf, r_held);                         // (N = 2: the only stage is i2 = -1)
+        r_held = (double)(rf[2] - rho * sv[2]);                                  // r of knot N - 3, for the stage after
+        if (N >= 4) stage_operands(N - 4, sv, rf);
+        for (int i2 = N - 3; i2 >= -1; --i2) {
+            mf_d4 c = mf_mma(cf[S::F_MB0], p[0], cpre);                          // + [AmBKt; B^T] p
             if constexpr (XS == 2) c = mf_mma(cf[S::F_MB1], p[1], c);
-            lds_f *const tw = ta;
-            ta = qa[2];
-            r_held = (double)(rf[2] - rho * sv[2]);                              // r of knot i2, for the next stage
-            if (i2 >= 1) stage_operands(i2 - 1, sv, rf);
+            if (i2 >= 0) {
+                cpre = stage_start(i2 - 1, sv, rf, r_held);
+                r_held = (double)(rf[2] - rho * sv[2]);
+                if (i2 >= 2) stage_operands(i2 - 2, sv, rf);
+            }
             p[0] = c[0], p[1] = c[1];
             *tw = (float)c[2];
+            tw -= a_str[2];
         }
+        TMPC_PROBE(if (dbg & 8) T_bwd += clock64() - tq0;)
     }
+#ifdef TMPC_MFMAC_PROBE
+    if (dbg & 16) {                                            // where the wavefronts run: HW_ID (simd_id bits 5:4, cu_id 11:8, se_id 15:13)
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        s_xchg[wave * 64 + l] = (float)((hw >> 4) & 3u);
+        if (wave == 0) s_ring[l] = (float)(((hw >> 8) & 15u) + 16u * ((hw >> 13) & 7u));
+        __syncthreads();
+        res0 = s_xchg[l], res1 = s_xchg[64 + l], res2 = s_xchg[128 + l], res3 = s_ring[l];
+    }
+    if (dbg & 8) {
+        if (wave == 1) s_xchg[l] = (float)T_w1;
+        __syncthreads();
+        const float steps = (float)it * (float)(N - 1);
+        res0 = (float)T_fwd / steps, res1 = (float)T_bar / steps, res2 = (float)T_bwd / steps, res3 = s_xchg[l] / steps;
+    }
+#endif
+#undef TMPC_PROBE
 
     if (wave == 0 && active && !conv && g == 0) {
         P.iter[b] = P.iter_offset + it;

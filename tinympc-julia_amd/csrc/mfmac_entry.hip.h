@@ -141,13 +141,15 @@ size_t mfmac_scratch_floats(const Solver &sv) {
 template <int NX, int NU>
 hipError_t launch_mfmac(const AdmmParams &P_, bool ext, size_t lds, hipStream_t stream) {
     AdmmParams P = P_;
-    P.mpc_steps = std::getenv("TINYMPC_HIP_MFMAC_DEBUG") ? std::atoi(std::getenv("TINYMPC_HIP_MFMAC_DEBUG")) : 0;   // timing experiments
+#ifdef TMPC_MFMAC_PROBE
+    P.mpc_steps = std::getenv("TINYMPC_HIP_MFMAC_DEBUG") ? std::atoi(std::getenv("TINYMPC_HIP_MFMAC_DEBUG")) : 0;   // timing probe build only
+#endif
     const int grid = (P.batch + 15) / 16;
 #define TMPC_MFMAC_LAUNCH(REFS_, CX_, CU_, BV_)                                                                       \
     do {                                                                                                              \
         (void)hipFuncSetAttribute((const void *)admm_mfmac_kernel<NX, NU, REFS_, CX_, CU_, BV_>,                      \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
-        hipLaunchKernelGGL((admm_mfmac_kernel<NX, NU, REFS_, CX_, CU_, BV_>), dim3(grid), dim3(128), lds, stream, P);  \
+        hipLaunchKernelGGL((admm_mfmac_kernel<NX, NU, REFS_, CX_, CU_, BV_>), dim3(grid), dim3(192), lds, stream, P);  \
     } while (0)
 #define TMPC_MFMAC_LAUNCH_BV(REFS_, CX_, CU_)                                                                         \
     do {                                                                                                              \
@@ -170,7 +172,7 @@ hipError_t launch_mfmac(const AdmmParams &P_, bool ext, size_t lds, hipStream_t 
 
 #define TMPC_DEFINE_MFMAC_ENTRY(NX, NU)                                                                              \
     const ConeEntry *mfmac_entry_##NX##_##NU() {                                                                    \
-        static const ConeEntry e = {NX, NU, "mfmac<" #NX "," #NU ">", &build_mfmac_coef<NX, NU>,                    \
+        static const ConeEntry e = {NX, NU, 0, nullptr, "mfmac<" #NX "," #NU ">", &build_mfmac_coef<NX, NU>,                    \
                                     &build_mfmac_bounds<NX, NU>, &mfmac_lds_bytes<NX, NU>, &mfmac_scratch_floats<NX, NU>, \
                                     &mfmac_bounds_vary, &launch_mfmac<NX, NU>};                                     \
         return &e;                                                                                                  \

@@ -44,6 +44,8 @@ const StreamEntry *find_stream_kernel(int nx, int nu);
 // one-shot solves with box bounds, the affine term and cones.
 struct ConeEntry {
     int nx, nu;
+    int N;                                      // compile-time horizon of the entry, 0: any (run-time horizon)
+    bool (*supports)(const Solver &);           // further conditions of the entry (null: none)
     const char *name;
     void (*build_coef)(const Solver &, std::vector<unsigned char> &);
     void (*build_bounds)(const Solver &, std::vector<float> &);
@@ -52,7 +54,7 @@ struct ConeEntry {
     bool (*bounds_vary)(const Solver &);
     hipError_t (*launch)(const AdmmParams &, bool ext, size_t lds, hipStream_t);
 };
-const ConeEntry *find_cone_kernel(int nx, int nu);
+const ConeEntry *find_cone_kernel(int nx, int nu, int N);   // N = 0: the run-time-horizon entry only
 hipError_t launch_generic(const AdmmParams &, int precision, hipStream_t);
 void build_generic_coef(const Solver &, std::vector<unsigned char> &);
 void build_generic_bounds(const Solver &, std::vector<float> &);

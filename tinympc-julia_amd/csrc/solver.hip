@@ -350,8 +350,10 @@ int Solver::select_kernel(bool rollout) {
         !st.adaptive_rho && (has_fdyn || cones_active() || plain_ok) && xref_kind < 2 && uref_kind < 2 &&
         !(refs_device_owned && ref_mode == REF_PER_INSTANCE) && !std::getenv("TINYMPC_HIP_NO_MFMAC") && !genv &&
         !std::getenv("TINYMPC_HIP_NO_MFMA")) {
-        c2 = find_cone_kernel(nx, nu);
-        if (c2 && c2->lds_bytes(*this) > 160 * 1024 - 1024) c2 = nullptr;   // horizon too long for one wavefront's LDS
+        c2 = std::getenv("TINYMPC_HIP_NO_MFMAR") ? nullptr : find_cone_kernel(nx, nu, N);   // horizon compiled in
+        if (c2 && c2->supports && !c2->supports(*this)) c2 = nullptr;
+        if (!c2) c2 = find_cone_kernel(nx, nu, 0);
+        if (c2 && c2->lds_bytes(*this) > 160 * 1024 - 1024) c2 = nullptr;   // horizon too long for one tile's LDS
         if ((st.en_state_soc && ncx > 1) || (st.en_input_soc && ncu > 1)) c2 = nullptr;   // one cone per side
         if (c2) {
             k = nullptr;
