@@ -209,6 +209,15 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
 
     lds_vi *const s_step = (lds_vi *)reinterpret_cast<int *>(s_xchg + 196);
     int any_left = 1;                                          // some instance of the tile still iterates (all waves agree)
+#ifdef TMPC_MFMAC_PROBE
+    // timing probe (scripts/mfmac_cycles.py; results are NOT a solution): TINYMPC_HIP_MFMAC_DEBUG & 8 reports s_memtime
+    // deltas per knot step in place of the residuals
+    const bool probe = (P.mpc_steps & 8) != 0;
+    long long T_fwd = 0, T_bar = 0, T_bwd = 0, T_w1 = 0;
+#define TMPC_PROBE(x) x
+#else
+#define TMPC_PROBE(x)
+#endif
     // what an iteration has to do besides iterating (identical in the three wavefronts)
     struct Flags {
         bool need_res, write_old, last, write_sol, read_old, full;
@@ -283,14 +292,24 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
                     (void)row_sets(cone_x, xf, lo_of(0, 0), hi_of(0, 0), a1[N - 1], a2[N - 1], vn, vc);
                     if (F.full) around_check(cone_x, F, pri, dua, xf, vn, vc, xo_i, own, scr_i + (N - 1) * 192);
                 }
+                bool have = false;                                               // the next cell's value was read ahead
+                float x_ahead = 0.f;
 #pragma unroll
                 for (int k = 0; k < N - 1; ++k) {
                     const int want = F.step0 + k + 1;                            // x_{k+1} is in the cell of position k
-                    while (seen < want) {
-                        seen = *s_step;
-                        if (seen < want) __builtin_amdgcn_s_sleep(1);
+                    float xf = x_ahead;
+                    if (!have) {
+                        TMPC_PROBE(const long long tb0 = probe ? clock64() : 0;)
+                        while (seen < want) {
+                            seen = __builtin_amdgcn_readfirstlane(*s_step);
+                            if (seen < want) __builtin_amdgcn_s_sleep(1);
+                        }
+                        TMPC_PROBE(if (probe) T_w1 += clock64() - tb0;)
+                        xf = *(lds_vf *)pa;
                     }
-                    const float xf = *(lds_vf *)pa;
+                    // wave 0 is usually steps ahead: the next cell is then read now, under this knot's arithmetic
+                    have = k + 1 < N - 1 && seen > want;
+                    if (have) x_ahead = *(lds_vf *)(pa + a_str[0]);
                     const float s = row_sets(cone_x, xf, lo_of(k + 1, 0), hi_of(k + 1, 0), a1[k], a2[k], vn, vc);
                     if (F.full) around_check(cone_x, F, pri, dua, xf, vn, vc, xo_i + (k + 1) * NX, own, scr_i + k * 192);
                     *pa = s;
@@ -298,14 +317,21 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
                 }
             } else {
                 float *const uo_i = P.uout + b * EU + row2 + opq;
+                bool have = false;
+                float u_ahead = 0.f;
 #pragma unroll
                 for (int k = 0; k < N - 1; ++k) {
                     const int want = F.step0 + k + 1;                            // u_k is in the cell of position k
-                    while (seen < want) {
-                        seen = *s_step;
-                        if (seen < want) __builtin_amdgcn_s_sleep(1);
+                    float uf = u_ahead;
+                    if (!have) {
+                        while (seen < want) {
+                            seen = __builtin_amdgcn_readfirstlane(*s_step);
+                            if (seen < want) __builtin_amdgcn_s_sleep(1);
+                        }
+                        uf = *(lds_vf *)pa;
                     }
-                    const float uf = *(lds_vf *)pa;
+                    have = k + 1 < N - 1 && seen > want;
+                    if (have) u_ahead = *(lds_vf *)(pa + a_str[2]);
                     const float s = row_sets(cone_u, uf, lo_of(k, 2), hi_of(k, 2), a1[k], a2[k], vn, vc);
                     if (F.full) around_check(cone_u, F, pri, dua, uf, vn, vc, uo_i + k * NU, own, scr_i + k * 192);
                     *pa = s;
@@ -344,6 +370,7 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
             opq_bv = opq;
             float pri = 0.f, dua = 0.f;
             {
+                TMPC_PROBE(const long long tf0 = probe ? clock64() : 0;)
                 float *const xo_i = P.xout + b * EX + row1 + opq;
                 auto t_product = [&](float t) -> mf_d4 {
                     mf_d4 c = {0.0, 0.0, 0.0, 0.0};
@@ -395,8 +422,11 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
                     for (int q = 0; q < 3; ++q) ph[q] += a_str[q];
                 }
                 if constexpr (XS == 2) slot1(N - 1, x1_prev, a1[N - 2], ph[1] - a_str[1]);
+                TMPC_PROBE(if (probe) T_fwd += clock64() - tf0;)
             }
+            TMPC_PROBE(const long long tb0 = probe ? clock64() : 0;)
             __syncthreads();                                                     // end of the forward sweep: s of every knot is in LDS
+            TMPC_PROBE(if (probe) T_bar += clock64() - tb0;)
             it += 1;
             if (F.need_res) {
                 const float r0 = fmaxf(s_xchg[l], mf_inst_max(pri)), r1 = fmaxf(s_xchg[64 + l], mf_inst_max(dua)) * rho;
@@ -418,6 +448,7 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
             }
             if (F.last || !any_left) break;
             // ---------------- fused backward sweep (admm.cpp:75-83, :13-20) ----------------
+            TMPC_PROBE(const long long tq0 = probe ? clock64() : 0;)
             lds_f *qa[3];
 #pragma unroll
             for (int q = 0; q < 3; ++q) qa[q] = a_ptr[q] + (N - 2) * a_str[q];
@@ -478,8 +509,18 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
                 *tw = (float)c[2];
                 tw -= a_str[2];
             }
+            TMPC_PROBE(if (probe) T_bwd += clock64() - tq0;)
         }
     }
+#ifdef TMPC_MFMAC_PROBE
+    if (probe) {
+        if (wave == 1) s_xchg[l] = (float)T_w1;
+        __syncthreads();
+        const float steps = (float)it * (float)(N - 1);
+        res0 = (float)T_fwd / steps, res1 = (float)T_bar / steps, res2 = (float)T_bwd / steps, res3 = s_xchg[l] / steps;
+    }
+#endif
+#undef TMPC_PROBE
 
     if (wave == 0 && active && !conv && g == 0) {
         P.iter[b] = P.iter_offset + it;

@@ -18,7 +18,12 @@ inline bool mfmar_supports(const Solver &sv) {
 }
 
 template <int NX, int NU, int N>
-hipError_t launch_mfmar(const AdmmParams &P, bool ext, size_t lds, hipStream_t stream) {
+hipError_t launch_mfmar(const AdmmParams &P_, bool ext, size_t lds, hipStream_t stream) {
+    AdmmParams P = P_;
+    P.mpc_steps = 0;
+#ifdef TMPC_MFMAC_PROBE
+    if (std::getenv("TINYMPC_HIP_MFMAC_DEBUG")) P.mpc_steps = std::atoi(std::getenv("TINYMPC_HIP_MFMAC_DEBUG")) & 8;   // timing probe build only
+#endif
     const int grid = (P.batch + 15) / 16;
 #define TMPC_MFMAR_LAUNCH(REFS_, CX_, CU_, BV_)                                                                          \
     do {                                                                                                                 \
