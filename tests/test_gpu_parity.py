@@ -1321,16 +1321,20 @@ ADAPTIVE = ["G9a_quadrotor_adaptive_fixed100", "G9b_quadrotor_adaptive_tol", "G9
             "G9d_cartpole_adaptive_noclip"]
 
 
+@pytest.mark.parametrize("kernel", ["stream", "generic"])
 @pytest.mark.parametrize("name", ADAPTIVE)
-def test_adaptive_rho_vs_reference_golden(hip_lib, name):
-    """adaptive rho (admm.cpp:147-174, rho_benchmark.cpp) per instance on the generic kernel against
-    outputs of the compiled reference: consecutive solves of one solver (workspace warm-starts, adapted cache
+def test_adaptive_rho_vs_reference_golden(hip_lib, monkeypatch, name, kernel):
+    """adaptive rho (admm.cpp:147-174, rho_benchmark.cpp) per instance — on the stream kernel's
+    adaptive variant (the norms gathered in the forward sweep, rho / Kinf / Pinf rows per instance; what an adaptive
+    solve runs on) and on the generic kernel (TINYMPC_HIP_NO_STREAM_ADP) — against outputs of the compiled reference: consecutive solves of one solver (workspace warm-starts, adapted cache
     persists), built-in 12x4 tables on the quadrotor, finite-difference sensitivities on the cartpole, clipping on and
     off.  Same iteration counts, rho path within 1e-5 relative, adapted Kinf / Pinf and the solution within the fp32
     tolerance."""
     g = load_golden(name)
     prob = problem_of(g)
     B = g["batch"]
+    if kernel == "generic":
+        monkeypatch.setenv("TINYMPC_HIP_NO_STREAM_ADP", "1")
     bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
     bs.update_settings(**g["settings"])
     if prob.has_bounds():
@@ -1341,7 +1345,7 @@ def test_adaptive_rho_vs_reference_golden(hip_lib, name):
     bs.set_x0(cm(g["x0"], prob.nx, B))
     for k in range(len(g["expect"][0])):
         status = bs.solve()
-        assert bs.kernel_name == "generic"
+        assert bs.kernel_name == ("generic" if kernel == "generic" else f"stream4<{prob.nx},{prob.nu}>")
         sol, st, ad = bs.get_solution(), bs.get_status(), bs.get_adaptive_state()
         assert status == max(e[k]["status"] for e in g["expect"])
         for b in range(B):

@@ -72,13 +72,15 @@ struct AdmmParams {
     int mlx, mlu;                        // rows per side (0: disabled), at most LIN_MAX_ROWS each
     const float *lin;                    // [mlx][nx] rows | b[mlx] | |a|^2[mlx] | [mlu][nu] rows | b[mlu] | |a|^2[mlu]
     float *sgl, *svl, *syl, *szl;        // warm-start state of the linear-inequality slack/dual pairs
-    // ---- generic kernel only: adaptive rho (admm.cpp:147-174, rho_benchmark.cpp) ----
+    // ---- stream / generic kernels: adaptive rho (admm.cpp:147-174, rho_benchmark.cpp) ----
     int adaptive_rho;                    // every 5th iteration each instance re-predicts its rho and Taylor-updates Kinf, Pinf
     int rho_clip;
     float rho_min, rho_max;
     const double *sens;                  // dKinf/drho [nu*nx] then dPinf/drho [nx*nx], column-major
     double *adapt;                       // [1 + nu*nx + nx*nx][batch]: rho, Kinf, Pinf of each instance; solver state, it
                                          // persists between solves like the reference's cache
+    long adapt_stride;                   // instances per row of `adapt` (the solver's batch)
+    void *adp_cols;                      // stream kernel, adaptive rho: [ADP_LEN][G * batch] scratch columns (kernel-local)
     // ---- stream kernel only: one problem family PER INSTANCE ----
     const float *het_aux;                // [nx + nu + 1][batch]: diag(Q)+rho, diag(R)+rho, rho of each instance
     // ---- mfmac kernel only: 0 = the bounds pack holds one knot's bounds (they do not depend on the knot) ----

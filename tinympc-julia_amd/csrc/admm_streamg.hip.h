@@ -33,7 +33,10 @@ struct StreamPackG {
     using S = QuadShape<NX, NU, 2, G>;
     static constexpr int RX = S::RX, RU = S::RU;
     static constexpr int O_F = S::CP, O_APF = O_F + RX, O_BPF = O_APF + RX;
-    static constexpr int CP = S::pad8(O_BPF + RU);
+    static constexpr int O_ATT = S::pad8(O_BPF + RU);   // A^T rows [RX][NXP] (adaptive rho: the dual residual's A' g)
+    static constexpr int CP = O_ATT + S::pad8(RX * S::NXP);
+    // adaptive rho (ADP): the rows that differ per instance, as this lane's column of a [ADP_LEN][G*batch] matrix
+    static constexpr int AO_K = 0, AO_KT = AO_K + RU * S::NXP, AO_PT = AO_KT + RX * S::NUP, ADP_LEN = AO_PT + RX * S::NXP;
     static constexpr int BW = 2 * RX + 2 * RU;  // bounds per knot and role: xmin xmax umin umax
     static constexpr int DW = RX + RU;          // diag(Q)+rho, diag(R)+rho per role
 };
@@ -132,6 +135,25 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
+// max over the G lanes of a group, any arithmetic type (the adaptive-rho norms are kept in the kernel's RT)
+template <int G, class T>
+__device__ __forceinline__ T group_max_t(T v) {
+    if constexpr (G >= 2) {
+        const T o = __shfl_xor(v, 1, 64);
+        v = o > v ? o : v;
+    }
+    if constexpr (G == 4) {
+        const T o = __shfl_xor(v, 2, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+template <class T>
+__device__ __forceinline__ void upmax_abs(T &m, T v) {
+    v = v < (T)0 ? -v : v;
+    m = v > m ? v : m;
+}
+
 // cone c restricted to this lane's R local rows: bit m of head / axis set when local row m belongs to it
 template <int G, int R>
 __device__ __forceinline__ void project_soc_group(float (&blk)[R], unsigned head, unsigned axis, float mu) {
@@ -187,8 +209,13 @@ struct StreamTune {
 #define TMPC_STREAM_WAVES(G) StreamTune<G>::WAVES
 #endif
 
-template <int NX, int NU, int G, class RT, int EXT, bool HET, bool OS>
+// ADP: adaptive rho (admm.cpp:147-174 with rho_benchmark.cpp:44-213).  One family for the batch (its rows in LDS), but
+// rho, Kinf and Pinf are every instance's own: the rows built from them (Kinf, Kinf^T, Pinf^T) are read from the lane's
+// column of a scratch matrix that the kernel fills from the solver's adaptive state at entry and re-writes, together
+// with that state, whenever it adapts — every 5th iteration, from norms gathered during that iteration's forward sweep.
+template <int NX, int NU, int G, class RT, int EXT, bool HET, bool OS, bool ADP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM_WAVES(G)))) void admm_streamg_kernel(const AdmmParams P) {
+    static_assert(!ADP || (!HET && EXT == 0), "adaptive rho: one family, box sets only");
     using PK = StreamPackG<NX, NU, G>;
     using S = typename PK::S;
     constexpr int T = 256, D = TMPC_STREAM_DEPTH(G), RX = S::RX, RU = S::RU, NXP = S::NXP, NUP = S::NUP, NXL = S::NXL,
@@ -243,9 +270,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
         cbase = CoefCol<RT>{gcoef, BG, (unsigned)(L * sizeof(RT))};
     else
         cbase = CoefRole<RT, G>{s_coef + q * CoefRole<RT, G>::VEC, 0};
-    const CPtr cA = cbase + S::O_A, cK = cbase + S::O_K, cB = cbase + S::O_B, cAT = cbase + S::O_AT,
-               cBT = cbase + S::O_BT, cKT = cbase + S::O_KT, cQI = cbase + S::O_QI, cPT = cbase + S::O_PT,
-               cF = cbase + PK::O_F, cAPF = cbase + PK::O_APF, cBPF = cbase + PK::O_BPF;
+    const CPtr cA = cbase + S::O_A, cB = cbase + S::O_B, cAT = cbase + S::O_AT, cBT = cbase + S::O_BT, cQI = cbase + S::O_QI,
+               cF = cbase + PK::O_F, cAPF = cbase + PK::O_APF, cBPF = cbase + PK::O_BPF, cATT = cbase + PK::O_ATT;
+    (void)cATT;
+    using KPtr = std::conditional_t<ADP, CoefCol<RT>, CPtr>;   // the rows made of Kinf / Pinf
+    KPtr cK, cKT, cPT;
+    RT *const adp_cols = ADP ? reinterpret_cast<RT *>(P.adp_cols) : nullptr;
+    double rho_d = (double)P.rho;                           // ADP: this instance's rho as the adaptive state holds it
+    if constexpr (ADP) {
+        const CoefCol<RT> col{adp_cols, BG, (unsigned)(L * sizeof(RT))};
+        cK = col + PK::AO_K, cKT = col + PK::AO_KT, cPT = col + PK::AO_PT;
+        // fill the column from the solver's adaptive state [1 + nu nx + nx nx][batch] (rho | Kinf | Pinf, column-major)
+        const long AB = P.adapt_stride;
+        const double *ad = P.adapt + b;
+        if (active) {
+            rho_d = ad[0];
+            rho = (float)rho_d;
+            RT *mine = adp_cols + L;
+#pragma unroll
+            for (int m = 0; m < RU; ++m)
+                for (int j = 0; j < NXP; ++j) {
+                    const int a = q * RU + m;
+                    mine[(long)(PK::AO_K + m * NXP + j) * BG] = (a < NU && j < NX) ? (RT)ad[(long)(1 + a + j * NU) * AB] : (RT)0;
+                }
+#pragma unroll
+            for (int m = 0; m < RX; ++m) {
+                const int r = q * RX + m;
+                for (int a = 0; a < NUP; ++a)
+                    mine[(long)(PK::AO_KT + m * NUP + a) * BG] = (r < NX && a < NU) ? (RT)ad[(long)(1 + a + r * NU) * AB] : (RT)0;
+                for (int j = 0; j < NXP; ++j)
+                    mine[(long)(PK::AO_PT + m * NXP + j) * BG] =
+                        (r < NX && j < NX) ? (RT)ad[(long)(1 + NU * NX + j + r * NX) * AB] : (RT)0;   // Pinf^T[r][j] = Pinf[j][r]
+            }
+        }
+    } else {
+        cK = cbase + S::O_K, cKT = cbase + S::O_KT, cPT = cbase + S::O_PT;
+    }
 
     // cone membership of each role's local rows, as bit masks in LDS: [cone][role]{x heads, x axis, u heads, u axis}
     const int ncx = EXT ? P.ncx : 0, ncu = EXT ? P.ncu : 0;
@@ -463,6 +523,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
 #pragma unroll
             for (int m = 0; m < RX; ++m) x[m] = x0[m];
             float pri_x = 0.f, dua_x = 0.f, pri_u = 0.f, dua_u = 0.f;
+            // adaptive rho: the iterations that adapt (admm.cpp:147) gather the norms of rho_benchmark.cpp:44-213 on the
+            // way — constraint rows [u_k; A x_k + B u_k (+ f) - x_{k+1}] against [znew_k; vnew_{k+1}], cost rows
+            // P x + q + A'y with P = blkdiag(Q~, R~, .., Pinf), q = [Q~ x; R~ u] (zero reference), y = [y_k; g_{k+1}] —
+            // each knot contributing the rows of knot k - 1 that needed its new dual g_k.
+            const bool adapt_now = ADP && i > 0 && i % 5 == 0;
+            const float rho_lin = rho;   // the linear cost of this iteration is formed before the adaptation (admm.cpp:139 vs :147)
+            RT a_pri = 0, a_axm = 0, a_zm = 0, a_dres = 0, a_pxm = 0, a_atym = 0, a_qm = 0;
+            RT a_xp[RX];
+            float a_gp[RX], a_up[RU], a_yp[RU];              // knot k - 1: x, new g, u, new y
+#pragma unroll
+            for (int m = 0; m < RX; ++m) a_xp[m] = (RT)0, a_gp[m] = 0.f;
+#pragma unroll
+            for (int m = 0; m < RU; ++m) a_up[m] = a_yp[m] = 0.f;
             FwdBuf fb[D];
 #pragma unroll
             for (int j = 0; j < D; ++j) {
@@ -562,6 +635,58 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
                             if (keep_w) stx(Swl, k, wl);
                         }
                 }
+                if constexpr (ADP) {
+                    if (adapt_now) {
+                        RT gk[RX], xfl[RX];
+#pragma unroll
+                        for (int m = 0; m < RX; ++m) gk[m] = (RT)gn[m], xfl[m] = (RT)xf[m];
+                        if (k >= 1) {
+                            RT atx[RX], atu[RU];
+#pragma unroll
+                            for (int m = 0; m < RX; ++m) atx[m] = (RT)0;
+#pragma unroll
+                            for (int m = 0; m < RU; ++m) atu[m] = (RT)0;
+                            quad_matvec<G, RX, NXL, RX, NXP>(atx, cATT, gk);     // A' g_k
+                            quad_matvec<G, RU, NXL, RX, NXP>(atu, cBT, gk);      // B' g_k
+#pragma unroll
+                            for (int m = 0; m < RX; ++m) {                       // state rows of knot k - 1
+                                if (k >= 2) atx[m] -= (RT)a_gp[m];
+                                const RT qv = (RT)cQD[m] * a_xp[m];
+                                upmax_abs(a_dres, qv + qv + atx[m]);
+                                upmax_abs(a_pxm, qv);
+                                upmax_abs(a_qm, qv);
+                                upmax_abs(a_atym, atx[m]);
+                                // the rollout's own x_k makes A x + B u (+ f) - x_k vanish: the row is 0 against vnew_k
+                                upmax_abs(a_pri, (RT)vn[m]);
+                                upmax_abs(a_zm, (RT)vn[m]);
+                            }
+#pragma unroll
+                            for (int m = 0; m < RU; ++m) {                       // input rows of knot k - 1
+                                const RT px = (RT)cRD[m] * (RT)a_up[m], aty = (RT)a_yp[m] + atu[m];
+                                upmax_abs(a_dres, px + px + aty);
+                                upmax_abs(a_pxm, px);
+                                upmax_abs(a_qm, px);
+                                upmax_abs(a_atym, aty);
+                            }
+                        }
+                        if (k == N - 1) {                                        // the terminal knot's own rows: Pinf x + Q~ x - g
+                            RT px[RX];
+#pragma unroll
+                            for (int m = 0; m < RX; ++m) px[m] = (RT)0;
+                            quad_matvec<G, RX, NXL, RX, NXP>(px, cPT, xfl);
+#pragma unroll
+                            for (int m = 0; m < RX; ++m) {
+                                const RT qv = (RT)cQD[m] * xfl[m], aty = (k >= 1) ? -gk[m] : (RT)0;
+                                upmax_abs(a_dres, px[m] + qv + aty);
+                                upmax_abs(a_pxm, px[m]);
+                                upmax_abs(a_qm, qv);
+                                upmax_abs(a_atym, aty);
+                            }
+                        }
+#pragma unroll
+                        for (int m = 0; m < RX; ++m) a_xp[m] = xfl[m], a_gp[m] = gn[m];
+                    }
+                }
                 if (pf) fetch_x(k + D, f);
                 if (k < N - 1) {
                     RT u[RU], xn[RX];
@@ -632,6 +757,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
                                 if (keep_w) stu(Szwl, k, zl2);
                             }
                     }
+                    if constexpr (ADP) {
+                        if (adapt_now) {
+#pragma unroll
+                            for (int m = 0; m < RU; ++m) {
+                                upmax_abs(a_pri, (RT)uf[m] - (RT)zn[m]);
+                                upmax_abs(a_axm, (RT)uf[m]);
+                                upmax_abs(a_zm, (RT)zn[m]);
+                                a_up[m] = uf[m], a_yp[m] = yn[m];
+                            }
+                        }
+                    }
                     if (pf && k + D < N - 1) fetch_u(k + D, f);
                     asm volatile("" ::: "memory");
                     quad_matvec<G, RX, NUL, RU, NUP>(xn, cB, u);   // + B u
@@ -652,6 +788,62 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
                     if (k0 + j < N) fwd_knot(k0 + j, fb[j]);
                 });
             it += 1;
+            RT accP[RX];                                     // Pinf' xref_{N-1}, with the Pinf the linear cost was formed with
+#pragma unroll
+            for (int m = 0; m < RX; ++m) accP[m] = (RT)0;
+            if constexpr (ADP) {
+                if (P.ref_mode != REF_ZERO) {
+                    RT xrl[RX];
+#pragma unroll
+                    for (int m = 0; m < RX; ++m) xrl[m] = (RT)ref_x(N - 1, m);
+                    quad_matvec<G, RX, NXL, RX, NXP>(accP, cPT, xrl);
+                }
+                if (adapt_now) {
+                    // predict_rho (rho_benchmark.cpp:173-195), then the first-order update of Kinf, Pinf (admm.cpp:160-172)
+                    const RT pri = group_max_t<G>(a_pri), axm = group_max_t<G>(a_axm), zm = group_max_t<G>(a_zm),
+                             dres = group_max_t<G>(a_dres), pxm = group_max_t<G>(a_pxm), atym = group_max_t<G>(a_atym),
+                             qm = group_max_t<G>(a_qm);
+                    const RT eps = (RT)1e-10, prin = axm > zm ? axm : zm;
+                    RT duan = pxm > atym ? pxm : atym;
+                    duan = qm > duan ? qm : duan;
+                    const RT ratio = (pri / (prin + eps)) / (dres / (duan + eps) + eps);
+                    RT nrho = (RT)rho_d * (RT)sqrt((double)ratio);
+                    if (P.rho_clip) nrho = nrho < (RT)P.rho_min ? (RT)P.rho_min : (nrho > (RT)P.rho_max ? (RT)P.rho_max : nrho);
+                    const double delta = (double)nrho - rho_d;
+                    const long AB = P.adapt_stride;
+                    double *ad = P.adapt + b;
+                    RT *mine = adp_cols + L;
+                    const double *sK = P.sens, *sP = P.sens + NU * NX;
+#pragma unroll
+                    for (int m = 0; m < RU; ++m) {
+                        const int a = q * RU + m;
+                        if (a < NU)
+                            for (int j = 0; j < NX; ++j) {       // this lane owns row a of Kinf: the solver's state and its own copy
+                                const double v = ad[(long)(1 + a + j * NU) * AB] + delta * sK[a + j * NU];
+                                ad[(long)(1 + a + j * NU) * AB] = v;
+                                mine[(long)(PK::AO_K + m * NXP + j) * BG] = (RT)v;
+                            }
+                    }
+#pragma unroll
+                    for (int m = 0; m < RX; ++m) {
+                        const int r = q * RX + m;
+                        if (r < NX) {
+                            for (int a = 0; a < NU; ++a) {       // Kinf^T rows: another lane owns the state's copy
+                                RT *c = mine + (long)(PK::AO_KT + m * NUP + a) * BG;
+                                *c = (RT)((double)*c + delta * sK[a + r * NU]);
+                            }
+                            for (int j = 0; j < NX; ++j) {       // column r of Pinf
+                                const double v = ad[(long)(1 + NU * NX + j + r * NX) * AB] + delta * sP[j + r * NX];
+                                ad[(long)(1 + NU * NX + j + r * NX) * AB] = v;
+                                mine[(long)(PK::AO_PT + m * NXP + j) * BG] = (RT)v;
+                            }
+                        }
+                    }
+                    if (q == 0) ad[0] = (double)nrho;
+                    rho_d = (double)nrho;
+                    rho = (float)nrho;
+                }
+            }
             if (need_res) {
                 res0 = group_max<G>(pri_x);
                 res1 = group_max<G>(dua_x) * rho;
@@ -748,8 +940,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
                 {
                     RT acc[RX];
 #pragma unroll
-                    for (int m = 0; m < RX; ++m) acc[m] = (RT)0;
-                    if (P.ref_mode != REF_ZERO) {
+                    for (int m = 0; m < RX; ++m) acc[m] = accP[m];
+                    if (!ADP && P.ref_mode != REF_ZERO) {
                         RT xrl[RX];
 #pragma unroll
                         for (int m = 0; m < RX; ++m) xrl[m] = (RT)ref_x(N - 1, m);
@@ -758,7 +950,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
                     float sx[RX];
                     take_x(N - 1, bterm, sx);
 #pragma unroll
-                    for (int m = 0; m < RX; ++m) p[m] = -acc[m] - (RT)(rho * sx[m]);
+                    for (int m = 0; m < RX; ++m) p[m] = -acc[m] - (RT)(rho_lin * sx[m]);
                 }
                 auto bwd_knot = [&](int t_, BwdBuf &f) __attribute__((always_inline)) {  // t counts knots from N-2 downwards
                     asm volatile("" ::: "memory");
@@ -769,9 +961,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMPC_STREAM
                     take_x(k, f, sx);
                     take_u(k, f, su);
 #pragma unroll
-                    for (int m = 0; m < RU; ++m) r[m] = (RT)(-(ref_u(k, m) * cRD[m]) - rho * su[m]);
+                    for (int m = 0; m < RU; ++m) r[m] = (RT)(-(ref_u(k, m) * cRD[m]) - rho_lin * su[m]);
 #pragma unroll
-                    for (int m = 0; m < RX; ++m) qk[m] = (RT)(-(ref_x(k, m) * cQD[m]) - rho * sx[m]);
+                    for (int m = 0; m < RX; ++m) qk[m] = (RT)(-(ref_x(k, m) * cQD[m]) - rho_lin * sx[m]);
                     if (t + D < N - 1) {
                         fetchb_x(k - D, f);
                         fetchb_u(k - D, f);

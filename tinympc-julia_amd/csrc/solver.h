@@ -102,6 +102,8 @@ struct Solver {
     std::vector<double> sens;
     bool sens_set = false, sens_dirty = true, adapt_dirty = true;
     double *d_sens = nullptr, *d_adapt = nullptr;
+    unsigned char *d_adp_cols = nullptr;  // stream kernel, adaptive rho: per-lane coefficient columns (scratch)
+    size_t adp_cols_bytes = 0;
     int set_sensitivity(const double *dK, const double *dP);
     int get_adaptive_state(double *rho, double *Kinf, double *Pinf);
     // one problem family PER INSTANCE: per-instance A, B (column-major, concatenated),

@@ -216,6 +216,8 @@ void Solver::free_batch() {
     dev_free(d_syl);
     dev_free(d_szl);
     dev_free(d_adapt);
+    dev_free(d_adp_cols);
+    adp_cols_bytes = 0;
     dev_free(d_x0d);
     adapt_dirty = true;
     dev_free(d_mpc_x);
@@ -314,7 +316,7 @@ int Solver::select_kernel(bool rollout) {
             set_error("adaptive_rho is not available on a per-instance-family solver");
             return -1;
         }
-        k = nullptr;  // adaptive rho: generic kernel only (per-instance rho, Kinf, Pinf in HBM)
+        k = nullptr;  // adaptive rho: the stream kernel's ADP variant (box sets), else the generic kernel
     }
     if (std::getenv("TINYMPC_HIP_NO_QUAD")) k = nullptr;    // tuning aid: time the fallback kernels on any shape
     // plain solves with fp64 recurrences: the matrix-core kernel of the shape (the fused closed loop stays on the quad
@@ -331,7 +333,8 @@ int Solver::select_kernel(bool rollout) {
     }
     // shapes / options without a quad kernel: the stream kernel for (nx, nu) if its LDS image fits
     const StreamEntry *s2 = nullptr;
-    if (!k && !st.adaptive_rho && !std::getenv("TINYMPC_HIP_NO_STREAM")) {
+    const bool adp_ok = !cones_active() && !lin_active() && !has_fdyn && chunk_iters == 0 && !std::getenv("TINYMPC_HIP_NO_STREAM_ADP");
+    if (!k && (!st.adaptive_rho || adp_ok) && !std::getenv("TINYMPC_HIP_NO_STREAM")) {
         s2 = find_stream_kernel(nx, nu);
         // 32-bit lane byte offsets into one knot's rows; LDS image of coefficients + bounds
         if (s2 && 16.0 * batch * std::max(nx, nu) >= 4.0e9) s2 = nullptr;
@@ -713,6 +716,16 @@ int Solver::ensure_extension_buffers() {
             dev_free(d_fam);
             adapt_dirty = false;
         }
+        if (se) {  // stream kernel: the per-lane columns of the rows built from Kinf / Pinf (kernel-local scratch)
+            const size_t G = (size_t)se->lanes, rx = (nx + G - 1) / G, ru = (nu + G - 1) / G;
+            const size_t len = ru * (G * rx) + rx * (G * ru) + rx * (G * rx);
+            const size_t bytes = len * G * Bn * (precision == 0 ? 8 : 4);
+            if (bytes > adp_cols_bytes) {
+                dev_free(d_adp_cols);
+                if (dev_alloc(d_adp_cols, bytes)) return -1;
+                adp_cols_bytes = bytes;
+            }
+        }
     }
     const size_t sets = (size_t)constraint_sets();
     size_t need = Bn * ((2 + 3 * sets) * EX + (3 + 3 * sets) * EU);  // generic kernel: admm_generic.hip.h
@@ -929,6 +942,8 @@ int Solver::launch_pass(hipStream_t stream, int mpc_steps, const int *idx, int n
     P.rho_max = (float)st.adaptive_rho_max;
     P.sens = d_sens;
     P.adapt = d_adapt;
+    P.adapt_stride = batch;
+    P.adp_cols = d_adp_cols;
     P.sgc = d_sgc;
     P.svc = d_svc;
     P.syc = d_syc;

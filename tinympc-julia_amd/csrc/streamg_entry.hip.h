@@ -30,6 +30,7 @@ void fill_streamg_family(const double *A, const double *Bm, const Cache &c, cons
                 put(q, S::O_A + m * NXP + j, A[row + (size_t)j * NX]);
                 put(q, S::O_AT + m * NXP + j, c.AmBKt(row, j));
                 put(q, S::O_PT + m * NXP + j, c.Pinf(j, row));
+                put(q, PK::O_ATT + m * NXP + j, A[j + (size_t)row * NX]);   // A^T (adaptive rho: A' g)
                 apf += c.AmBKt(row, j) * Pf[j];
             }
             for (int a = 0; a < NU; ++a) {
@@ -158,7 +159,22 @@ hipError_t launch_streamg(const AdmmParams &P, int precision, int ext, bool het,
     do {                                                                           \
         if (het) TMPC_LAUNCH_EXT(RT_, true); else TMPC_LAUNCH_EXT(RT_, false);     \
     } while (0)
-    if (precision == 0) TMPC_LAUNCH_RT(double); else TMPC_LAUNCH_RT(float);
+    if (P.adaptive_rho) {   // one family, box sets only (the solver checks): rho, Kinf, Pinf per instance
+#define TMPC_LAUNCH_ADP(RT_, OS_)                                                                                  \
+    do {                                                                                                           \
+        if (lds > 48 * 1024)                                                                                       \
+            (void)hipFuncSetAttribute((const void *)admm_streamg_kernel<NX, NU, G, RT_, 0, false, OS_, true>,      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
+        hipLaunchKernelGGL((admm_streamg_kernel<NX, NU, G, RT_, 0, false, OS_, true>), dim3(grid), dim3(256), lds, \
+                           stream, P);                                                                             \
+    } while (0)
+        if (precision == 0) {
+            if (oneshot) TMPC_LAUNCH_ADP(double, true); else TMPC_LAUNCH_ADP(double, false);
+        } else {
+            if (oneshot) TMPC_LAUNCH_ADP(float, true); else TMPC_LAUNCH_ADP(float, false);
+        }
+#undef TMPC_LAUNCH_ADP
+    } else if (precision == 0) TMPC_LAUNCH_RT(double); else TMPC_LAUNCH_RT(float);
 #undef TMPC_LAUNCH_RT
 #undef TMPC_LAUNCH_EXT
 #undef TMPC_LAUNCH_OS
