@@ -12,7 +12,7 @@ for cfg in cartpole quadrotor rocket_soc; do
     n=$(echo $grp | tr ' ' '_')
     timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d $R/gpurun_out/pmcS_${tag}_${cfg}_$n -- python3 $R/bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 || exit 1
   done
-  if [ $cfg = quadrotor ]; then  # matrix-core kernel: MFMA issue / busy counters (optional: skipped if the names are unknown)
+  if [ $cfg != cartpole ]; then  # matrix-core kernels: MFMA issue / busy counters (optional: skipped if the names are unknown)
     timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d $R/gpurun_out/pmcS_${tag}_${cfg}_MFMA -- python3 $R/bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 || echo "MFMA counter pass skipped"
   fi
 done

@@ -21,7 +21,7 @@ module TinyMPC
 
 export TinyMPCSolver, setup, solve, get_solution, get_status, set_x0, set_x_ref, set_u_ref,
        set_bound_constraints, set_linear_constraints, set_equality_constraints, set_cone_constraints, update_settings,
-       set_cache_terms, set_batch_size, reset_workspace, print_problem_data,
+       set_cache_terms, set_batch_size, set_gpus, get_gpus, reset_workspace, print_problem_data,
        compute_sensitivity_autograd, set_sensitivity, get_adaptive_rho
 
 using LinearAlgebra, Libdl, Printf
@@ -95,6 +95,16 @@ function set_batch_size(solver::TinyMPCSolver, batch::Int)
     solver.batch = batch
     return 0
 end
+
+# Spread the solver's batch over GPUs 0 .. n-1 of the node in contiguous shards (n = 1: back to one device).  Every
+# other call is unchanged and acts on the whole batch; solve() returns 0 iff every instance on every GPU converged
+# (the status block is folded over RCCL).  include/tinympc_hip.h section 3, INTEGRATION.md section 4.
+function set_gpus(solver::TinyMPCSolver, n::Integer)
+    _need(solver)
+    _ok(ccall((:set_gpus, _lib_path()), Int32, (Int32,), Int32(n)), "Failed to set the number of GPUs")
+    return 0
+end
+get_gpus() = Int(ccall((:get_gpus, _lib_path()), Int32, ()))
 
 # x0: Vector (length nx, broadcast to the batch) or Matrix (nx, batch)
 function set_x0(solver::TinyMPCSolver, x0::AbstractVecOrMat{Float64}; verbose::Bool=false)
