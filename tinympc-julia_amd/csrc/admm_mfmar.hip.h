@@ -52,9 +52,16 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
     __shared__ uint4 s_cmask[4];  // [lane group]: x head bits, x axis bits, u head bit, u axis bit (bit = slot)
 
     const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, g = l >> 4, j = l & 15;
-    const long slot_id = (long)blockIdx.x * 16 + j;
-    const bool active = slot_id < P.batch;
-    const long b = active ? slot_id : 0;
+    // Persistent workgroups: a workgroup takes 16-instance tiles off a global counter until none is left (the launch
+    // has at most as many workgroups as fit on the chip at once).  Left to the hardware dispatcher, 2 048 equally long
+    // tiles on 1 024 slots took 2.5 rounds: workgroups are handed to the XCDs in strict rotation, so a slot freed on
+    // one XCD stays empty while another XCD is still full (measured: scripts/mfmar_timeline.py).
+    const int n_tiles = (P.batch + 15) / 16;
+    __shared__ int s_tile;
+    int tile = 0;
+    long slot_id = j;                                          // of the current tile (set at the top of the tile loop)
+    bool active = false;
+    long b = 0;
     const long EX = (long)NX * N, EU = (long)NU * (N - 1);
     // rows of this lane: slot 0 -> x_g, slot 1 -> x_{4+g}, slot 2 -> u_g
     const int row0 = g, row1 = 4 + g, row2 = g;
@@ -101,14 +108,11 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
             s_cmask[tid] = make_uint4(hx, ax, hu, au);
         }
     }
-    // cold start = the zero workspace tiny_setup leaves (tiny_api.cpp:73-88)
-    for (int i = tid; i < PLEN * (N - 1) + 64; i += 192) s_state[i] = 0.f;
     constexpr int PAD_LO = 2 * NROW * nk + NROW, PAD_HI = PAD_LO + 1;
     __syncthreads();
     if (tid == 0) {
         s_bnd[PAD_LO] = -__builtin_inff();
         s_bnd[PAD_HI] = __builtin_inff();
-        *reinterpret_cast<int *>(s_xchg + 196) = 0;            // the hand-over step counter
     }
     __syncthreads();
 
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
     const int rf_str[3] = {ok0 ? NROW : 0, ok1 ? NROW : 0, ok2 ? NROW : 0};
     (void)rf_off, (void)rf_str;
     // HBM scratch of this tile: cone slack kept around a check
-    float *const scr = P.scratch + (size_t)blockIdx.x * S::scratch_floats(N) + l;
+    float *scr = P.scratch + l;                                // (+ the tile's block, set in the tile loop)
 
     int it = 0, conv = 0;
     float res0 = 0.f, res1 = 0.f, res2 = 0.f, res3 = 0.f;
@@ -203,9 +207,7 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
         return s;
     };
 
-    double x0r[2];
-    x0r[0] = (active && ok0) ? (double)P.x0[b * NX + row0] : 0.0;
-    x0r[1] = (active && ok1) ? (double)P.x0[b * NX + row1] : 0.0;
+    double x0r[2] = {0.0, 0.0};
 
     lds_vi *const s_step = (lds_vi *)reinterpret_cast<int *>(s_xchg + 196);
     int any_left = 1;                                          // some instance of the tile still iterates (all waves agree)
@@ -213,6 +215,7 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
     // timing probe (scripts/mfmac_cycles.py; results are NOT a solution): TINYMPC_HIP_MFMAC_DEBUG & 8 reports s_memtime
     // deltas per knot step in place of the residuals
     const bool probe = (P.mpc_steps & 8) != 0;
+    const bool probe_tl = (P.mpc_steps & 32) != 0;           // timeline: start (100 MHz clock, 2 x 16 bits), duration, where
     long long T_fwd = 0, T_bar = 0, T_bwd = 0, T_w1 = 0;
 #define TMPC_PROBE(x) x
 #else
@@ -268,6 +271,26 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
         return z;
     };
 
+    float fm0 = 0.f, fm1 = 0.f, fm2 = 0.f, fm3 = 0.f;          // over this workgroup's tiles: residual maxima, unsolved instances
+    int f_unsolved = 0;
+    for (;;) {
+    if (tid == 0) s_tile = (int)atomicAdd(&P.gacc[6], 1u);
+    __syncthreads();
+    tile = s_tile;
+    if (tile >= n_tiles) break;
+    slot_id = (long)tile * 16 + j;
+    active = slot_id < P.batch;
+    b = active ? slot_id : 0;
+    scr = P.scratch + (size_t)tile * S::scratch_floats(N) + l;
+    x0r[0] = (active && ok0) ? (double)P.x0[b * NX + row0] : 0.0;
+    x0r[1] = (active && ok1) ? (double)P.x0[b * NX + row1] : 0.0;
+    it = 0, conv = 0, any_left = 1;
+    res0 = res1 = res2 = res3 = 0.f;
+    // cold start = the zero workspace tiny_setup leaves (tiny_api.cpp:73-88)
+    for (int i = tid; i < PLEN * (N - 1) + 64; i += 192) s_state[i] = 0.f;
+    if (tid == 0) *s_step = 0;                                 // the hand-over step counter
+    TMPC_PROBE(const unsigned long long tl0 = wall_clock64();)
+    __syncthreads();
     if (wave != 0) {
         // ================= wave 1: state slot 0, wave 2: the input rows — box + cone of one row per lane =================
         // (admm.cpp:43-69, :93-96).  The duals of knot k are registers a1[k], a2[k] ([N-1]: state knot 0, which x0 feeds).
@@ -513,6 +536,12 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
         }
     }
 #ifdef TMPC_MFMAC_PROBE
+    if (probe_tl) {
+        const unsigned long long tl1 = wall_clock64();
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        res0 = (float)(tl0 & 0xFFFFull), res1 = (float)((tl0 >> 16) & 0xFFFFFFull), res2 = (float)(tl1 - tl0);
+        res3 = (float)(((hw >> 8) & 15u) + 16u * ((hw >> 13) & 7u) + 128u * (xcc & 15u));   // cu_id | se_id | xcc_id
+    }
     if (probe) {
         if (wave == 1) s_xchg[l] = (float)T_w1;
         __syncthreads();
@@ -534,16 +563,21 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
     }
     {
         const bool rep = active && wave == 0;                // the other wavefronts report nothing
-        float m0 = rep ? res0 : 0.f, m1 = rep ? res1 : 0.f, m2 = rep ? res2 : 0.f, m3 = rep ? res3 : 0.f;
+        fm0 = fmaxf(fm0, rep ? res0 : 0.f), fm1 = fmaxf(fm1, rep ? res1 : 0.f);
+        fm2 = fmaxf(fm2, rep ? res2 : 0.f), fm3 = fmaxf(fm3, rep ? res3 : 0.f);
+        f_unsolved += __popcll(__builtin_amdgcn_ballot_w64(rep && !conv && g == 0));
+    }
+    __syncthreads();                                           // the tile's LDS is free for the next one
+    }   // tile loop
+    {
 #pragma unroll
-        for (int off = 1; off < 16; off <<= 1) {
-            m0 = fmaxf(m0, __shfl_xor(m0, off, 64));
-            m1 = fmaxf(m1, __shfl_xor(m1, off, 64));
-            m2 = fmaxf(m2, __shfl_xor(m2, off, 64));
-            m3 = fmaxf(m3, __shfl_xor(m3, off, 64));
+        for (int off = 1; off < 64; off <<= 1) {
+            fm0 = fmaxf(fm0, __shfl_xor(fm0, off, 64));
+            fm1 = fmaxf(fm1, __shfl_xor(fm1, off, 64));
+            fm2 = fmaxf(fm2, __shfl_xor(fm2, off, 64));
+            fm3 = fmaxf(fm3, __shfl_xor(fm3, off, 64));
         }
-        const unsigned long long unsolved = __builtin_amdgcn_ballot_w64(rep && !conv && g == 0);
-        fold_status(P, m0, m1, m2, m3, __popcll(unsolved), tid);
+        fold_status(P, fm0, fm1, fm2, fm3, f_unsolved, tid);
     }
 }
 

@@ -107,6 +107,7 @@ __device__ __forceinline__ void fold_status(const AdmmParams &P, float m0, float
             __threadfence();
 #pragma unroll
             for (int i = 0; i < 5; ++i) P.gstat[i] = atomicExch(&P.gacc[i], 0u);
+            atomicExch(&P.gacc[6], 0u);   // (persistent kernels' tile counter)
             atomicExch(&P.gacc[7], 0u);
         }
     }
