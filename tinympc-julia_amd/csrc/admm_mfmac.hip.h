@@ -124,9 +124,16 @@ __global__ __launch_bounds__(192) void admm_mfmac_kernel(const AdmmParams P) {
     __shared__ uint4 s_cmask[8 * 4];  // [cone][lane group]: x head bits, x axis bits, u head bit, u axis bit (bit = slot)
 
     const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, g = l >> 4, j = l & 15;
-    const long slot_id = (long)blockIdx.x * 16 + j;
-    const bool active = slot_id < P.batch;
-    const long b = active ? slot_id : 0;
+    // Persistent workgroups: a workgroup takes 16-instance tiles off a global counter until none is left (the launch
+    // has at most as many workgroups as fit on the chip at once).  The hardware dispatcher hands workgroups to the XCDs
+    // in strict rotation, so with several rounds of long-running workgroups a slot freed on one XCD stays empty while
+    // another XCD is still full (admm_mfmar.hip.h, scripts/mfmar_timeline.py).
+    const int n_tiles = (P.batch + 15) / 16;
+    __shared__ int s_tile;
+    int tile = 0;
+    long slot_id = j;                                          // of the current tile (set at the top of the tile loop)
+    bool active = false;
+    long b = 0;
     const long EX = (long)NX * N, EU = (long)NU * (N - 1);
     // rows of this lane: slot 0 -> x_g, slot 1 -> x_{4+g}, slot 2 -> u_g
     const int row0 = g, row1 = 4 + g, row2 = g;
@@ -178,8 +185,6 @@ __global__ __launch_bounds__(192) void admm_mfmac_kernel(const AdmmParams P) {
             s_cmask[tid] = make_uint4(hx, ax, hu, au);
         }
     }
-    // cold start = the zero workspace tiny_setup leaves (tiny_api.cpp:73-88)
-    for (int i = tid; i < PLEN * (N - 1) + S::PAD_LEN; i += 192) s_state[i] = 0.f;
     __syncthreads();
 
     constexpr bool soc_x = CX > 0, soc_u = CU > 0;
@@ -199,7 +204,6 @@ __global__ __launch_bounds__(192) void admm_mfmac_kernel(const AdmmParams P) {
     if (tid == 0) {
         s_bnd[PAD_LO] = -__builtin_inff();
         s_bnd[PAD_HI] = __builtin_inff();
-        *reinterpret_cast<int *>(s_xchg + 196) = 0;            // the hand-over step counter
     }
     __syncthreads();
     const int bidx[3] = {ok0 ? row0 : -1, ok1 ? row1 : -1, ok2 ? NX + row2 : -1};
@@ -254,12 +258,10 @@ __global__ __launch_bounds__(192) void admm_mfmac_kernel(const AdmmParams P) {
     const int rf_str[3] = {ok0 ? NROW : 0, ok1 ? NROW : 0, ok2 ? NROW : 0};
     (void)rf_off, (void)rf_str;
     // HBM scratch of this wavefront: cone slack kept around a check
-    float *const scr = P.scratch + (size_t)blockIdx.x * S::scratch_floats(N) + l;
+    float *scr = P.scratch + l;                                // (+ the tile's block, set in the tile loop)
     auto SCR = [&](int pos, int sl) -> float & { return scr[((size_t)pos * 3 + sl) * 64]; };
 
-    double x0r[2];
-    x0r[0] = (active && ok0) ? (double)P.x0[b * NX + row0] : 0.0;
-    x0r[1] = (active && ok1) ? (double)P.x0[b * NX + row1] : 0.0;
+    double x0r[2] = {0.0, 0.0};
     float g0[2] = {0.f, 0.f}, gc0[2] = {0.f, 0.f};  // duals of knot 0 (state side)
 
     int it = 0, conv = 0;
@@ -330,6 +332,26 @@ __global__ __launch_bounds__(192) void admm_mfmac_kernel(const AdmmParams P) {
     constexpr int dbg = 0;
 #define TMPC_PROBE(x)
 #endif
+    float fm0 = 0.f, fm1 = 0.f, fm2 = 0.f, fm3 = 0.f;          // over this workgroup's tiles: residual maxima, unsolved instances
+    int f_unsolved = 0;
+    for (;;) {
+    if (tid == 0) s_tile = (int)atomicAdd(&P.gacc[6], 1u);
+    __syncthreads();
+    tile = s_tile;
+    if (tile >= n_tiles) break;
+    slot_id = (long)tile * 16 + j;
+    active = slot_id < P.batch;
+    b = active ? slot_id : 0;
+    scr = P.scratch + (size_t)tile * S::scratch_floats(N) + l;
+    x0r[0] = (active && ok0) ? (double)P.x0[b * NX + row0] : 0.0;
+    x0r[1] = (active && ok1) ? (double)P.x0[b * NX + row1] : 0.0;
+    g0[0] = g0[1] = gc0[0] = gc0[1] = 0.f;
+    it = 0, conv = 0, any_left = 1;
+    res0 = res1 = res2 = res3 = 0.f;
+    // cold start = the zero workspace tiny_setup leaves (tiny_api.cpp:73-88)
+    for (int i = tid; i < PLEN * (N - 1) + S::PAD_LEN; i += 192) s_state[i] = 0.f;
+    if (tid == 0) *s_step = 0;                                 // the hand-over step counter
+    __syncthreads();
     for (int i = 0; i < P.max_iter; ++i) {
         const int itn = i + 1;
         const bool check = ct > 0 && itn % ct == 0;
@@ -663,17 +685,22 @@ __global__ __launch_bounds__(192) void admm_mfmac_kernel(const AdmmParams P) {
         P.res[b * 4 + 3] = res3;
     }
     {
-        const bool rep = active && wave == 0;                // the state-side wavefront reports nothing
-        float m0 = rep ? res0 : 0.f, m1 = rep ? res1 : 0.f, m2 = rep ? res2 : 0.f, m3 = rep ? res3 : 0.f;
+        const bool rep = active && wave == 0;                // the other wavefronts report nothing
+        fm0 = fmaxf(fm0, rep ? res0 : 0.f), fm1 = fmaxf(fm1, rep ? res1 : 0.f);
+        fm2 = fmaxf(fm2, rep ? res2 : 0.f), fm3 = fmaxf(fm3, rep ? res3 : 0.f);
+        f_unsolved += __popcll(__builtin_amdgcn_ballot_w64(rep && !conv && g == 0));
+    }
+    __syncthreads();                                           // the tile's LDS is free for the next one
+    }   // tile loop
+    {
 #pragma unroll
-        for (int off = 1; off < 16; off <<= 1) {
-            m0 = fmaxf(m0, __shfl_xor(m0, off, 64));
-            m1 = fmaxf(m1, __shfl_xor(m1, off, 64));
-            m2 = fmaxf(m2, __shfl_xor(m2, off, 64));
-            m3 = fmaxf(m3, __shfl_xor(m3, off, 64));
+        for (int off = 1; off < 64; off <<= 1) {
+            fm0 = fmaxf(fm0, __shfl_xor(fm0, off, 64));
+            fm1 = fmaxf(fm1, __shfl_xor(fm1, off, 64));
+            fm2 = fmaxf(fm2, __shfl_xor(fm2, off, 64));
+            fm3 = fmaxf(fm3, __shfl_xor(fm3, off, 64));
         }
-        const unsigned long long unsolved = __builtin_amdgcn_ballot_w64(rep && !conv && g == 0);
-        fold_status(P, m0, m1, m2, m3, __popcll(unsolved), tid);
+        fold_status(P, fm0, fm1, fm2, fm3, f_unsolved, tid);
     }
 }
 

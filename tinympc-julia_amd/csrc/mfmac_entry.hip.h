@@ -144,11 +144,24 @@ hipError_t launch_mfmac(const AdmmParams &P_, bool ext, size_t lds, hipStream_t 
 #ifdef TMPC_MFMAC_PROBE
     P.mpc_steps = std::getenv("TINYMPC_HIP_MFMAC_DEBUG") ? std::atoi(std::getenv("TINYMPC_HIP_MFMAC_DEBUG")) : 0;   // timing probe build only
 #endif
-    const int grid = (P.batch + 15) / 16;
+    const int tiles = (P.batch + 15) / 16;
+    // persistent workgroups (the kernel takes tiles off a counter): as many as fit on the chip at once
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
 #define TMPC_MFMAC_LAUNCH(REFS_, CX_, CU_, BV_)                                                                       \
     do {                                                                                                              \
         (void)hipFuncSetAttribute((const void *)admm_mfmac_kernel<NX, NU, REFS_, CX_, CU_, BV_>,                      \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
+        int per_cu = 0;                                                                                               \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, admm_mfmac_kernel<NX, NU, REFS_, CX_, CU_, BV_>,    \
+                                                         192, lds) != hipSuccess || per_cu <= 0)                      \
+            per_cu = 1;                                                                                               \
+        const int grid = tiles < per_cu * cus ? tiles : per_cu * cus;                                                 \
         hipLaunchKernelGGL((admm_mfmac_kernel<NX, NU, REFS_, CX_, CU_, BV_>), dim3(grid), dim3(192), lds, stream, P);  \
     } while (0)
 #define TMPC_MFMAC_LAUNCH_BV(REFS_, CX_, CU_)                                                                         \
