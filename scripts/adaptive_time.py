@@ -4,14 +4,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tinympc_julia_amd as t
 B = int(os.environ.get("B", 65536))
 which = os.environ.get("PROB", "cartpole")
-prob = t.problems.cartpole(10, u_bound=0.5) if which == "cartpole" else t.problems.quadrotor(20, u_bound=0.5)
+NH = int(os.environ.get("N", 10 if which == "cartpole" else 20))
+tol = float(os.environ.get("TOL", 1e-3))
+prob = t.problems.cartpole(NH, u_bound=0.5) if which == "cartpole" else t.problems.quadrotor(NH, u_bound=0.5)
 x0 = t.problems.cartpole_x0(B, seed=3) if which == "cartpole" else t.problems.quadrotor_x0(B, seed=3)
 outs = []
 for env in (None, "1"):
     if env: os.environ["TINYMPC_HIP_NO_STREAM_ADP"] = "1"
     else: os.environ.pop("TINYMPC_HIP_NO_STREAM_ADP", None)
     bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
-    bs.update_settings(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1)
+    bs.update_settings(abs_pri_tol=tol, abs_dua_tol=tol, max_iter=100, check_termination=1)
     bs.set_adaptive_rho(True)
     bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
     bs.set_warm_start(False); bs.set_x0(x0); bs.set_profiling(True)
