@@ -315,50 +315,80 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
                     (void)row_sets(cone_x, xf, lo_of(0, 0), hi_of(0, 0), a1[N - 1], a2[N - 1], vn, vc);
                     if (F.full) around_check(cone_x, F, pri, dua, xf, vn, vc, xo_i, own, scr_i + (N - 1) * 192);
                 }
-                bool have = false;                                               // the next cell's value was read ahead
-                float x_ahead = 0.f;
-#pragma unroll
-                for (int k = 0; k < N - 1; ++k) {
-                    const int want = F.step0 + k + 1;                            // x_{k+1} is in the cell of position k
-                    float xf = x_ahead;
-                    if (!have) {
-                        TMPC_PROBE(const long long tb0 = probe ? clock64() : 0;)
-                        while (seen < want) {
-                            seen = __builtin_amdgcn_readfirstlane(*s_step);
-                            if (seen < want) __builtin_amdgcn_s_sleep(1);
-                        }
-                        TMPC_PROBE(if (probe) T_w1 += clock64() - tb0;)
-                        xf = *(lds_vf *)pa;
+                // Knots are taken TWO at a time: a knot's set arithmetic is one dependent chain of ~50 VALU instructions,
+                // and a wavefront issues dependent instructions every 8-12 cycles but independent ones every ~6
+                // (experiments/valu_dep_probe.hip) — two knots interleave into one stream.  Wave 0 is usually steps
+                // ahead; then the next pair's cells are read now, under this pair's arithmetic.
+                bool have = false;
+                float xa0 = 0.f, xa1 = 0.f;                                      // cells read ahead
+                auto until_step = [&](int want) {
+                    TMPC_PROBE(const long long tb0 = probe ? clock64() : 0;)
+                    while (seen < want) {
+                        seen = __builtin_amdgcn_readfirstlane(*s_step);
+                        if (seen < want) __builtin_amdgcn_s_sleep(1);
                     }
-                    // wave 0 is usually steps ahead: the next cell is then read now, under this knot's arithmetic
-                    have = k + 1 < N - 1 && seen > want;
-                    if (have) x_ahead = *(lds_vf *)(pa + a_str[0]);
-                    const float s = row_sets(cone_x, xf, lo_of(k + 1, 0), hi_of(k + 1, 0), a1[k], a2[k], vn, vc);
-                    if (F.full) around_check(cone_x, F, pri, dua, xf, vn, vc, xo_i + (k + 1) * NX, own, scr_i + k * 192);
-                    *pa = s;
-                    pa += a_str[0];
+                    TMPC_PROBE(if (probe) T_w1 += clock64() - tb0;)
+                };
+#pragma unroll
+                for (int k = 0; k < N - 1; k += 2) {
+                    const bool two = k + 1 < N - 1;                              // (the last knot of an odd count goes alone)
+                    const int want = F.step0 + k + (two ? 2 : 1);                // x_{k+1}, x_{k+2} are in the cells of positions k, k + 1
+                    float xf0 = xa0, xf1 = xa1;
+                    if (!have) {
+                        until_step(want);
+                        xf0 = *(lds_vf *)pa;
+                        if (two) xf1 = *(lds_vf *)(pa + a_str[0]);
+                    }
+                    const int nxt = k + 2 < N - 1 ? (k + 3 < N - 1 ? 2 : 1) : 0;  // knots of the next pair
+                    have = nxt > 0 && seen >= want + nxt;
+                    if (have) {
+                        xa0 = *(lds_vf *)(pa + 2 * a_str[0]);
+                        if (nxt == 2) xa1 = *(lds_vf *)(pa + 3 * a_str[0]);
+                    }
+                    float vn0, vc0 = 0.f, vn1 = 0.f, vc1 = 0.f, s1 = 0.f;
+                    const float s0 = row_sets(cone_x, xf0, lo_of(k + 1, 0), hi_of(k + 1, 0), a1[k], a2[k], vn0, vc0);
+                    if (two) s1 = row_sets(cone_x, xf1, lo_of(k + 2, 0), hi_of(k + 2, 0), a1[k + 1], a2[k + 1], vn1, vc1);
+                    if (F.full) {
+                        around_check(cone_x, F, pri, dua, xf0, vn0, vc0, xo_i + (k + 1) * NX, own, scr_i + k * 192);
+                        if (two) around_check(cone_x, F, pri, dua, xf1, vn1, vc1, xo_i + (k + 2) * NX, own, scr_i + (k + 1) * 192);
+                    }
+                    *pa = s0;
+                    if (two) pa[a_str[0]] = s1;
+                    pa += 2 * a_str[0];
                 }
             } else {
                 float *const uo_i = P.uout + b * EU + row2 + opq;
                 bool have = false;
-                float u_ahead = 0.f;
+                float ua0 = 0.f, ua1 = 0.f;
 #pragma unroll
-                for (int k = 0; k < N - 1; ++k) {
-                    const int want = F.step0 + k + 1;                            // u_k is in the cell of position k
-                    float uf = u_ahead;
+                for (int k = 0; k < N - 1; k += 2) {
+                    const bool two = k + 1 < N - 1;
+                    const int want = F.step0 + k + (two ? 2 : 1);                // u_k, u_{k+1} are in the cells of positions k, k + 1
+                    float uf0 = ua0, uf1 = ua1;
                     if (!have) {
                         while (seen < want) {
                             seen = __builtin_amdgcn_readfirstlane(*s_step);
                             if (seen < want) __builtin_amdgcn_s_sleep(1);
                         }
-                        uf = *(lds_vf *)pa;
+                        uf0 = *(lds_vf *)pa;
+                        if (two) uf1 = *(lds_vf *)(pa + a_str[2]);
                     }
-                    have = k + 1 < N - 1 && seen > want;
-                    if (have) u_ahead = *(lds_vf *)(pa + a_str[2]);
-                    const float s = row_sets(cone_u, uf, lo_of(k, 2), hi_of(k, 2), a1[k], a2[k], vn, vc);
-                    if (F.full) around_check(cone_u, F, pri, dua, uf, vn, vc, uo_i + k * NU, own, scr_i + k * 192);
-                    *pa = s;
-                    pa += a_str[2];
+                    const int nxt = k + 2 < N - 1 ? (k + 3 < N - 1 ? 2 : 1) : 0;
+                    have = nxt > 0 && seen >= want + nxt;
+                    if (have) {
+                        ua0 = *(lds_vf *)(pa + 2 * a_str[2]);
+                        if (nxt == 2) ua1 = *(lds_vf *)(pa + 3 * a_str[2]);
+                    }
+                    float vn0, vc0 = 0.f, vn1 = 0.f, vc1 = 0.f, s1 = 0.f;
+                    const float s0 = row_sets(cone_u, uf0, lo_of(k, 2), hi_of(k, 2), a1[k], a2[k], vn0, vc0);
+                    if (two) s1 = row_sets(cone_u, uf1, lo_of(k + 1, 2), hi_of(k + 1, 2), a1[k + 1], a2[k + 1], vn1, vc1);
+                    if (F.full) {
+                        around_check(cone_u, F, pri, dua, uf0, vn0, vc0, uo_i + k * NU, own, scr_i + k * 192);
+                        if (two) around_check(cone_u, F, pri, dua, uf1, vn1, vc1, uo_i + (k + 1) * NU, own, scr_i + (k + 1) * 192);
+                    }
+                    *pa = s0;
+                    if (two) pa[a_str[2]] = s1;
+                    pa += 2 * a_str[2];
                 }
             }
             if (F.need_res) {                                                    // hand the maxima to wave 0
