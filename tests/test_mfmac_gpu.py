@@ -176,10 +176,11 @@ def test_mfmac_general_cones_and_bounds(hip_lib, oracle_built, monkeypatch, case
     bs.close()
 
 
-@pytest.mark.parametrize("case", ["knot_bounds", "zero_refs_input_cone", "state_cone_outside_slot0"])
+@pytest.mark.parametrize("case", ["knot_bounds", "zero_refs_input_cone", "state_cone_outside_slot0", "box_only"])
 def test_mfmar_variants(hip_lib, oracle_built, case):
     """the compiled-horizon kernel's other instantiations at N = 50: bounds that depend on the knot (LDS pack), no
-    references + a cone on the input side only; a state cone outside rows 0..3 is not its case (-> the LDS kernel)"""
+    references + a cone on the input side only, box sets only; a state cone outside rows 0..3 is not its case (-> the
+    LDS kernel)"""
     N, B = 50, 21
     prob = t.problems.rocket(N)
     x0 = t.problems.rocket_x0(B, seed=8)
@@ -193,6 +194,8 @@ def test_mfmar_variants(hip_lib, oracle_built, case):
         prob.u_max[:, ::3] += 1.0
     elif case == "zero_refs_input_cone":
         xr, ur, cones = None, None, ([0], [3], [0.25], [], [], [])
+    elif case == "box_only":
+        cones, fdyn = None, None                            # plain one-shot solve of the compiled shape: mfmar, not the quad kernel
     else:
         cones = ([0], [3], [0.25], [2], [3], [0.6])         # state rows 2..4: slot 0 and slot 1
         expect = "mfmac<6,3>"

@@ -348,13 +348,16 @@ int Solver::select_kernel(bool rollout) {
     // kernel of the shape (TINYMPC_HIP_NO_MFMAC: tuning / test aid).  TINYMPC_HIP_MFMAC_ALL=1 also sends box-only
     // one-shot solves of the shape there.
     const ConeEntry *c2 = nullptr;
-    const bool plain_ok = std::getenv("TINYMPC_HIP_MFMAC_ALL") != nullptr;
+    // box-only one-shot solves go there too where the horizon is compiled in (rocket N = 50: 4.3 ms on mfmar against
+    // 5.5 ms on the quad kernel, which spills at this horizon); TINYMPC_HIP_MFMAC_ALL extends that to the LDS kernel
+    const ConeEntry *cn = std::getenv("TINYMPC_HIP_NO_MFMAR") ? nullptr : find_cone_kernel(nx, nu, N);
+    if (cn && cn->supports && !cn->supports(*this)) cn = nullptr;
+    const bool plain_ok = std::getenv("TINYMPC_HIP_MFMAC_ALL") != nullptr || cn != nullptr;
     if ((s2 || (k && plain_ok)) && !warm_start && chunk_iters == 0 && !rollout && precision == 0 && !hetero && !lin_active() &&
         !st.adaptive_rho && (has_fdyn || cones_active() || plain_ok) && xref_kind < 2 && uref_kind < 2 &&
         !(refs_device_owned && ref_mode == REF_PER_INSTANCE) && !std::getenv("TINYMPC_HIP_NO_MFMAC") && !genv &&
         !std::getenv("TINYMPC_HIP_NO_MFMA")) {
-        c2 = std::getenv("TINYMPC_HIP_NO_MFMAR") ? nullptr : find_cone_kernel(nx, nu, N);   // horizon compiled in
-        if (c2 && c2->supports && !c2->supports(*this)) c2 = nullptr;
+        c2 = cn;                                                             // horizon compiled in
         if (!c2) c2 = find_cone_kernel(nx, nu, 0);
         if (c2 && c2->lds_bytes(*this) > 160 * 1024 - 1024) c2 = nullptr;   // horizon too long for one tile's LDS
         if ((st.en_state_soc && ncx > 1) || (st.en_input_soc && ncu > 1)) c2 = nullptr;   // one cone per side
