@@ -40,6 +40,25 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _lib_hash():
+    """source hash of the library (csrc/ + include/), the same digest as tinympc_julia_amd.source_hash() — restated here
+    because the parent of a multi-rank launch must not import the package (tests/test_bench_launch.py holds them equal)"""
+    import glob
+    import hashlib
+    pkg = os.path.join(ROOT, "tinympc-julia_amd")
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(pkg, "csrc", "*.hip")) + glob.glob(os.path.join(pkg, "csrc", "*.h")) +
+                   glob.glob(os.path.join(pkg, "csrc", "*.cpp")) +
+                   [os.path.join(pkg, "csrc", "Makefile"), os.path.join(ROOT, "include", "tinympc_hip.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+LIB_HASH = _lib_hash()
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
@@ -154,18 +173,27 @@ def committed_counters(family, precision, batch, kernel):
     import glob
     out = {"traffic": None, "valu_issue": None, "mfma_issue": None, "valu_insts": None, "source": None}
     path = os.path.join(ROOT, "profiles", "traffic.json")
+
+    def lib_note(e):
+        """was the profile taken on the library as it is now?  (source hash of csrc/ + include/, recorded by collect_profiles)"""
+        h = e.get("library_sha256")
+        if not h:
+            return "library version not recorded"
+        return "same library sources" if h == LIB_HASH else "taken on an EARLIER version of the library sources"
+
     if os.path.isfile(path):
         for e in json.load(open(path)):
             if (e["family"], e["precision"], e["batch"], e["kernel"]) == (family, precision, batch, kernel):
                 out["traffic"] = e["hbm_bytes_per_launch"]
-                out["source"] = "profiles/traffic.json (committed rocprofv3 --pmc passes, " + e.get("tag", "r01") + ")"
+                out["source"] = ("profiles/traffic.json (committed rocprofv3 --pmc passes, " + e.get("tag", "r01") + "; " +
+                                 lib_note(e) + ")")
     for p in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{family}_sq_counters.json"))):
         e = json.load(open(p))
         if (e.get("kernel"), e.get("batch")) == (kernel, batch) and precision == 0:
             out["valu_issue"] = e.get("derived_valu_issue_utilisation")
             out["mfma_issue"] = e.get("derived_mfma_issue_utilisation")
             out["valu_insts"] = e.get("SQ_INSTS_VALU")
-            out["sq_source"] = "profiles/" + os.path.basename(p) + " (committed)"
+            out["sq_source"] = "profiles/" + os.path.basename(p) + " (committed; " + lib_note(e) + ")"
     return out
 
 
@@ -492,6 +520,7 @@ def main():
                  else f"batch={n_local}/GPU")
         out = {
             "metric": "qp_solves_per_sec", "value": value, "unit": "solves/s", "n_gpus": world,
+            "library_sha256": LIB_HASH,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": avg_step_ms,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32" if args.precision == 1 else "f32 (f64 recurrences)", "data": "synthetic",

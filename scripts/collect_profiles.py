@@ -46,8 +46,9 @@ for cfg in ("cartpole", "quadrotor", "rocket_soc"):
     d = json.loads(line)
     if sq:
         sq["family"], sq["kernel"], sq["batch"] = cfg, d["config"]["kernel"], d["config"]["batch_per_gpu"]
+        sq["library_sha256"] = d.get("library_sha256")
         json.dump(sq, open(f"{root}/profiles/{tag}_{cfg}_sq_counters.json", "w"), indent=1)
-    traffic.append({"tag": tag, "family": cfg, "precision": 0, "batch": d["config"]["batch_per_gpu"], "kernel": d["config"]["kernel"],
+    traffic.append({"tag": tag, "library_sha256": d.get("library_sha256"), "family": cfg, "precision": 0, "batch": d["config"]["batch_per_gpu"], "kernel": d["config"]["kernel"],
                     "FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"],
                     "hbm_bytes_per_launch": (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
                     "algorithmic_bytes_per_launch": d["roofline"]["algorithmic_bytes_per_launch"],

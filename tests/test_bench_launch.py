@@ -53,3 +53,13 @@ def test_no_gpu_is_refused_loudly():
         pytest.skip("a GPU is present")
     p, lines = _run("--steps", "1", "--warmup", "0")
     assert p.returncode != 0 and not lines and "no CPU fallback" in p.stderr
+
+
+def test_bench_library_hash_matches_package():
+    """bench.py labels replayed counters with the library's source hash; it must be the package's own digest"""
+    import importlib.util
+    import tinympc_julia_amd as t
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.LIB_HASH == t.source_hash()
