@@ -1095,6 +1095,46 @@ def test_config4_full_size_properties(hip_lib, oracle_built):
     bs.close()
 
 
+def test_config4_persistent_tiles_tolerance_terminated(hip_lib, oracle_built):
+    """the on-chip kernel's persistent workgroups with early exits: 40 000 rocket instances (2 500 tiles, more than fit on
+    the chip at once, so workgroups take several tiles off the counter and tiles finish at different iterations),
+    tolerance-terminated as in rocket_landing_constraints.jl:61-62 — 48 distinct instances replicated through the batch
+    in a scrambled order: every copy bit-identical to its first occurrence wherever its tile ran, the distinct ones
+    against the fp64 oracle by solution, the launch status and the per-instance counters consistent"""
+    B, D, N = 40000, 48, 50
+    prob = t.problems.rocket(N)
+    base = t.problems.rocket_x0(D, seed=6)
+    base[:, :8] *= 0.15                                   # some easy instances: whole tiles of them stop early
+    rng = np.random.default_rng(11)
+    pick = np.concatenate([np.arange(D), np.sort(rng.integers(0, 8, 4096)), rng.integers(0, D, B - D - 4096)])
+    x0 = np.asfortranarray(base[:, pick])
+    xr, ur = t.problems.rocket_refs(N)
+    kw = dict(abs_pri_tol=2e-2, abs_dua_tol=1e-2, max_iter=250, check_termination=1)
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+    bs.update_settings(**kw)
+    bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    bs.set_fdyn(prob.fdyn)
+    bs.set_cone_constraints([0], [3], [0.25], [0], [3], [0.5])
+    bs.set_warm_start(False)
+    bs.set_x_ref(xr)
+    bs.set_u_ref(ur)
+    bs.set_x0(x0)
+    status = bs.solve()
+    assert bs.kernel_name == "mfmar<6,3,50>"
+    sol, st = bs.get_solution(), bs.get_status()
+    assert status == int(np.any(st["solved"] == 0))
+    assert len(np.unique(st["iter"][:D])) > 3, np.unique(st["iter"][:D], return_counts=True)   # tiles stop at different iterations
+    for name in ("iter", "solved"):
+        assert np.array_equal(st[name], st[name][:D][pick])
+    assert np.array_equal(sol["controls"], sol["controls"][:, :, :D][:, :, pick])
+    assert np.array_equal(sol["states"], sol["states"][:, :, :D][:, :, pick])
+    mk = _rocket_oracle(oracle_built, prob, xr, ur, True, True, kw)
+    ref = _oracle_loop(mk, base)
+    first = dict(states=sol["states"][:, :, :D], controls=sol["controls"][:, :, :D])
+    parity_every_instance(first, {k: v[:D] for k, v in st.items()}, ref, mk, base, kw, prob.rho, tag="config 4 persistent")
+    bs.close()
+
+
 def test_config5_shard_tolerance_terminated(hip_lib, oracle_built):
     """BASELINE config 5 as one rank sees it: a 2^17-instance shard of the 2^20 quadrotor batch (seed 3),
     tolerance-terminated with check_termination = 10 — every instance against the fp64 oracle, iteration
