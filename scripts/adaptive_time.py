@@ -9,9 +9,11 @@ tol = float(os.environ.get("TOL", 1e-3))
 prob = t.problems.cartpole(NH, u_bound=0.5) if which == "cartpole" else t.problems.quadrotor(NH, u_bound=0.5)
 x0 = t.problems.cartpole_x0(B, seed=3) if which == "cartpole" else t.problems.quadrotor_x0(B, seed=3)
 outs = []
-for env in (None, "1"):
-    if env: os.environ["TINYMPC_HIP_NO_STREAM_ADP"] = "1"
-    else: os.environ.pop("TINYMPC_HIP_NO_STREAM_ADP", None)
+for env in ((), ("TINYMPC_HIP_NO_QUAD_ADP",), ("TINYMPC_HIP_NO_QUAD_ADP", "TINYMPC_HIP_NO_STREAM_ADP")):
+    for v in ("TINYMPC_HIP_NO_QUAD_ADP", "TINYMPC_HIP_NO_STREAM_ADP"):
+        os.environ.pop(v, None)
+    for v in env:
+        os.environ[v] = "1"
     bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
     bs.update_settings(abs_pri_tol=tol, abs_dua_tol=tol, max_iter=100, check_termination=1)
     bs.set_adaptive_rho(True)
@@ -26,7 +28,9 @@ for env in (None, "1"):
     outs.append((bs.kernel_name, ms, sol, st, rho))
     print(f"{bs.kernel_name:16s} {ms:8.3f} ms  iters mean {st['iter'].mean():.1f}  solved {st['solved'].mean():.3f}  rho range {(float(np.min(rho)), float(np.max(rho)))}")
     bs.close()
-a, b = outs
-same = a[3]["iter"] == b[3]["iter"]
-print("same iteration count:", same.mean(), " max |du| on those:", np.abs(a[2]["controls"] - b[2]["controls"])[..., same].max() if same.any() else None,
-      " max |drho|:", np.abs(np.asarray(a[4]) - np.asarray(b[4]))[same].max())
+b = outs[-1]
+for a in outs[:-1]:
+    same = a[3]["iter"] == b[3]["iter"]
+    print(a[0], "vs", b[0], ": same iteration count:", same.mean(), " max |du| on those:",
+          np.abs(a[2]["controls"] - b[2]["controls"])[..., same].max() if same.any() else None,
+          " max |drho|:", np.abs(np.asarray(a[4]) - np.asarray(b[4]))[same].max())

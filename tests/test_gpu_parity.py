@@ -1361,20 +1361,26 @@ ADAPTIVE = ["G9a_quadrotor_adaptive_fixed100", "G9b_quadrotor_adaptive_tol", "G9
             "G9d_cartpole_adaptive_noclip"]
 
 
-@pytest.mark.parametrize("kernel", ["stream", "generic"])
+@pytest.mark.parametrize("kernel", ["default", "stream", "generic"])
 @pytest.mark.parametrize("name", ADAPTIVE)
 def test_adaptive_rho_vs_reference_golden(hip_lib, monkeypatch, name, kernel):
-    """adaptive rho (admm.cpp:147-174, rho_benchmark.cpp) per instance — on the stream kernel's
-    adaptive variant (the norms gathered in the forward sweep, rho / Kinf / Pinf rows per instance; what an adaptive
-    solve runs on) and on the generic kernel (TINYMPC_HIP_NO_STREAM_ADP) — against outputs of the compiled reference: consecutive solves of one solver (workspace warm-starts, adapted cache
+    """adaptive rho (admm.cpp:147-174, rho_benchmark.cpp) per instance — on the kernel an adaptive solve
+    runs on by default (the quad kernel's adaptive variant for the cartpole shapes: rho / Kinf / Pinf rows in the lanes'
+    registers; the stream kernel's for every other shape: the same rows as HBM columns; both gather the norms in the
+    forward sweep), on the stream kernel (TINYMPC_HIP_NO_QUAD_ADP) and on the generic kernel (+ TINYMPC_HIP_NO_STREAM_ADP)
+    — against outputs of the compiled reference: consecutive solves of one solver (workspace warm-starts, adapted cache
     persists), built-in 12x4 tables on the quadrotor, finite-difference sensitivities on the cartpole, clipping on and
     off.  Same iteration counts, rho path within 1e-5 relative, adapted Kinf / Pinf and the solution within the fp32
     tolerance."""
     g = load_golden(name)
     prob = problem_of(g)
     B = g["batch"]
+    if kernel in ("stream", "generic"):
+        monkeypatch.setenv("TINYMPC_HIP_NO_QUAD_ADP", "1")
     if kernel == "generic":
         monkeypatch.setenv("TINYMPC_HIP_NO_STREAM_ADP", "1")
+    quad = kernel == "default" and (prob.nx, prob.nu) == (4, 1)
+    expect = "generic" if kernel == "generic" else (f"quad<4,1,{prob.N},g4>" if quad else f"stream4<{prob.nx},{prob.nu}>")
     bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
     bs.update_settings(**g["settings"])
     if prob.has_bounds():
@@ -1385,7 +1391,7 @@ def test_adaptive_rho_vs_reference_golden(hip_lib, monkeypatch, name, kernel):
     bs.set_x0(cm(g["x0"], prob.nx, B))
     for k in range(len(g["expect"][0])):
         status = bs.solve()
-        assert bs.kernel_name == ("generic" if kernel == "generic" else f"stream4<{prob.nx},{prob.nu}>")
+        assert bs.kernel_name == expect
         sol, st, ad = bs.get_solution(), bs.get_status(), bs.get_adaptive_state()
         assert status == max(e[k]["status"] for e in g["expect"])
         for b in range(B):

@@ -103,6 +103,9 @@ struct QuadShape {
     static constexpr int REFS_LEN = N * G * RW;
     static constexpr int THREADS = 256;
     static constexpr int INST_PER_BLOCK = THREADS / G;
+    // adaptive rho (ADP kernels): built where a lane's coefficient rows live in its own registers — 4 lanes per instance
+    // and a pack small enough for VGPRs (the cartpole shapes): the adapted Kinf / Pinf rows are then just those registers
+    static constexpr bool ADP_OK = G == 4 && CP_LIVE * 2 <= 72;
     // ---- storage policy ----
     // ---- storage policy -------------------------------------------------------------------
     // Coefficient rows: VGPRs when small, LDS when their (live) register footprint would exceed
@@ -299,14 +302,39 @@ __device__ __forceinline__ void quad_matvec(RT (&acc)[ROWS], const CP C, const R
     if constexpr (!std::is_pointer<CP>::value && TMPC_FENCE_LDS_MATVEC == 1) __builtin_amdgcn_sched_barrier(0);
 }
 
+template <class T>
+__device__ __forceinline__ void upmax_abs_q(T &m, T v) {
+    v = v < (T)0 ? -v : v;
+    m = v > m ? v : m;
+}
+// max over the G lanes of a group, any arithmetic type (the adaptive-rho norms are kept in the kernel's RT)
+template <int G, class T>
+__device__ __forceinline__ T group_max_q(T v) {
+    if constexpr (G >= 2) {
+        const T o = __shfl_xor(v, 1, 64);
+        v = o > v ? o : v;
+    }
+    if constexpr (G == 4) {
+        const T o = __shfl_xor(v, 2, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
 // OS ("one shot"): cold start and no workspace kept (the benchmark configs).  vnew / znew then overwrite
 // v / z in place — the separate copies only exist to reproduce what the reference leaves in its
 // workspace after a converged exit (admm.cpp:181-197) — which removes E_x + E_u floats of state per
 // instance.  Same arithmetic, same results.
 // UNI ("uniform"): additionally no instance can converge (fixed-iteration solves): see the loop body.
-template <class S, int REFS, class RT, bool XB, bool OS, bool UNI>
+// ADP: adaptive rho (admm.cpp:147-174 with rho_benchmark.cpp:44-213), for shapes whose coefficient rows are per-lane
+// registers (QuadShape::ADP_OK).  Every instance carries its own rho, Kinf and Pinf: the Kinf / Kinf^T / Pinf^T rows of the
+// lane's pack are loaded from the solver's adaptive state at entry and updated in place — with that state — on the
+// iterations that adapt (i > 0, i % 5 == 0), from norms gathered during that iteration's forward sweep (the stream
+// kernel's ADP variant does the same with its rows in HBM columns: admm_streamg.hip.h has the derivation).
+template <class S, int REFS, class RT, bool XB, bool OS, bool UNI, bool ADP = false>
 __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
     static_assert(!UNI || OS, "the uniform variant is only built for one-shot solves");
+    static_assert(!ADP || (S::ADP_OK && !UNI), "adaptive rho: per-lane coefficient registers, per-lane guard");
     constexpr int NX = S::NX, NU = S::NU, N = S::N, G = S::G;
     constexpr int RX = S::RX, RU = S::RU, NXP = S::NXP, NUP = S::NUP;
     constexpr int NXL = S::NXL, NUL = S::NUL;
@@ -389,7 +417,43 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
     for (int m = 0; m < RX; ++m) cQD[m] = ld[m];
 #pragma unroll
     for (int m = 0; m < RU; ++m) cRD[m] = ld[RX + m];
-    const float rho = P.rho;
+    float rho = P.rho;         // (ADP: this instance's own, re-predicted every 5th iteration)
+    float rho_lin = rho;       // the rho the linear cost of the current iteration is formed with (admm.cpp:139 precedes :147)
+    double rho_d = (double)P.rho;
+    bool adapt_now = false;    // this iteration's forward sweep gathers the norms
+    RT a_pri = 0, a_axm = 0, a_zm = 0, a_dres = 0, a_pxm = 0, a_atym = 0, a_qm = 0;
+    RT accP[RX];               // ADP: Pinf' xref_{N-1} with the Pinf the linear cost was formed with
+#pragma unroll
+    for (int m = 0; m < RX; ++m) accP[m] = (RT)0;
+    // the family's Kinf^T rows: A' g = AmBKt g + Kinf0' (B' g) — the pack has no A^T block, and AmBKt stays the family's
+    RT kt0[ADP ? RX * NUP : 1];
+    if constexpr (ADP) {
+#pragma unroll
+        for (int i = 0; i < RX * NUP; ++i) kt0[i] = rcoef[S::O_KT + i];
+        if (active) {   // this instance's rows from the solver's adaptive state [1 + nu nx + nx nx][batch] (rho | Kinf | Pinf)
+            const long AB = P.adapt_stride;
+            const double *ad = P.adapt + b;
+            rho_d = ad[0];
+            rho = (float)rho_d;
+#pragma unroll
+            for (int m = 0; m < RU; ++m) {
+                const int a = UREP ? m : q * RU + m;
+#pragma unroll
+                for (int j = 0; j < NX; ++j)
+                    if (a < NU) rcoef[S::O_K + m * NXP + j] = (RT)ad[(long)(1 + a + j * NU) * AB];
+            }
+#pragma unroll
+            for (int m = 0; m < RX; ++m) {
+                const int r = q * RX + m;
+                if (r < NX) {
+#pragma unroll
+                    for (int a = 0; a < NU; ++a) rcoef[S::O_KT + m * NUP + a] = (RT)ad[(long)(1 + a + r * NU) * AB];
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) rcoef[S::O_PT + m * NXP + j] = (RT)ad[(long)(1 + NU * NX + j + r * NX) * AB];
+                }
+            }
+        }
+    }
 
     // ---- per-instance state ----
     // One accessor per trajectory: a statically indexed register array, or a per-thread column of
@@ -558,6 +622,11 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
 #pragma unroll
         for (int m = 0; m < RX; ++m) x[m] = x0[m];
         if constexpr (RES) pri_x = dua_x = pri_u = dua_u = 0.f;
+        RT a_gn[RX], a_xf[RX], a_vn[RX], a_xp[RX], a_gp[RX], a_up[RU], a_yp[RU];   // ADP: this knot's / the previous knot's values
+#pragma unroll
+        for (int m = 0; m < RX; ++m) a_gn[m] = a_xf[m] = a_vn[m] = a_xp[m] = a_gp[m] = (RT)0;
+#pragma unroll
+        for (int m = 0; m < RU; ++m) a_up[m] = a_yp[m] = (RT)0;
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             // LDS-resident constants (bounds, shared references, big coefficient packs) are re-read
@@ -577,6 +646,61 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
                     dua_x = fmaxf(dua_x, fabsf(v_get(k, m) - vn));
                 }
                 w_set(k, m, vn);
+                if constexpr (ADP) a_gn[m] = (RT)((gk + xf) - vn), a_xf[m] = (RT)xf, a_vn[m] = (RT)vn;
+            }
+            if constexpr (ADP) {
+                if (adapt_now) {   // rows of knot k - 1 that needed g_k, the terminal knot's own (see admm_streamg.hip.h)
+                    if (k >= 1) {
+                        RT btg[RU], atx[RX];
+#pragma unroll
+                        for (int m = 0; m < RU; ++m) btg[m] = (RT)0;
+#pragma unroll
+                        for (int m = 0; m < RX; ++m) atx[m] = (RT)0;
+                        quad_matvec<G, RU, NXL, RX, NXP>(btg, cBT, a_gn);          // B' g_k
+                        quad_matvec<G, RX, NXL, RX, NXP>(atx, cAT, a_gn);          // AmBKt g_k
+                        if constexpr (UREP) {
+#pragma unroll
+                            for (int m = 0; m < RX; ++m) atx[m] = tfma(kt0[m * NUP], btg[0], atx[m]);   // + Kinf0' B' g_k = A' g_k
+                        } else {
+                            quad_matvec<G, RX, NUL, RU, NUP>(atx, (const RT *)kt0, btg);
+                        }
+#pragma unroll
+                        for (int m = 0; m < RX; ++m) {
+                            if (k >= 2) atx[m] -= a_gp[m];
+                            const RT qv = (RT)cQD[m] * a_xp[m];
+                            upmax_abs_q(a_dres, qv + qv + atx[m]);
+                            upmax_abs_q(a_pxm, qv);
+                            upmax_abs_q(a_qm, qv);
+                            upmax_abs_q(a_atym, atx[m]);
+                            upmax_abs_q(a_pri, a_vn[m]);   // A x + B u - x_k vanishes against the rollout's own x_k
+                            upmax_abs_q(a_zm, a_vn[m]);
+                        }
+#pragma unroll
+                        for (int m = 0; m < RU; ++m) {
+                            const RT px = (RT)cRD[m] * a_up[m], aty = a_yp[m] + btg[m];
+                            upmax_abs_q(a_dres, px + px + aty);
+                            upmax_abs_q(a_pxm, px);
+                            upmax_abs_q(a_qm, px);
+                            upmax_abs_q(a_atym, aty);
+                        }
+                    }
+                    if (k == N - 1) {
+                        RT px[RX];
+#pragma unroll
+                        for (int m = 0; m < RX; ++m) px[m] = (RT)0;
+                        quad_matvec<G, RX, NXL, RX, NXP>(px, cPT, a_xf);
+#pragma unroll
+                        for (int m = 0; m < RX; ++m) {
+                            const RT qv = (RT)cQD[m] * a_xf[m], aty = (k >= 1) ? -a_gn[m] : (RT)0;
+                            upmax_abs_q(a_dres, px[m] + qv + aty);
+                            upmax_abs_q(a_pxm, px[m]);
+                            upmax_abs_q(a_qm, qv);
+                            upmax_abs_q(a_atym, aty);
+                        }
+                    }
+#pragma unroll
+                    for (int m = 0; m < RX; ++m) a_xp[m] = a_xf[m], a_gp[m] = a_gn[m];
+                }
             }
             if (k < N - 1) {
                 RT u[RU], xn[RX];
@@ -600,6 +724,14 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
                         dua_u = fmaxf(dua_u, fabsf(z_get(k, m) - zn));
                     }
                     zw_set(k, m, zn);
+                    if constexpr (ADP) {
+                        if (adapt_now) {
+                            upmax_abs_q(a_pri, (RT)uf - (RT)zn);
+                            upmax_abs_q(a_axm, (RT)uf);
+                            upmax_abs_q(a_zm, (RT)zn);
+                            a_up[m] = (RT)uf, a_yp[m] = (RT)((yk + uf) - zn);
+                        }
+                    }
                 }
                 // A x does not wait for u: both mat-vecs of x issue side by side, B u joins last
                 if constexpr (UREP) {
@@ -632,8 +764,8 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
             {
                 RT acc[RX];
 #pragma unroll
-                for (int m = 0; m < RX; ++m) acc[m] = (RT)0;
-                if constexpr (REFS != REF_ZERO) {
+                for (int m = 0; m < RX; ++m) acc[m] = ADP ? accP[m] : (RT)0;
+                if constexpr (REFS != REF_ZERO && !ADP) {
                     RT xrl[RX];
 #pragma unroll
                     for (int m = 0; m < RX; ++m) xrl[m] = (RT)ref_x(std::integral_constant<int, N - 1>{}, m);
@@ -642,7 +774,7 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
 #pragma unroll
                 for (int m = 0; m < RX; ++m) {
                     const float wN = w_get(N - 1, m);
-                    p[m] = -acc[m] - (RT)(rho * (wN - g_get(N - 1, m)));    // admm.cpp:81-82
+                    p[m] = -acc[m] - (RT)(rho_lin * (wN - g_get(N - 1, m)));    // admm.cpp:81-82
                     v_set(N - 1, m, wN);
                 }
             }
@@ -656,7 +788,7 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
                     float rr = 0.f;
                     if constexpr (REFS != REF_ZERO) rr = -(ref_u(kc, m) * cRD[m]);  // -(Uref .* R)
                     const float zk = zw_get(k, m);
-                    r[m] = (RT)(rr - rho * (zk - y_get(k, m)));             // admm.cpp:77-78
+                    r[m] = (RT)(rr - rho_lin * (zk - y_get(k, m)));         // admm.cpp:77-78
                     z_set(k, m, zk);
                 }
 #pragma unroll
@@ -664,7 +796,7 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
                     float qq = 0.f;
                     if constexpr (REFS != REF_ZERO) qq = -(ref_x(kc, m) * cQD[m]);  // -(Xref .* Q)
                     const float wk = w_get(k, m);
-                    qk[m] = (RT)(qq - rho * (wk - g_get(k, m)));            // admm.cpp:79-80
+                    qk[m] = (RT)(qq - rho_lin * (wk - g_get(k, m)));        // admm.cpp:79-80
                     v_set(k, m, wk);
                 }
                 RT t[RU];
@@ -749,6 +881,20 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
                 }
             }
             const bool need_res = check && (can_converge || it + 1 == last_check_it);
+            rho_lin = rho;
+            if constexpr (ADP) {
+                adapt_now = i > 0 && i % 5 == 0;                                // admm.cpp:147 (loop index, before it is bumped)
+                a_pri = a_axm = a_zm = a_dres = a_pxm = a_atym = a_qm = (RT)0;
+                if constexpr (REFS != REF_ZERO) {                               // the terminal cost with the Pinf of this iteration's linear cost
+                    RT xrl[RX];
+#pragma unroll
+                    for (int m = 0; m < RX; ++m) {
+                        xrl[m] = (RT)ref_x(std::integral_constant<int, N - 1>{}, m);
+                        accP[m] = (RT)0;
+                    }
+                    quad_matvec<G, RX, NXL, RX, NXP>(accP, cPT, xrl);
+                }
+            }
             if constexpr (DUAL_FWD) {
                 if (need_res)
                     forward_sweep(std::true_type{});
@@ -758,6 +904,54 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
                 forward_sweep(std::true_type{});
             }
             it += 1;  // admm.cpp:143
+            if constexpr (ADP) {
+                if (adapt_now) {
+                    // predict_rho (rho_benchmark.cpp:173-195), then the first-order update of Kinf, Pinf (admm.cpp:160-172)
+                    const RT pri = group_max_q<G>(a_pri), axm = group_max_q<G>(a_axm), zm = group_max_q<G>(a_zm),
+                             dres = group_max_q<G>(a_dres), pxm = group_max_q<G>(a_pxm), atym = group_max_q<G>(a_atym),
+                             qm = group_max_q<G>(a_qm);
+                    const RT eps = (RT)1e-10, prin = axm > zm ? axm : zm;
+                    RT duan = pxm > atym ? pxm : atym;
+                    duan = qm > duan ? qm : duan;
+                    const RT ratio = (pri / (prin + eps)) / (dres / (duan + eps) + eps);
+                    RT nrho = (RT)rho_d * (RT)sqrt((double)ratio);
+                    if (P.rho_clip) nrho = nrho < (RT)P.rho_min ? (RT)P.rho_min : (nrho > (RT)P.rho_max ? (RT)P.rho_max : nrho);
+                    const double delta = (double)nrho - rho_d;
+                    const long AB = P.adapt_stride;
+                    double *ad = P.adapt + b;
+                    const double *sK = P.sens, *sP = P.sens + NU * NX;
+#pragma unroll
+                    for (int m = 0; m < RU; ++m) {
+                        const int a = UREP ? m : q * RU + m;
+                        if (a < NU) {
+#pragma unroll
+                            for (int j = 0; j < NX; ++j) {   // row a of Kinf: the solver's state and this lane's register
+                                const double v = ad[(long)(1 + a + j * NU) * AB] + delta * sK[a + j * NU];
+                                if (!UREP || q == 0) ad[(long)(1 + a + j * NU) * AB] = v;
+                                rcoef[S::O_K + m * NXP + j] = (RT)v;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int m = 0; m < RX; ++m) {
+                        const int r = q * RX + m;
+                        if (r < NX) {
+#pragma unroll
+                            for (int a = 0; a < NU; ++a)
+                                rcoef[S::O_KT + m * NUP + a] = (RT)((double)rcoef[S::O_KT + m * NUP + a] + delta * sK[a + r * NU]);
+#pragma unroll
+                            for (int j = 0; j < NX; ++j) {   // column r of Pinf
+                                const double v = ad[(long)(1 + NU * NX + j + r * NX) * AB] + delta * sP[j + r * NX];
+                                ad[(long)(1 + NU * NX + j + r * NX) * AB] = v;
+                                rcoef[S::O_PT + m * NXP + j] = (RT)v;
+                            }
+                        }
+                    }
+                    if (q == 0) ad[0] = (double)nrho;
+                    rho_d = (double)nrho;
+                    rho = (float)nrho;
+                }
+            }
 
             // ================= termination_condition (admm.cpp:89-107) =================
             if (need_res) {

@@ -222,7 +222,8 @@ int tinympc_set_cache_terms(tinympc_solver *s, const double *Kinf, const double 
     v.cache.AmBKt = tmpc::Mat(v.nx, v.nx, AmBKt);
     v.packs_dirty = true;
     v.adapt_dirty = true;  // adaptive rho restarts from the new cache
-    return 0;
+    v.cache_overridden = true;  // AmBKt may no longer equal (A - B Kinf)': the quad kernel's adaptive variant relies on that identity
+    return v.select_kernel();
 }
 
 int tinympc_set_adaptive_rho(tinympc_solver *s, int enable, double rho_min, double rho_max, int enable_clipping) {

@@ -117,8 +117,37 @@ hipError_t launch_quad_os(const AdmmParams &P, hipStream_t stream) {
 // state does not fit the register file (rocket N=50: 7.8 -> 5.9 ms), neutral to slightly negative for the
 // small shapes (cartpole: 0.42 -> 0.45 ms) and for quadrotor (11.6 -> 11.4 / 14.7 ms), so the variants are
 // built per shape (QuadShape::LOOPV).
+// adaptive rho: the ADP kernels (per-lane guard; one-shot or workspace-carrying)
+template <class S, class RT, bool XB, bool OS>
+hipError_t launch_quad_adp(const AdmmParams &P, hipStream_t stream) {
+    const int grid = (P.batch + S::INST_PER_BLOCK - 1) / S::INST_PER_BLOCK;
+    switch (P.ref_mode) {
+        case REF_ZERO:
+            hipLaunchKernelGGL((admm_quad_kernel<S, REF_ZERO, RT, XB, OS, false, true>), dim3(grid), dim3(S::THREADS), 0,
+                               stream, P);
+            break;
+        case REF_SHARED:
+            hipLaunchKernelGGL((admm_quad_kernel<S, REF_SHARED, RT, XB, OS, false, true>), dim3(grid), dim3(S::THREADS), 0,
+                               stream, P);
+            break;
+        default:
+            hipLaunchKernelGGL((admm_quad_kernel<S, REF_PER_INSTANCE, RT, XB, OS, false, true>), dim3(grid),
+                               dim3(S::THREADS), 0, stream, P);
+            break;
+    }
+    return hipGetLastError();
+}
+
 template <class S, class RT, bool XB>
 hipError_t launch_quad_rt(const AdmmParams &P, hipStream_t stream) {
+    if (P.adaptive_rho) {
+        if constexpr (S::ADP_OK) {
+            const bool oneshot = P.cold_start && !P.save_state && P.mpc_steps == 0;
+            return oneshot ? launch_quad_adp<S, RT, XB, true>(P, stream) : launch_quad_adp<S, RT, XB, false>(P, stream);
+        } else {
+            return hipErrorInvalidValue;   // (the solver never selects such an entry for an adaptive solve)
+        }
+    }
     if constexpr (S::LOOPV != 0) {
         const bool oneshot = P.cold_start && !P.save_state && P.mpc_steps == 0;
         const bool uniform = oneshot && !(P.abs_pri_tol > 0.f && P.abs_dua_tol > 0.f);  // nobody can converge
@@ -156,7 +185,7 @@ hipError_t launch_quad(const AdmmParams &P, int precision, bool state_bounds_act
     const KernelEntry *quad_entry_##NX##_##NU##_##NN##_g##GG() {                               \
         using S = QuadShape<NX, NU, NN, GG, ##__VA_ARGS__>;                                    \
         static const KernelEntry e = {NX, NU, NN, GG, "quad<" #NX "," #NU "," #NN ",g" #GG ">", \
-                                      &build_quad_coef<S>, &build_quad_bounds<S>, &launch_quad<S>}; \
+                                      &build_quad_coef<S>, &build_quad_bounds<S>, &launch_quad<S>, S::ADP_OK}; \
         return &e;                                                                             \
     }
 

@@ -21,6 +21,7 @@ struct KernelEntry {
     void (*build_coef)(const Solver &, std::vector<unsigned char> &);  // typed by Solver::precision
     void (*build_bounds)(const Solver &, std::vector<float> &);
     hipError_t (*launch)(const AdmmParams &, int precision, bool state_bounds_active, hipStream_t);
+    bool adp = false;  // the entry also carries the adaptive-rho kernels (QuadShape::ADP_OK)
 };
 // group < 0: the shape's default group size; otherwise that exact variant (nullptr if not built)
 const KernelEntry *find_quad_kernel(int nx, int nu, int N, int group = -1);
@@ -119,6 +120,7 @@ struct Solver {
     bool refs_device_owned = false;  // caller writes d_xref/d_uref itself (tinympc_set_ref_mode)
     int ref_mode = REF_ZERO;
     bool warm_start = true;
+    bool cache_overridden = false;  // set_cache_terms replaced the host Riccati's terms
     bool packs_dirty = true;
     bool state_bounds_active = false;  // any finite (|b| < 1e17) enabled state bound
     const KernelEntry *ke = nullptr;  // specialised quad kernel, or

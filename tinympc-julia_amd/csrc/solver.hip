@@ -181,6 +181,7 @@ int Solver::copy_family_state(const Solver &o) {
     cache = o.cache;
     sens = o.sens, sens_set = o.sens_set, sens_dirty = true, adapt_dirty = true;
     warm_start = o.warm_start;
+    cache_overridden = o.cache_overridden;
     precision = o.precision;
     chunk_iters = o.chunk_iters;
     packs_dirty = true;
@@ -316,7 +317,12 @@ int Solver::select_kernel(bool rollout) {
             set_error("adaptive_rho is not available on a per-instance-family solver");
             return -1;
         }
-        k = nullptr;  // adaptive rho: the stream kernel's ADP variant (box sets), else the generic kernel
+        // adaptive rho: the quad kernel's ADP variant where the shape has one (4 lanes per instance, coefficient rows in
+        // registers: the cartpole shapes), else the stream kernel's (box sets), else the generic kernel
+        const KernelEntry *ka = std::getenv("TINYMPC_HIP_NO_QUAD_ADP") ? nullptr : find_quad_kernel(nx, nu, N, 4);
+        const bool quad_adp_ok = ka && ka->adp && !has_fdyn && !cones_active() && !lin_active() && chunk_iters == 0 &&
+                                 !rollout && !cache_overridden;
+        k = quad_adp_ok ? ka : nullptr;
     }
     if (std::getenv("TINYMPC_HIP_NO_QUAD")) k = nullptr;    // tuning aid: time the fallback kernels on any shape
     // plain solves with fp64 recurrences: the matrix-core kernel of the shape (the fused closed loop stays on the quad
@@ -324,8 +330,8 @@ int Solver::select_kernel(bool rollout) {
     const bool mfma_ws_ok = !std::getenv("TINYMPC_HIP_MFMA_ONESHOT_ONLY");
     if (rollout && (!mfma_ws_ok || !warm_start)) rollout_quad = true;  // else: rollout_steps() on the matrix-core kernel
     else rollout_quad = false;
-    if (k && !(rollout && rollout_quad) && (mfma_ws_ok || (!warm_start && chunk_iters == 0)) && precision == 0 && !genv &&
-        !std::getenv("TINYMPC_HIP_NO_MFMA"))
+    if (k && !st.adaptive_rho && !(rollout && rollout_quad) && (mfma_ws_ok || (!warm_start && chunk_iters == 0)) &&
+        precision == 0 && !genv && !std::getenv("TINYMPC_HIP_NO_MFMA"))
         if (const KernelEntry *m = find_mfma_kernel(nx, nu, N)) k = m;
     if (!k && (nx > GEN_MAX_NX || nu > GEN_MAX_NU)) {
         set_error("problem shape exceeds the generic kernel limits (nx <= 64, nu <= 32)");
@@ -686,7 +692,7 @@ int Solver::set_linear(const double *Ax, int mx, const double *bx, const double 
 
 // Scratch and cone / linear warm-start buffers of the stream and generic kernels, sized for the current batch / options.
 int Solver::ensure_extension_buffers() {
-    if (ke) return 0;
+    if (ke && !st.adaptive_rho) return 0;
     HIP_TRY(hipSetDevice(device));
     const size_t Bn = (size_t)batch, EX = (size_t)ex(), EU = (size_t)eu();
     if (st.adaptive_rho) {
@@ -730,6 +736,7 @@ int Solver::ensure_extension_buffers() {
             }
         }
     }
+    if (ke) return 0;  // (a quad kernel running an adaptive solve: the adaptive state above is all it needs)
     const size_t sets = (size_t)constraint_sets();
     size_t need = Bn * ((2 + 3 * sets) * EX + (3 + 3 * sets) * EU);  // generic kernel: admm_generic.hip.h
     if (se) need = std::max(need, Bn * se->scratch_floats(N, (int)sets));
