@@ -73,16 +73,16 @@ SETTINGS = {
 
 
 def _kernel_for(N, lds_only=False):
-    return "mfmar<6,3,50>" if N == 50 and not lds_only else "mfmac<6,3>"
+    return f"mfmar<6,3,{N}>" if N in (10, 50) and not lds_only else "mfmac<6,3>"
 
 
-@pytest.mark.parametrize("N", [10, 50, -50, 23, 2])
+@pytest.mark.parametrize("N", [10, -10, 50, -50, 23, 2])
 @pytest.mark.parametrize("mode", ["fdyn+cones", "fdyn", "cones"])
 @pytest.mark.parametrize("setting", list(SETTINGS))
 def test_mfmac_rocket_vs_oracle(hip_lib, oracle_built, monkeypatch, N, mode, setting):
     if N in (23, 2, -50) and (mode != "fdyn+cones" or setting not in ("fixed60", "tol")):
         pytest.skip("the odd horizons (and the LDS kernel at N = 50) run the two main settings only")
-    lds_only = N < 0                                        # -50: N = 50 on the run-time-horizon kernel
+    lds_only = N < 0                                        # -10, -50: the compiled horizons on the run-time-horizon kernel
     N = abs(N)
     if lds_only:
         monkeypatch.setenv("TINYMPC_HIP_NO_MFMAR", "1")

@@ -36,6 +36,8 @@ struct RegShape {
 
 template <int NX, int NU, int N, int REFS, int CX, int CU, bool BV>
 __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) {
+    // (three wavefronts per SIMD also for short horizons, whose 2 N dual registers would allow more: at N = 10 four and six
+    // per SIMD measured slower, 1.22 / 1.59 ms against 1.12)
     using S = ConeShape<NX, NU>;
     constexpr int XS = S::XS, NROW = S::NROW, PLEN = RegShape<NX, NU, N>::PLEN;
     constexpr bool EXT = CX + CU > 0;

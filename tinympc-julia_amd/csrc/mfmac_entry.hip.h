@@ -185,7 +185,7 @@ hipError_t launch_mfmac(const AdmmParams &P_, bool ext, size_t lds, hipStream_t 
 
 #define TMPC_DEFINE_MFMAC_ENTRY(NX, NU)                                                                              \
     const ConeEntry *mfmac_entry_##NX##_##NU() {                                                                    \
-        static const ConeEntry e = {NX, NU, 0, nullptr, "mfmac<" #NX "," #NU ">", &build_mfmac_coef<NX, NU>,                    \
+        static const ConeEntry e = {NX, NU, 0, nullptr, false, "mfmac<" #NX "," #NU ">", &build_mfmac_coef<NX, NU>,                    \
                                     &build_mfmac_bounds<NX, NU>, &mfmac_lds_bytes<NX, NU>, &mfmac_scratch_floats<NX, NU>, \
                                     &mfmac_bounds_vary, &launch_mfmac<NX, NU>};                                     \
         return &e;                                                                                                  \

@@ -63,9 +63,9 @@ hipError_t launch_mfmar(const AdmmParams &P_, bool ext, size_t lds, hipStream_t 
     return hipGetLastError();
 }
 
-#define TMPC_DEFINE_MFMAR_ENTRY(NX, NU, N)                                                                           \
+#define TMPC_DEFINE_MFMAR_ENTRY(NX, NU, N, PLAIN)                                                                         \
     const ConeEntry *mfmar_entry_##NX##_##NU##_##N() {                                                              \
-        static const ConeEntry e = {NX, NU, N, &mfmar_supports, "mfmar<" #NX "," #NU "," #N ">",                    \
+        static const ConeEntry e = {NX, NU, N, &mfmar_supports, PLAIN, "mfmar<" #NX "," #NU "," #N ">",                    \
                                     &build_mfmac_coef<NX, NU>, &build_mfmac_bounds<NX, NU>, &mfmar_lds_bytes<NX, NU, N>, \
                                     &mfmac_scratch_floats<NX, NU>, &mfmac_bounds_vary, &launch_mfmar<NX, NU, N>};   \
         return &e;                                                                                                  \

@@ -47,6 +47,7 @@ struct ConeEntry {
     int nx, nu;
     int N;                                      // compile-time horizon of the entry, 0: any (run-time horizon)
     bool (*supports)(const Solver &);           // further conditions of the entry (null: none)
+    bool plain;                                 // box-only one-shot solves of the shape run here too (measured faster than the quad kernel)
     const char *name;
     void (*build_coef)(const Solver &, std::vector<unsigned char> &);
     void (*build_bounds)(const Solver &, std::vector<float> &);

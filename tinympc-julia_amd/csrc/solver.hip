@@ -358,7 +358,7 @@ int Solver::select_kernel(bool rollout) {
     // 5.5 ms on the quad kernel, which spills at this horizon); TINYMPC_HIP_MFMAC_ALL extends that to the LDS kernel
     const ConeEntry *cn = std::getenv("TINYMPC_HIP_NO_MFMAR") ? nullptr : find_cone_kernel(nx, nu, N);
     if (cn && cn->supports && !cn->supports(*this)) cn = nullptr;
-    const bool plain_ok = std::getenv("TINYMPC_HIP_MFMAC_ALL") != nullptr || cn != nullptr;
+    const bool plain_ok = std::getenv("TINYMPC_HIP_MFMAC_ALL") != nullptr || (cn != nullptr && cn->plain);
     if ((s2 || (k && plain_ok)) && !warm_start && chunk_iters == 0 && !rollout && precision == 0 && !hetero && !lin_active() &&
         !st.adaptive_rho && (has_fdyn || cones_active() || plain_ok) && xref_kind < 2 && uref_kind < 2 &&
         !(refs_device_owned && ref_mode == REF_PER_INSTANCE) && !std::getenv("TINYMPC_HIP_NO_MFMAC") && !genv &&
