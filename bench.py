@@ -295,17 +295,23 @@ def cpu_baseline(prob, x0, refs, iters, seconds):
 # ----------------------------------------------------------------------------------------------------------------------
 # extra configurations (one GPU): configs 3, 4 and one shard of config 5
 # ----------------------------------------------------------------------------------------------------------------------
-def time_config(t, torch, dev, stream, name, batch, seed, iters=100, tol=0.0, check=1, steps=5, warmup=2, compaction=0):
+def time_config(t, torch, dev, stream, name, batch, seed, iters=100, tol=0.0, check=1, steps=5, warmup=2, compaction=0,
+                adaptive=False):
     import numpy as np
     prob, x0, refs, label = make_workload(t, name, batch, seed)
     bs = build_solver(t, name, prob, x0, refs, dev.index, iters, tol, check, 0, compaction)
+    if adaptive:
+        bs.set_adaptive_rho(True)
+        label += ", adaptive rho (every 5th iteration)"
     try:
-        for _ in range(warmup):
+        def one():    # (adaptive: the adapted rho / Kinf / Pinf persist from solve to solve, as in the reference)
             bs.solve_async(stream.cuda_stream)
+        for _ in range(warmup):
+            one()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for _ in range(steps):
-            bs.solve_async(stream.cuda_stream)
+            one()
         torch.cuda.synchronize(dev)
         ms = 1e3 * (time.perf_counter() - t0) / steps
         st = bs.get_status()
@@ -557,6 +563,8 @@ def main():
         ex["quadrotor_131072_tol"] = time_config(t, torch, dev, stream, "quadrotor", 131072, 3, tol=1e-3, check=10)
         ex["quadrotor_131072_tol_compaction"] = time_config(t, torch, dev, stream, "quadrotor", 131072, 3, tol=1e-3,
                                                             check=10, compaction=20)
+        # the headline workload with the reference's adaptive rho switched on
+        ex["cartpole_65536_adaptive_rho"] = time_config(t, torch, dev, stream, "cartpole", 65536, 0, adaptive=True)
         out["configs"] = ex
     if rank == 0:
         print(json.dumps(out), flush=True)
