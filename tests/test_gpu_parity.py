@@ -1158,6 +1158,49 @@ def test_config5_shard_tolerance_terminated(hip_lib, oracle_built):
     bs.close()
 
 
+@pytest.mark.parametrize("case", ["zero_refs_ct10", "shared_refs_ct5", "state_bounds_ct20", "ragged_not_refilled"])
+def test_mfma_refill_is_the_same_solve(hip_lib, monkeypatch, case):
+    """the matrix-core kernel's refill variant (tolerance-terminated one-shot solves of more instances than the chip holds:
+    a finished instance's slot takes the next unstarted instance) against the plain launch (TINYMPC_HIP_NO_REFILL): every
+    instance runs the same iteration sequence wherever and whenever it runs, so states, controls, iteration counts,
+    solved flags, residuals and the launch status are bit for bit the same"""
+    N = 30
+    prob = t.problems.quadrotor(N, u_bound=0.5)
+    B = 40960 if case != "ragged_not_refilled" else 40000   # (a batch that is no multiple of 64 stays on the plain launch: same answers trivially)
+    rng = np.random.default_rng(5)
+    x0 = t.problems.quadrotor_x0(B, seed=9)
+    x0[:, rng.integers(0, B, B // 3)] *= 0.1               # a third of the instances are easy: slots turn over at different rates
+    ct = {"zero_refs_ct10": 10, "shared_refs_ct5": 5, "state_bounds_ct20": 20, "ragged_not_refilled": 10}[case]
+    kw = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=ct)
+    outs = []
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("TINYMPC_HIP_NO_REFILL", env)
+        bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+        bs.update_settings(**kw)
+        if case == "state_bounds_ct20":
+            xmin, xmax = prob.x_min.copy(), prob.x_max.copy()
+            xmin[:3], xmax[:3] = -0.25, 0.25                  # finite state bounds: the state dual is carried (XB)
+            bs.set_bound_constraints(xmin, xmax, prob.u_min, prob.u_max)
+        else:
+            bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        if case == "shared_refs_ct5":
+            bs.set_x_ref(0.05 * np.random.default_rng(77).standard_normal((12, N)))
+            bs.set_u_ref(np.zeros((4, N - 1)))
+        bs.set_warm_start(False)
+        bs.set_x0(x0)
+        status = bs.solve()
+        assert bs.kernel_name == "mfma<12,4,30>"
+        outs.append((status, bs.get_solution(), bs.get_status(), 0.0))
+        bs.close()
+    (s1, sol1, st1, _), (s2, sol2, st2, _) = outs
+    assert s1 == s2
+    for k in ("iter", "solved", "residuals"):
+        assert np.array_equal(st1[k], st2[k]), k
+    assert np.array_equal(sol1["states"], sol2["states"]) and np.array_equal(sol1["controls"], sol2["controls"])
+    assert len(np.unique(st1["iter"])) > 3 and np.all(st1["iter"] % ct == 0)
+
+
 @pytest.mark.parametrize("family,kernel", [("cartpole", "quad<4,1,20"), ("quadrotor", "mfma<12,4,30"),
                                            ("quadrotor_quad", "quad<12,4,30"), ("cartpole19", "stream4<4,1>")])
 def test_chunked_solve_with_compaction_is_the_same_solve(hip_lib, oracle_built, monkeypatch, family, kernel):

@@ -98,8 +98,16 @@ constexpr int mfma_blocks_per_cu() {
     return (TMPC_MFMA_TWO_WAVES && VXof<NX>() * N + 3 * (N - 1) <= TMPC_MFMA_TWO_WAVES_MAX_STATE && !XB && !WS && REFS != REF_PER_INSTANCE) ? 2 : 1;
 }
 
-template <int NX, int NU, int N, int REFS, bool XB, bool WS = false>
+// RF ("refill"): tolerance-terminated one-shot solves of a batch larger than the chip holds at once.  The launch has as
+// many workgroups as are resident together; an instance slot (16 per wavefront) whose instance has finished — converged
+// at a check, or out of iterations — stores its solution and takes the next unstarted instance off a global counter,
+// cold: the iteration sequence of every instance is exactly the plain kernel's, but no slot idles behind the slowest
+// instance of its wavefront (config 5's shard: mean 46 of 100 iterations, yet nearly every wavefront holds an instance
+// that runs to max_iter).  Needs max_iter % check_termination == 0, so that a slot is only ever refilled on a check
+// iteration and every instance's own check schedule coincides with the launch's.
+template <int NX, int NU, int N, int REFS, bool XB, bool WS = false, bool RF = false>
 __global__ __launch_bounds__(256, (mfma_blocks_per_cu<NX, NU, N, REFS, XB, WS>())) void admm_mfma_kernel(const AdmmParams P) {
+    static_assert(!RF || (!WS && REFS != REF_PER_INSTANCE), "refill: one-shot solves, shared or zero references");
     // XB = false with WS: the caller guarantees that the workspace's state dual is zero and stays zero (no finite
     // state bound now, none since the last reset) — g is then neither loaded, carried nor written.
     using S = MfmaShape<NX, NU, N>;
@@ -116,8 +124,11 @@ __global__ __launch_bounds__(256, (mfma_blocks_per_cu<NX, NU, N, REFS, XB, WS>()
     const int l = tid & 63, g = l >> 4, j = l & 15;
     const int inst = (tid >> 6) * 16 + j;  // instance of the workgroup
     const long slot = (long)blockIdx.x * 64 + inst;
-    const bool active = slot < P.batch;
-    const long b = (active && P.idx) ? P.idx[slot] : slot;
+    bool active = slot < P.batch;                                // (RF: the slot still has an instance)
+    long b = (active && P.idx) ? P.idx[slot] : slot;             // (RF: the instance the slot is working on)
+    int it0 = 0;                                                 // RF: the launch's iteration count when the slot's instance started
+    float fm0 = 0.f, fm1 = 0.f, fm2 = 0.f, fm3 = 0.f;            // RF: residual maxima / unsolved count over the slot's finished instances
+    int f_unsolved = 0;
     constexpr long EX = (long)NX * N, EU = (long)NU * (N - 1);
     const bool uok = g < NU;
     bool xok[VX];
@@ -210,7 +221,7 @@ __global__ __launch_bounds__(256, (mfma_blocks_per_cu<NX, NU, N, REFS, XB, WS>()
             for (int k = 0; k < N - 1; ++k) P.uout[b * EU + k * NU + g] = szw[k];
         }
         if (g == 0) {
-            P.iter[b] = P.iter_offset + it;
+            P.iter[b] = P.iter_offset + it - it0;
             P.solved[b] = conv;
             P.res[b * 4 + 0] = res0;
             P.res[b * 4 + 1] = res1;
@@ -241,8 +252,8 @@ __global__ __launch_bounds__(256, (mfma_blocks_per_cu<NX, NU, N, REFS, XB, WS>()
         }
     };
 
-    for (int i = 0; i < P.max_iter; ++i) {
-        const bool check = ct > 0 && (i + 1) % ct == 0;                       // every lane's it == i here
+    for (int i = 0; RF || i < P.max_iter; ++i) {
+        const bool check = ct > 0 && (i + 1) % ct == 0;                       // every lane's it == i here (RF: it - it0 is a multiple of ct behind)
         const bool need_res = check && (can_converge || i + 1 == last_check_it);
         // ================= fused forward sweep (admm.cpp:25-69, :93-96) =================
         float pri_x = 0.f, dua_x = 0.f, pri_u = 0.f, dua_u = 0.f;
@@ -332,14 +343,53 @@ __global__ __launch_bounds__(256, (mfma_blocks_per_cu<NX, NU, N, REFS, XB, WS>()
                 }
             }
         }
-        if (__builtin_amdgcn_ballot_w64(newly)) {
-            if (newly && active) {
-                store_solution();
-                if constexpr (WS)
-                    if (P.save_state) store_workspace(true);
+        bool fresh = false;                                                   // RF: the slot took a new instance in this iteration
+        if constexpr (RF) {
+            const bool fin = active && check && (newly || it - it0 >= P.max_iter);
+            if (__builtin_amdgcn_ballot_w64(fin)) {
+                long nb = -1;
+                if (fin) {
+                    store_solution();
+                    fm0 = fmaxf(fm0, res0), fm1 = fmaxf(fm1, res1), fm2 = fmaxf(fm2, res2), fm3 = fmaxf(fm3, res3);
+                    if (g == 0) {
+                        f_unsolved += conv ? 0 : 1;
+                        nb = 64L * gridDim.x + (long)atomicAdd(&P.gacc[6], 1u);   // the next unstarted instance
+                    }
+                }
+                nb = __shfl(nb, j, 64);                                        // lane j (g = 0) holds the instance's draw
+                if (fin) {
+                    if (nb < (long)P.batch) {
+                        fresh = true;
+                        b = nb, it0 = it, conv = 0;
+                        res0 = res1 = res2 = res3 = 0.f;
+#pragma unroll
+                        for (int v = 0; v < VX; ++v) x0[v] = xok[v] ? (double)P.x0[b * NX + 4 * v + g] : 0.0;
+#pragma unroll
+                        for (int k = 0; k < N; ++k)
+#pragma unroll
+                            for (int v = 0; v < VX; ++v) {
+                                if constexpr (XB) sg[k][v] = 0.f;
+                                sw[k][v] = 0.f;
+                            }
+#pragma unroll
+                        for (int k = 0; k < N - 1; ++k) sy[k] = szw[k] = sd[k] = 0.f;
+                    } else {
+                        active = false;
+                        conv = 1;
+                    }
+                }
             }
+            if (!__builtin_amdgcn_ballot_w64(active)) break;
+        } else {
+            if (__builtin_amdgcn_ballot_w64(newly)) {
+                if (newly && active) {
+                    store_solution();
+                    if constexpr (WS)
+                        if (P.save_state) store_workspace(true);
+                }
+            }
+            if (!__builtin_amdgcn_ballot_w64(active && !conv)) break;
         }
-        if (!__builtin_amdgcn_ballot_w64(active && !conv)) break;
         // ================= fused backward sweep (admm.cpp:75-83, :13-20) =================
         double p[VX];
         {
@@ -395,14 +445,35 @@ __global__ __launch_bounds__(256, (mfma_blocks_per_cu<NX, NU, N, REFS, XB, WS>()
             dq = mf_mma(cf[S::O_QI], t_pend, dq);
             sd[0] = (float)dq[3];
         }
+        if constexpr (RF) {
+            if (fresh) {   // a fresh instance has not run a forward sweep yet: its feed-forward term stays the cold start's zero
+#pragma unroll
+                for (int k = 0; k < N - 1; ++k) sd[k] = 0.f;
+            }
+        }
     }
 
-    if (active && !conv) {
-        store_solution();
-        if constexpr (WS)
-            if (P.save_state) store_workspace(false);
+    if constexpr (!RF) {
+        if (active && !conv) {
+            store_solution();
+            if constexpr (WS)
+                if (P.save_state) store_workspace(false);
+        }
     }
-    {
+    if constexpr (RF) {
+        float m0 = fm0, m1 = fm1, m2 = fm2, m3 = fm3;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            m0 = fmaxf(m0, __shfl_xor(m0, off, 64));
+            m1 = fmaxf(m1, __shfl_xor(m1, off, 64));
+            m2 = fmaxf(m2, __shfl_xor(m2, off, 64));
+            m3 = fmaxf(m3, __shfl_xor(m3, off, 64));
+        }
+        int un = f_unsolved;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) un += __shfl_xor(un, off, 64);
+        fold_status(P, m0, m1, m2, m3, un, tid);
+    } else {
         float m0 = active ? res0 : 0.f, m1 = active ? res1 : 0.f, m2 = active ? res2 : 0.f, m3 = active ? res3 : 0.f;
 #pragma unroll
         for (int off = 1; off < 16; off <<= 1) {  // over the 16 instances of the wavefront (lanes of a group)

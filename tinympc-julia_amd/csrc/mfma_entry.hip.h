@@ -1,5 +1,6 @@
 // Host-side pack builders + launcher for one (nx, nu, N) instantiation of the matrix-core kernel (admm_mfma.hip.h).
 #pragma once
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -83,6 +84,36 @@ hipError_t launch_mfma_xb(const AdmmParams &P, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// Tolerance-terminated one-shot solves of more instances than the chip holds at once: the refill variant (admm_mfma.hip.h,
+// RF) on as many workgroups as are resident together.  Returns hipErrorNotReady when the launch is not such a case.
+template <int NX, int NU, int N, bool XB>
+hipError_t launch_mfma_refill(const AdmmParams &P, hipStream_t stream) {
+    const int tiles = (P.batch + 63) / 64, ct = P.check_termination;
+    if (!(P.abs_pri_tol > 0.f && P.abs_dua_tol > 0.f) || ct <= 0 || P.max_iter % ct != 0 || P.idx != nullptr ||
+        P.ref_mode == REF_PER_INSTANCE || P.x0d != nullptr || P.batch % 64 != 0 || std::getenv("TINYMPC_HIP_NO_REFILL"))
+        return hipErrorNotReady;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+#define TMPC_MFMA_RF(REFS_)                                                                                          \
+    do {                                                                                                             \
+        int per_cu = 0;                                                                                              \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, admm_mfma_kernel<NX, NU, N, REFS_, XB, false, true>, \
+                                                         256, 0) != hipSuccess || per_cu <= 0)                       \
+            per_cu = 1;                                                                                              \
+        if (tiles < 2 * per_cu * cus) return hipErrorNotReady;   /* fewer than two rounds: nothing to refill */       \
+        hipLaunchKernelGGL((admm_mfma_kernel<NX, NU, N, REFS_, XB, false, true>), dim3(per_cu * cus), dim3(256), 0,   \
+                           stream, P);                                                                               \
+    } while (0)
+    if (P.ref_mode == REF_ZERO) TMPC_MFMA_RF(REF_ZERO); else TMPC_MFMA_RF(REF_SHARED);
+#undef TMPC_MFMA_RF
+    return hipGetLastError();
+}
+
 // precision is ignored: the matrix cores run the recurrences in fp64 (the kernel is only selected for precision 0).
 // A launch that reads or keeps the workspace takes the WS variant (old slack parked in LDS).  `state_bounds_active`
 // here also covers "the workspace's state dual may be non-zero" (Solver::launch_pass) — only then is g carried.
@@ -91,6 +122,9 @@ hipError_t launch_mfma(const AdmmParams &P, int /*precision*/, bool state_bounds
     if (!P.cold_start || P.save_state)
         return state_bounds_active ? launch_mfma_xb<NX, NU, N, true, true>(P, stream)
                                    : launch_mfma_xb<NX, NU, N, false, true>(P, stream);
+    const hipError_t rf = state_bounds_active ? launch_mfma_refill<NX, NU, N, true>(P, stream)
+                                              : launch_mfma_refill<NX, NU, N, false>(P, stream);
+    if (rf != hipErrorNotReady) return rf;
     return state_bounds_active ? launch_mfma_xb<NX, NU, N, true, false>(P, stream)
                                : launch_mfma_xb<NX, NU, N, false, false>(P, stream);
 }
