@@ -145,3 +145,64 @@ def test_global_solver_set_gpus(hip_lib, monkeypatch):
         t.set_gpus(s, 9)                                         # more devices than the box has
     assert hip_lib.get_gpus() in (0, 1)
     t.cleanup()
+
+
+@pytest.mark.gpu
+def test_sharded_persistent_and_refill_kernels_share_a_device(hip_lib):
+    """two shards on ONE device launch their kernels concurrently on their own streams: the persistent on-chip kernel
+    (rocket, cones + affine term set through each shard's own handle, tinympc_sharded_shard) and the matrix-core kernel's
+    refill launch (tolerance-terminated quadrotor, enough instances per shard for two rounds) each size their grid for the
+    whole chip and take work off their own counters — results must equal the single-device solver's, bit for bit"""
+    import ctypes
+    lib = hip_lib
+    # (a) rocket N = 50, cones + fdyn, one-shot: mfmar on both shards
+    N, B = 50, 96
+    prob = t.problems.rocket(N)
+    x0 = t.problems.rocket_x0(B, seed=4)
+    xr, ur = t.problems.rocket_refs(N)
+    kw = dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=60, check_termination=1)
+    one = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B, device=0)
+    one.update_settings(**kw)
+    one.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    one.set_fdyn(prob.fdyn)
+    one.set_cone_constraints([0], [3], [0.25], [0], [3], [0.5])
+    one.set_warm_start(False); one.set_x_ref(xr); one.set_u_ref(ur); one.set_x0(x0)
+    one.solve()
+    ref = one.get_solution()
+    assert one.kernel_name == "mfmar<6,3,50>"
+    one.close()
+    sh = t.ShardedBatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B, devices=[0, 0])
+    _configure(sh, prob, x0, 0.0, 60)
+    fd = np.ascontiguousarray(prob.fdyn, dtype=np.float64)
+    ia = lambda v: np.ascontiguousarray(v, dtype=np.int32).ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+    da = lambda v: np.ascontiguousarray(v, dtype=np.float64).ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    for i in range(sh.n_shards):
+        loc = sh.shard(i)[3]
+        assert lib.tinympc_set_fdyn(loc, fd.ctypes.data_as(ctypes.POINTER(ctypes.c_double))) == 0
+        assert lib.tinympc_set_cone_constraints(loc, ia([0]), ia([3]), da([0.25]), 1, ia([0]), ia([3]), da([0.5]), 1) == 0
+    sh.set_warm_start(False); sh.set_x_ref(xr); sh.set_u_ref(ur)
+    sh.solve()
+    assert sh.kernel_names() == ["mfmar<6,3,50>"] * 2
+    got = sh.get_solution()
+    assert np.array_equal(got["states"], ref["states"]) and np.array_equal(got["controls"], ref["controls"])
+    sh.close()
+    # (b) quadrotor, tolerance-terminated, 2 x 40 960 instances: the refill launch on both shards at once
+    prob = t.problems.quadrotor(30, u_bound=0.5)
+    B = 81920
+    x0 = t.problems.quadrotor_x0(B, seed=13)
+    x0[:, ::3] *= 0.1
+    outs = []
+    for mk in (lambda: t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B, device=0),
+               lambda: t.ShardedBatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B, devices=[0, 0])):
+        bs = mk()
+        bs.update_settings(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=10)
+        bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        bs.set_warm_start(False)
+        bs.set_x0(x0)
+        st = bs.solve()
+        outs.append((st, bs.get_solution(), bs.get_status()))
+        bs.close()
+    assert outs[0][0] == outs[1][0]
+    assert np.array_equal(outs[0][2]["iter"], outs[1][2]["iter"]) and len(np.unique(outs[0][2]["iter"])) > 3
+    assert np.array_equal(outs[0][1]["controls"], outs[1][1]["controls"])
+    assert np.array_equal(outs[0][1]["states"], outs[1][1]["states"])
