@@ -301,6 +301,11 @@ int tinympc_sharded_get_workspace(tinympc_sharded *s, double *d, double *y, doub
  * setup() and nothing else.  Inputs and the workspace are reset, as by set_batch_size. */
 int set_gpus(int n_gpus);
 int get_gpus(void);
+/* warm_start = 0: every solve_mpc of the global solver starts from the zero workspace and keeps none (one-shot solves:
+ * the regime of the benchmark configs, served by the on-chip kernels); 1 (default) = the reference's semantics, the
+ * workspace persists between solves (admm.cpp:112-115).  The kernel the last solve ran on, for logs. */
+int set_warm_start(int warm_start);
+const char *get_kernel_name(void);
 
 #ifdef __cplusplus
 }

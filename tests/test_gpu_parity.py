@@ -826,6 +826,41 @@ def test_rocket_fdyn_cones_vs_oracle(hip_lib, oracle_built, monkeypatch, N, fdyn
     bs.close()
 
 
+def test_config4_one_shot_through_dropin_api(hip_lib, oracle_built):
+    """config 4 on the process-global entry points a Julia host binds: setup(...; batch) -> set_warm_start(false) ->
+    set_cone_constraints / bounds / references -> solve: runs on the on-chip kernel and matches the oracle; with the
+    reference's default (workspace persists) the same calls run on the stream kernel"""
+    N, B = 50, 40
+    prob = t.problems.rocket(N)
+    x0 = t.problems.rocket_x0(B, seed=3)
+    xr, ur = t.problems.rocket_refs(N)
+    kw = dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=80, check_termination=1)
+    names = []
+    for one_shot in (True, False):
+        s = t.TinyMPCSolver()
+        t.setup(s, prob.A, prob.B, prob.fdyn, prob.Q, prob.R, prob.rho, 6, 3, N, batch=B, max_iter=80, abs_pri_tol=0.0,
+                abs_dua_tol=0.0)
+        if one_shot:
+            t.set_warm_start(s, False)
+        t.set_bound_constraints(s, prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        t.set_cone_constraints(s, [0], [3], [0.25], [0], [3], [0.5])
+        t.set_x_ref(s, xr)
+        t.set_u_ref(s, ur)
+        t.set_x0(s, x0)
+        assert t.solve(s) == 1
+        names.append(t.kernel_name())
+        sol = t.get_solution(s)
+        if one_shot:
+            ref = _oracle_loop(_rocket_oracle(oracle_built, prob, xr, ur, True, True, kw), x0)
+            assert nrel_batch(sol["states"], ref["x"]).max() <= FP32_TOL
+            assert nrel_batch(sol["controls"], ref["u"]).max() <= FP32_TOL
+            first = sol
+        else:
+            assert nrel_batch(sol["controls"], first["controls"]).max() <= 3e-6   # same solve, other kernel
+        t.cleanup()
+    assert names == ["mfmar<6,3,50>", "stream4<6,3>"]
+
+
 def test_rocket_example_through_dropin_api(hip_lib, oracle_built):
     """examples/rocket_landing_constraints.jl:59-69 call sequence on the process-global entry points:
     setup with fdyn, set_bound_constraints, set_cone_constraints (inputs first), solve."""

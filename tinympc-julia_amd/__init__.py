@@ -84,6 +84,8 @@ from .tinympc import (  # noqa: E402,F401
     BatchSolver,
     ShardedBatchSolver,
     set_gpus,
+    set_warm_start,
+    kernel_name,
     shard_range,
     TinyMPCError,
     TinyMPCSolver,

@@ -527,6 +527,18 @@ int set_gpus(int n_gpus) {
 }
 int get_gpus(void) { return g_sharded ? tinympc_sharded_n_shards(g_sharded.get()) : (g_solver ? 1 : 0); }
 
+// warm_start = 0: every solve() of the global solver starts from the zero workspace and keeps none ("one-shot": the
+// benchmark configs' regime, and what lets the on-chip kernels run); 1 (default): the reference's semantics, the
+// workspace persists between solves (admm.cpp:112-115 resets only the counters)
+int set_warm_start(int warm_start) {
+    if (need_global("set_warm_start")) return -1;
+    return each_global([&](tinympc_solver *h) { return tinympc_set_warm_start(h, warm_start); });
+}
+const char *get_kernel_name(void) {
+    if (!g_solver) return "";
+    return (g_sharded ? global_shard(0)->s : g_solver->s).kernel_name.c_str();
+}
+
 int set_x0(double *x0_data, int x0_rows, int x0_cols, int verbose) {
     (void)verbose;
     if (need_global("set_x0")) return -1;

@@ -21,7 +21,7 @@ module TinyMPC
 
 export TinyMPCSolver, setup, solve, get_solution, get_status, set_x0, set_x_ref, set_u_ref,
        set_bound_constraints, set_linear_constraints, set_equality_constraints, set_cone_constraints, update_settings,
-       set_cache_terms, set_batch_size, set_gpus, get_gpus, reset_workspace, print_problem_data,
+       set_cache_terms, set_batch_size, set_gpus, get_gpus, set_warm_start, kernel_name, reset_workspace, print_problem_data,
        compute_sensitivity_autograd, set_sensitivity, get_adaptive_rho
 
 using LinearAlgebra, Libdl, Printf
@@ -105,6 +105,15 @@ function set_gpus(solver::TinyMPCSolver, n::Integer)
     return 0
 end
 get_gpus() = Int(ccall((:get_gpus, _lib_path()), Int32, ()))
+
+# on = false: every solve() starts from the zero workspace and keeps none (one-shot solves: the benchmark regime, served by
+# the on-chip kernels); true (default): the reference's semantics, the workspace persists between solves
+function set_warm_start(solver::TinyMPCSolver, on::Bool)
+    _need(solver)
+    _ok(ccall((:set_warm_start, _lib_path()), Int32, (Int32,), on ? 1 : 0), "Failed to set warm start")
+    return 0
+end
+kernel_name() = unsafe_string(ccall((:get_kernel_name, _lib_path()), Cstring, ()))
 
 # x0: Vector (length nx, broadcast to the batch) or Matrix (nx, batch)
 function set_x0(solver::TinyMPCSolver, x0::AbstractVecOrMat{Float64}; verbose::Bool=false)

@@ -56,6 +56,8 @@ SIGNATURES = {
                                 c_int, c_int, c_int]),
     "set_sensitivity": (c_int, [c_dp, c_int, c_int, c_dp, c_int, c_int, c_dp, c_int, c_int, c_dp, c_int, c_int, c_int]),
     "get_adaptive_rho": (c_int, [c_dp, c_ip]),
+    "set_warm_start": (c_int, [c_int]),
+    "get_kernel_name": (ctypes.c_char_p, []),
     "print_problem_data": (c_int, [c_int]),
     "set_linear_constraints": (c_int, [c_dp, c_int, c_int, c_dp, c_int, c_dp, c_int, c_int, c_dp,
                                        c_int, c_int]),
@@ -235,6 +237,19 @@ def set_gpus(solver, n_gpus):
         raise TinyMPCError(f"Failed to set the number of GPUs ({_err()})")
     solver.n_gpus = int(n_gpus)
     return 0
+
+
+def set_warm_start(solver, on):
+    """on=False: every solve() starts from the zero workspace and keeps none (one-shot solves; the on-chip kernels
+    apply); True (default): the reference's semantics, the workspace persists between solves"""
+    _need_setup(solver)
+    if load_library().set_warm_start(1 if on else 0) != 0:
+        raise TinyMPCError(f"Failed to set warm start ({_err()})")
+
+
+def kernel_name():
+    """the kernel the global solver's last solve ran on"""
+    return load_library().get_kernel_name().decode()
 
 
 def set_batch_size(solver, batch):
