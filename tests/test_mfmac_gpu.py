@@ -73,14 +73,14 @@ SETTINGS = {
 
 
 def _kernel_for(N, lds_only=False):
-    return f"mfmar<6,3,{N}>" if N in (10, 50) and not lds_only else "mfmac<6,3>"
+    return f"mfmar<6,3,{N}>" if N in (10, 20, 30, 50) and not lds_only else "mfmac<6,3>"
 
 
-@pytest.mark.parametrize("N", [10, -10, 50, -50, 23, 2])
+@pytest.mark.parametrize("N", [10, -10, 50, -50, 20, 30, 23, 2])
 @pytest.mark.parametrize("mode", ["fdyn+cones", "fdyn", "cones"])
 @pytest.mark.parametrize("setting", list(SETTINGS))
 def test_mfmac_rocket_vs_oracle(hip_lib, oracle_built, monkeypatch, N, mode, setting):
-    if N in (23, 2, -50) and (mode != "fdyn+cones" or setting not in ("fixed60", "tol")):
+    if N in (23, 2, -50, 20, 30) and (mode != "fdyn+cones" or setting not in ("fixed60", "tol")):
         pytest.skip("the odd horizons (and the LDS kernel at N = 50) run the two main settings only")
     lds_only = N < 0                                        # -10, -50: the compiled horizons on the run-time-horizon kernel
     N = abs(N)
@@ -222,7 +222,7 @@ def test_mfmac_is_not_used_where_it_does_not_apply(hip_lib):
     assert bs.kernel_name == "stream4<6,3>"
     bs.set_warm_start(False)
     bs.solve()
-    assert bs.kernel_name == "mfmac<6,3>"
+    assert bs.kernel_name == "mfmar<6,3,20>"
     bs.set_x_ref(np.repeat(xr[:, :, None], 8, axis=2))      # per-instance references
     bs.set_u_ref(np.repeat(ur[:, :, None], 8, axis=2))
     bs.solve()

@@ -59,12 +59,14 @@ const KernelEntry *select_quad_kernel(int nx, int nu, int N, int batch) {
 const ConeEntry *mfmac_entry_6_3();
 const ConeEntry *mfmar_entry_6_3_50();
 const ConeEntry *mfmar_entry_6_3_10();
+const ConeEntry *mfmar_entry_6_3_20();
+const ConeEntry *mfmar_entry_6_3_30();
 
 // matrix-core kernels for one-shot solves with the affine term / cones, instantiated for the rocket's shape: the
 // register-resident one where the horizon is compiled in (admm_mfmar.hip.h), else the LDS-resident one with a run-time
 // horizon (admm_mfmac.hip.h)
 const ConeEntry *find_cone_kernel(int nx, int nu, int N) {
-    static const ConeEntry *const table[] = {mfmar_entry_6_3_50(), mfmar_entry_6_3_10(), mfmac_entry_6_3()};
+    static const ConeEntry *const table[] = {mfmar_entry_6_3_50(), mfmar_entry_6_3_30(), mfmar_entry_6_3_20(), mfmar_entry_6_3_10(), mfmac_entry_6_3()};
     for (const ConeEntry *e : table)
         if (e->nx == nx && e->nu == nu && e->N == N) return e;
     return nullptr;
