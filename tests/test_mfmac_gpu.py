@@ -176,6 +176,23 @@ def test_mfmac_general_cones_and_bounds(hip_lib, oracle_built, monkeypatch, case
     bs.close()
 
 
+def test_mfmar_box_only_other_horizons(hip_lib, oracle_built):
+    """box-only one-shot solves at N = 20 (no quad instantiation: the stream kernel otherwise) run on mfmar and match the oracle"""
+    N, B = 20, 33
+    prob = t.problems.rocket(N)
+    x0 = t.problems.rocket_x0(B, seed=5)
+    xr, ur = t.problems.rocket_refs(N)
+    kw = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=60, check_termination=1)
+    mk = _oracle(oracle_built, prob, kw, xr, ur, None, None)
+    ref = _loop(mk, x0)
+    bs = _solver(prob, B, kw, xr, ur, None, None)
+    bs.set_x0(x0)
+    bs.solve()
+    assert bs.kernel_name == "mfmar<6,3,20>"
+    parity_every_instance(bs.get_solution(), bs.get_status(), ref, mk, x0, kw, prob.rho, tag="box only N=20")
+    bs.close()
+
+
 @pytest.mark.parametrize("case", ["knot_bounds", "zero_refs_input_cone", "state_cone_outside_slot0", "box_only"])
 def test_mfmar_variants(hip_lib, oracle_built, case):
     """the compiled-horizon kernel's other instantiations at N = 50: bounds that depend on the knot (LDS pack), no
