@@ -151,6 +151,15 @@ def load_library(path=None):
     path = path or _LIB_PATH
     if not os.path.isfile(path):
         raise TinyMPCError(f"TinyMPC library not found: {path} (build it with __graft_entry__.build())")
+    # A process that also uses PyTorch must load torch FIRST: the torch wheel brings its own copy of the HIP / HSA runtime
+    # libraries, and if this library has pulled in the system's (/opt/rocm) before, torch's later initialisation finds
+    # "No HIP GPUs" (two runtimes in one process; measured on this image).  A host without
+    # torch (Julia, C) is not concerned.
+    import sys
+    if "torch" not in sys.modules and os.environ.get("TINYMPC_HIP_NO_TORCH_PRELOAD") is None:
+        import importlib.util
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
     lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export it
