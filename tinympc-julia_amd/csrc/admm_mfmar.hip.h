@@ -244,17 +244,28 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
     };
     // residual terms and solution / scratch traffic of one row at one knot, on the iterations around a check
     // (admm.cpp:93-96: pri = |x - vnew|, dua = |v - vnew| rho over every set)
+    // The previous slack of a row at a knot comes back from HBM (solution buffers / scratch) on a checking iteration: it is
+    // loaded one pair of knots AHEAD of its use (load_old), so that the sets wavefronts do not sit out the memory latency
+    // at every knot (with the check live every iteration that was half of the solve time).
+    struct Old {
+        float box, cone;
+    };
+    auto load_old = [&](auto has_cone, const Flags &F, const float *out_cell, bool own, const float *scr_cell) -> Old {
+        Old o = {0.f, 0.f};
+        if (F.read_old) {
+            if (active && own) o.box = *out_cell;
+            if constexpr (decltype(has_cone)::value) o.cone = *scr_cell;
+        }
+        return o;
+    };
     auto around_check = [&](auto has_cone, const Flags &F, float &pri, float &dua, float xf, float vn, float vc, float *out_cell,
-                            bool own, float *scr_cell) {
+                            bool own, float *scr_cell, const Old &old) {
         if (F.need_res) {
-            float old = 0.f;
-            if (F.read_old && active && own) old = *out_cell;
             pri = fmaxf(pri, fabsf(xf - vn));
-            dua = fmaxf(dua, fabsf(old - vn));
+            dua = fmaxf(dua, fabsf(old.box - vn));
             if constexpr (decltype(has_cone)::value) {
-                const float oldc = F.read_old ? *scr_cell : 0.f;
                 pri = fmaxf(pri, fabsf(xf - vc));
-                dua = fmaxf(dua, fabsf(oldc - vc));
+                dua = fmaxf(dua, fabsf(old.cone - vc));
             }
         }
         if (F.write_sol && active && !conv && own) *out_cell = vn;       // a converged instance's outputs are frozen
@@ -314,8 +325,17 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
                 float *const xo_i = P.xout + b * EX + row0 + opq;
                 {
                     const float xf = (float)x0r[0];                              // knot 0: its fused value feeds nothing
+                    Old o0 = {0.f, 0.f};
+                    if (F.full) o0 = load_old(cone_x, F, xo_i, own, scr_i + (N - 1) * 192);
                     (void)row_sets(cone_x, xf, lo_of(0, 0), hi_of(0, 0), a1[N - 1], a2[N - 1], vn, vc);
-                    if (F.full) around_check(cone_x, F, pri, dua, xf, vn, vc, xo_i, own, scr_i + (N - 1) * 192);
+                    if (F.full) around_check(cone_x, F, pri, dua, xf, vn, vc, xo_i, own, scr_i + (N - 1) * 192, o0);
+                }
+                Old oA = {0.f, 0.f}, oB = {0.f, 0.f}, pA = oA, pB = oA;          // previous slack of this pair's knots, of the next pair's
+                if (F.full) {
+                    oA = load_old(cone_x, F, xo_i + 1 * NX, own, scr_i);
+                    oB = load_old(cone_x, F, xo_i + 2 * NX, own, scr_i + 192);
+                    if (N - 1 > 2) pA = load_old(cone_x, F, xo_i + 3 * NX, own, scr_i + 2 * 192);
+                    if (N - 1 > 3) pB = load_old(cone_x, F, xo_i + 4 * NX, own, scr_i + 3 * 192);
                 }
                 // Knots are taken TWO at a time: a knot's set arithmetic is one dependent chain of ~50 VALU instructions,
                 // and a wavefront issues dependent instructions every 8-12 cycles but independent ones every ~6
@@ -335,6 +355,11 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
                 for (int k = 0; k < N - 1; k += 2) {
                     const bool two = k + 1 < N - 1;                              // (the last knot of an odd count goes alone)
                     const int want = F.step0 + k + (two ? 2 : 1);                // x_{k+1}, x_{k+2} are in the cells of positions k, k + 1
+                    Old nA = {0.f, 0.f}, nB = {0.f, 0.f};                        // ... of the pair after next: read now (two pairs of latency cover)
+                    if (F.full) {
+                        if (k + 4 < N - 1) nA = load_old(cone_x, F, xo_i + (k + 5) * NX, own, scr_i + (k + 4) * 192);
+                        if (k + 5 < N - 1) nB = load_old(cone_x, F, xo_i + (k + 6) * NX, own, scr_i + (k + 5) * 192);
+                    }
                     float xf0 = xa0, xf1 = xa1;
                     if (!have) {
                         until_step(want);
@@ -351,9 +376,10 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
                     const float s0 = row_sets(cone_x, xf0, lo_of(k + 1, 0), hi_of(k + 1, 0), a1[k], a2[k], vn0, vc0);
                     if (two) s1 = row_sets(cone_x, xf1, lo_of(k + 2, 0), hi_of(k + 2, 0), a1[k + 1], a2[k + 1], vn1, vc1);
                     if (F.full) {
-                        around_check(cone_x, F, pri, dua, xf0, vn0, vc0, xo_i + (k + 1) * NX, own, scr_i + k * 192);
-                        if (two) around_check(cone_x, F, pri, dua, xf1, vn1, vc1, xo_i + (k + 2) * NX, own, scr_i + (k + 1) * 192);
+                        around_check(cone_x, F, pri, dua, xf0, vn0, vc0, xo_i + (k + 1) * NX, own, scr_i + k * 192, oA);
+                        if (two) around_check(cone_x, F, pri, dua, xf1, vn1, vc1, xo_i + (k + 2) * NX, own, scr_i + (k + 1) * 192, oB);
                     }
+                    oA = pA, oB = pB, pA = nA, pB = nB;
                     *pa = s0;
                     if (two) pa[a_str[0]] = s1;
                     pa += 2 * a_str[0];
@@ -362,10 +388,22 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
                 float *const uo_i = P.uout + b * EU + row2 + opq;
                 bool have = false;
                 float ua0 = 0.f, ua1 = 0.f;
+                Old oA = {0.f, 0.f}, oB = {0.f, 0.f}, pA = oA, pB = oA;
+                if (F.full) {
+                    oA = load_old(cone_u, F, uo_i, own, scr_i);
+                    oB = load_old(cone_u, F, uo_i + NU, own, scr_i + 192);
+                    if (N - 1 > 2) pA = load_old(cone_u, F, uo_i + 2 * NU, own, scr_i + 2 * 192);
+                    if (N - 1 > 3) pB = load_old(cone_u, F, uo_i + 3 * NU, own, scr_i + 3 * 192);
+                }
 #pragma unroll
                 for (int k = 0; k < N - 1; k += 2) {
                     const bool two = k + 1 < N - 1;
                     const int want = F.step0 + k + (two ? 2 : 1);                // u_k, u_{k+1} are in the cells of positions k, k + 1
+                    Old nA = {0.f, 0.f}, nB = {0.f, 0.f};
+                    if (F.full) {
+                        if (k + 4 < N - 1) nA = load_old(cone_u, F, uo_i + (k + 4) * NU, own, scr_i + (k + 4) * 192);
+                        if (k + 5 < N - 1) nB = load_old(cone_u, F, uo_i + (k + 5) * NU, own, scr_i + (k + 5) * 192);
+                    }
                     float uf0 = ua0, uf1 = ua1;
                     if (!have) {
                         while (seen < want) {
@@ -385,9 +423,10 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
                     const float s0 = row_sets(cone_u, uf0, lo_of(k, 2), hi_of(k, 2), a1[k], a2[k], vn0, vc0);
                     if (two) s1 = row_sets(cone_u, uf1, lo_of(k + 1, 2), hi_of(k + 1, 2), a1[k + 1], a2[k + 1], vn1, vc1);
                     if (F.full) {
-                        around_check(cone_u, F, pri, dua, uf0, vn0, vc0, uo_i + k * NU, own, scr_i + k * 192);
-                        if (two) around_check(cone_u, F, pri, dua, uf1, vn1, vc1, uo_i + (k + 1) * NU, own, scr_i + (k + 1) * 192);
+                        around_check(cone_u, F, pri, dua, uf0, vn0, vc0, uo_i + k * NU, own, scr_i + k * 192, oA);
+                        if (two) around_check(cone_u, F, pri, dua, uf1, vn1, vc1, uo_i + (k + 1) * NU, own, scr_i + (k + 1) * 192, oB);
                     }
+                    oA = pA, oB = pB, pA = nA, pB = nB;
                     *pa = s0;
                     if (two) pa[a_str[2]] = s1;
                     pa += 2 * a_str[2];
@@ -433,10 +472,18 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
                     return mf_mma(cf[S::F_MF2], (double)(one_lane ? 1.f : t), c);
                 };
                 float *const scr_i = scr + opq + 64;
-                auto slot1 = [&](int kn, float xf, float &dual, lds_f *cell) {   // knot kn of state slot 1; cell: where s goes
+                auto slot1_old = [&](int kn) -> Old {                            // the previous slack of knot kn's slot 1 rows (read a step ahead)
+                    Old o = {0.f, 0.f};
+                    if (F.full && F.read_old) {
+                        if (active && ok1) o.box = xo_i[kn * NX];
+                        if constexpr (CX > 0) o.cone = scr_i[(kn > 0 ? kn - 1 : N - 1) * 192];
+                    }
+                    return o;
+                };
+                auto slot1 = [&](int kn, float xf, float &dual, lds_f *cell, const Old &old) {   // knot kn of state slot 1; cell: where s goes
                     float vn, vc = 0.f, none = 0.f;
                     float s = row_sets(no_cone, xf, lo_of(kn, 1), hi_of(kn, 1), dual, none, vn, vc);
-                    if (F.full) around_check(no_cone, F, pri, dua, xf, vn, vc, xo_i + kn * NX, ok1, nullptr);
+                    if (F.full) around_check(no_cone, F, pri, dua, xf, vn, vc, xo_i + kn * NX, ok1, nullptr, old);
                     if constexpr (CX > 0) {
                         // With a state cone enabled EVERY state row carries the cone set's slack and dual (the solver's
                         // arrays are full size); for a row outside the cone the "projection" is the identity: slack =
@@ -445,7 +492,7 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
                         s += xf;
                         if (F.full) {
                             float *const sc = scr_i + (kn > 0 ? kn - 1 : N - 1) * 192;
-                            if (F.need_res) dua = fmaxf(dua, fabsf((F.read_old ? *sc : 0.f) - xf));
+                            if (F.need_res) dua = fmaxf(dua, fabsf(old.cone - xf));
                             if (F.write_old) *sc = xf;
                         }
                     }
@@ -455,7 +502,11 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
                 mf_d4 cpre = t_product(*ph[2]);
                 float t_next = ph[2][a_str[2]];                                  // t of position 1
                 double xa = x0r[0], xb = x0r[1];
-                if constexpr (XS == 2) slot1(0, (float)x0r[1], a1[N - 1], nullptr);
+                Old s1o = slot1_old(0);
+                if constexpr (XS == 2) {
+                    slot1(0, (float)x0r[1], a1[N - 1], nullptr, s1o);
+                    s1o = slot1_old(1);
+                }
                 float x1_prev = 0.f;
 #pragma unroll
                 for (int k = 0; k < N - 1; ++k) {
@@ -466,7 +517,10 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
                         if (k + 2 < N - 1) t_next = ph[2][2 * a_str[2]];
                     }
                     if constexpr (XS == 2) {
-                        if (k > 0) slot1(k, x1_prev, a1[k - 1], ph[1] - a_str[1]);
+                        if (k > 0) {
+                            slot1(k, x1_prev, a1[k - 1], ph[1] - a_str[1], s1o);
+                            s1o = slot1_old(k + 1);
+                        }
                     }
                     xa = c[0], xb = c[1];
                     *(lds_vf *)ph[0] = (float)xa;                                // x_{k+1} (slot 0) for wave 1
@@ -476,7 +530,7 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
 #pragma unroll
                     for (int q = 0; q < 3; ++q) ph[q] += a_str[q];
                 }
-                if constexpr (XS == 2) slot1(N - 1, x1_prev, a1[N - 2], ph[1] - a_str[1]);
+                if constexpr (XS == 2) slot1(N - 1, x1_prev, a1[N - 2], ph[1] - a_str[1], s1o);
                 TMPC_PROBE(if (probe) T_fwd += clock64() - tf0;)
             }
             TMPC_PROBE(const long long tb0 = probe ? clock64() : 0;)
