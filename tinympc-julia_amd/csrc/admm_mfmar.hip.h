@@ -34,7 +34,10 @@ struct RegShape {
     }
 };
 
-template <int NX, int NU, int N, int REFS, int CX, int CU, bool BV>
+// PF: the previous slack is read from HBM two pairs of knots ahead of its use (solves whose termination check is live:
+// every checking iteration reads it) — or at its use (fixed-iteration solves: read once per solve; the read-ahead's
+// registers and moves cost them 2 %, measured side by side).
+template <int NX, int NU, int N, int REFS, int CX, int CU, bool BV, bool PF>
 __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) {
     // (three wavefronts per SIMD also for short horizons, whose 2 N dual registers would allow more: at N = 10 four and six
     // per SIMD measured slower, 1.22 / 1.59 ms against 1.12)
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
                     if (F.full) around_check(cone_x, F, pri, dua, xf, vn, vc, xo_i, own, scr_i + (N - 1) * 192, o0);
                 }
                 Old oA = {0.f, 0.f}, oB = {0.f, 0.f}, pA = oA, pB = oA;          // previous slack of this pair's knots, of the next pair's
-                if (F.full) {
+                if (PF && F.full) {
                     oA = load_old(cone_x, F, xo_i + 1 * NX, own, scr_i);
                     oB = load_old(cone_x, F, xo_i + 2 * NX, own, scr_i + 192);
                     if (N - 1 > 2) pA = load_old(cone_x, F, xo_i + 3 * NX, own, scr_i + 2 * 192);
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
                     const bool two = k + 1 < N - 1;                              // (the last knot of an odd count goes alone)
                     const int want = F.step0 + k + (two ? 2 : 1);                // x_{k+1}, x_{k+2} are in the cells of positions k, k + 1
                     Old nA = {0.f, 0.f}, nB = {0.f, 0.f};                        // ... of the pair after next: read now (two pairs of latency cover)
-                    if (F.full) {
+                    if (PF && F.full) {
                         if (k + 4 < N - 1) nA = load_old(cone_x, F, xo_i + (k + 5) * NX, own, scr_i + (k + 4) * 192);
                         if (k + 5 < N - 1) nB = load_old(cone_x, F, xo_i + (k + 6) * NX, own, scr_i + (k + 5) * 192);
                     }
@@ -376,10 +379,14 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
                     const float s0 = row_sets(cone_x, xf0, lo_of(k + 1, 0), hi_of(k + 1, 0), a1[k], a2[k], vn0, vc0);
                     if (two) s1 = row_sets(cone_x, xf1, lo_of(k + 2, 0), hi_of(k + 2, 0), a1[k + 1], a2[k + 1], vn1, vc1);
                     if (F.full) {
+                        if constexpr (!PF) {
+                            oA = load_old(cone_x, F, xo_i + (k + 1) * NX, own, scr_i + k * 192);
+                            if (two) oB = load_old(cone_x, F, xo_i + (k + 2) * NX, own, scr_i + (k + 1) * 192);
+                        }
                         around_check(cone_x, F, pri, dua, xf0, vn0, vc0, xo_i + (k + 1) * NX, own, scr_i + k * 192, oA);
                         if (two) around_check(cone_x, F, pri, dua, xf1, vn1, vc1, xo_i + (k + 2) * NX, own, scr_i + (k + 1) * 192, oB);
                     }
-                    oA = pA, oB = pB, pA = nA, pB = nB;
+                    if constexpr (PF) oA = pA, oB = pB, pA = nA, pB = nB;
                     *pa = s0;
                     if (two) pa[a_str[0]] = s1;
                     pa += 2 * a_str[0];
@@ -389,7 +396,7 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
                 bool have = false;
                 float ua0 = 0.f, ua1 = 0.f;
                 Old oA = {0.f, 0.f}, oB = {0.f, 0.f}, pA = oA, pB = oA;
-                if (F.full) {
+                if (PF && F.full) {
                     oA = load_old(cone_u, F, uo_i, own, scr_i);
                     oB = load_old(cone_u, F, uo_i + NU, own, scr_i + 192);
                     if (N - 1 > 2) pA = load_old(cone_u, F, uo_i + 2 * NU, own, scr_i + 2 * 192);
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
                     const bool two = k + 1 < N - 1;
                     const int want = F.step0 + k + (two ? 2 : 1);                // u_k, u_{k+1} are in the cells of positions k, k + 1
                     Old nA = {0.f, 0.f}, nB = {0.f, 0.f};
-                    if (F.full) {
+                    if (PF && F.full) {
                         if (k + 4 < N - 1) nA = load_old(cone_u, F, uo_i + (k + 4) * NU, own, scr_i + (k + 4) * 192);
                         if (k + 5 < N - 1) nB = load_old(cone_u, F, uo_i + (k + 5) * NU, own, scr_i + (k + 5) * 192);
                     }
@@ -423,10 +430,14 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
                     const float s0 = row_sets(cone_u, uf0, lo_of(k, 2), hi_of(k, 2), a1[k], a2[k], vn0, vc0);
                     if (two) s1 = row_sets(cone_u, uf1, lo_of(k + 1, 2), hi_of(k + 1, 2), a1[k + 1], a2[k + 1], vn1, vc1);
                     if (F.full) {
+                        if constexpr (!PF) {
+                            oA = load_old(cone_u, F, uo_i + k * NU, own, scr_i + k * 192);
+                            if (two) oB = load_old(cone_u, F, uo_i + (k + 1) * NU, own, scr_i + (k + 1) * 192);
+                        }
                         around_check(cone_u, F, pri, dua, uf0, vn0, vc0, uo_i + k * NU, own, scr_i + k * 192, oA);
                         if (two) around_check(cone_u, F, pri, dua, uf1, vn1, vc1, uo_i + (k + 1) * NU, own, scr_i + (k + 1) * 192, oB);
                     }
-                    oA = pA, oB = pB, pA = nA, pB = nB;
+                    if constexpr (PF) oA = pA, oB = pB, pA = nA, pB = nB;
                     *pa = s0;
                     if (two) pa[a_str[2]] = s1;
                     pa += 2 * a_str[2];
@@ -505,7 +516,7 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
                 Old s1o = slot1_old(0);
                 if constexpr (XS == 2) {
                     slot1(0, (float)x0r[1], a1[N - 1], nullptr, s1o);
-                    s1o = slot1_old(1);
+                    if constexpr (PF) s1o = slot1_old(1);
                 }
                 float x1_prev = 0.f;
 #pragma unroll
@@ -518,8 +529,9 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
                     }
                     if constexpr (XS == 2) {
                         if (k > 0) {
+                            if constexpr (!PF) s1o = slot1_old(k);
                             slot1(k, x1_prev, a1[k - 1], ph[1] - a_str[1], s1o);
-                            s1o = slot1_old(k + 1);
+                            if constexpr (PF) s1o = slot1_old(k + 1);
                         }
                     }
                     xa = c[0], xb = c[1];
@@ -530,7 +542,10 @@ __global__ __launch_bounds__(192, 3) void admm_mfmar_kernel(const AdmmParams P) 
 #pragma unroll
                     for (int q = 0; q < 3; ++q) ph[q] += a_str[q];
                 }
-                if constexpr (XS == 2) slot1(N - 1, x1_prev, a1[N - 2], ph[1] - a_str[1], s1o);
+                if constexpr (XS == 2) {
+                    if constexpr (!PF) s1o = slot1_old(N - 1);
+                    slot1(N - 1, x1_prev, a1[N - 2], ph[1] - a_str[1], s1o);
+                }
                 TMPC_PROBE(if (probe) T_fwd += clock64() - tf0;)
             }
             TMPC_PROBE(const long long tb0 = probe ? clock64() : 0;)

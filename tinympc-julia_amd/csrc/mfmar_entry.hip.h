@@ -25,6 +25,8 @@ hipError_t launch_mfmar(const AdmmParams &P_, bool ext, size_t lds, hipStream_t 
     if (std::getenv("TINYMPC_HIP_MFMAC_DEBUG")) P.mpc_steps = std::atoi(std::getenv("TINYMPC_HIP_MFMAC_DEBUG")) & 40;   // timing probe build only
 #endif
     const int tiles = (P.batch + 15) / 16;
+    // the termination check can end instances: every checking iteration reads the previous slack back (kernel variant PF)
+    const bool live_check = P.abs_pri_tol > 0.f && P.abs_dua_tol > 0.f && P.check_termination > 0;
     // persistent workgroups (the kernel takes tiles off a counter): as many as fit on the chip at once
     static int cus = 0;
     if (!cus) {
@@ -33,20 +35,24 @@ hipError_t launch_mfmar(const AdmmParams &P_, bool ext, size_t lds, hipStream_t 
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
         if (cus <= 0) cus = 256;
     }
-#define TMPC_MFMAR_LAUNCH(REFS_, CX_, CU_, BV_)                                                                          \
+#define TMPC_MFMAR_LAUNCH(REFS_, CX_, CU_, BV_, PF_)                                                                          \
     do {                                                                                                                 \
-        (void)hipFuncSetAttribute((const void *)admm_mfmar_kernel<NX, NU, N, REFS_, CX_, CU_, BV_>,                      \
+        (void)hipFuncSetAttribute((const void *)admm_mfmar_kernel<NX, NU, N, REFS_, CX_, CU_, BV_, PF_>,                      \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
         int per_cu = 0;                                                                                                  \
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, admm_mfmar_kernel<NX, NU, N, REFS_, CX_, CU_, BV_>,    \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, admm_mfmar_kernel<NX, NU, N, REFS_, CX_, CU_, BV_, PF_>,    \
                                                          192, lds) != hipSuccess || per_cu <= 0)                         \
             per_cu = 1;                                                                                                  \
         const int grid = tiles < per_cu * cus ? tiles : per_cu * cus;                                                    \
-        hipLaunchKernelGGL((admm_mfmar_kernel<NX, NU, N, REFS_, CX_, CU_, BV_>), dim3(grid), dim3(192), lds, stream, P); \
+        hipLaunchKernelGGL((admm_mfmar_kernel<NX, NU, N, REFS_, CX_, CU_, BV_, PF_>), dim3(grid), dim3(192), lds, stream, P); \
+    } while (0)
+#define TMPC_MFMAR_LAUNCH_PF(REFS_, CX_, CU_, BV_)                                                                      \
+    do {                                                                                                               \
+        if (live_check) TMPC_MFMAR_LAUNCH(REFS_, CX_, CU_, BV_, true); else TMPC_MFMAR_LAUNCH(REFS_, CX_, CU_, BV_, false); \
     } while (0)
 #define TMPC_MFMAR_LAUNCH_BV(REFS_, CX_, CU_)                                                                          \
     do {                                                                                                               \
-        if (P.bounds_stride) TMPC_MFMAR_LAUNCH(REFS_, CX_, CU_, true); else TMPC_MFMAR_LAUNCH(REFS_, CX_, CU_, false);  \
+        if (P.bounds_stride) TMPC_MFMAR_LAUNCH_PF(REFS_, CX_, CU_, true); else TMPC_MFMAR_LAUNCH_PF(REFS_, CX_, CU_, false); \
     } while (0)
 #define TMPC_MFMAR_LAUNCH_C(REFS_)                                                         \
     do {                                                                                   \
@@ -59,6 +65,7 @@ hipError_t launch_mfmar(const AdmmParams &P_, bool ext, size_t lds, hipStream_t 
     if (P.ref_mode == REF_ZERO) TMPC_MFMAR_LAUNCH_C(REF_ZERO); else TMPC_MFMAR_LAUNCH_C(REF_SHARED);
 #undef TMPC_MFMAR_LAUNCH_C
 #undef TMPC_MFMAR_LAUNCH_BV
+#undef TMPC_MFMAR_LAUNCH_PF
 #undef TMPC_MFMAR_LAUNCH
     return hipGetLastError();
 }
