@@ -207,6 +207,14 @@ int tinympc_solve_status(tinympc_solver *s);
  * negated when the step hit max_iter).  Any log pointer may be NULL. */
 int tinympc_mpc_rollout(tinympc_solver *s, int steps, void *hip_stream);
 int tinympc_get_mpc_log(tinympc_solver *s, double *x, double *u, int *iter);
+/* Shared references of EVERY step of the next closed loops — the caller pattern of
+ * examples/rocket_landing_constraints.jl:97-134, which shifts x_ref by one knot per step (:107-115) before each solve:
+ * x_ref_seq is nx x (N*steps), u_ref_seq nu x ((N-1)*steps), column-major, step after step (what `steps` calls of
+ * set_x_ref / set_u_ref would have passed).  The plant step of such a loop includes the affine term,
+ * x0 = A x0 + B u0 + f (:123).  Step 0's references become the solver's own; a later set_x_ref / set_u_ref or
+ * steps = 0 drops the sequence.  Needs the transposed-sets kernel (mfmat) for the shape. */
+int tinympc_set_ref_sequence(tinympc_solver *s, const double *x_ref_seq, int x_rows, int x_cols, const double *u_ref_seq,
+                             int u_rows, int u_cols, int steps);
 /* Tolerance-terminated solves of big batches: with chunk_iters > 0 (rounded up to a multiple of check_termination)
  * a solve runs in chunks of that many iterations and, between chunks, gathers the instances still iterating into
  * a dense list, so that wavefronts do not idle behind their slowest instance.  Iterates, iteration counts and

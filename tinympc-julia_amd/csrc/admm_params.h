@@ -85,6 +85,9 @@ struct AdmmParams {
     const float *het_aux;                // [nx + nu + 1][batch]: diag(Q)+rho, diag(R)+rho, rho of each instance
     // ---- mfmac kernel only: 0 = the bounds pack holds one knot's bounds (they do not depend on the knot) ----
     int bounds_stride;
+    // ---- mfmat kernel, fused closed loop: shared references of every step, [steps][N][nx] / [steps][N-1][nu] (NULL: the
+    // references stay as set) — the per-step shift of rocket_landing_constraints.jl:107-115 ----
+    const float *xref_seq, *uref_seq;
 };
 
 #ifdef __HIPCC__

@@ -325,6 +325,18 @@ int tinympc_mpc_rollout(tinympc_solver *s, int steps, void *hip_stream) {
         return sync_status(s, (hipStream_t)hip_stream);
     });
 }
+int tinympc_set_ref_sequence(tinympc_solver *s, const double *x_ref_seq, int x_rows, int x_cols, const double *u_ref_seq,
+                             int u_rows, int u_cols, int steps) {
+    if (!s) return -1;
+    return guarded("set_ref_sequence", [&]() -> int {
+        if (steps > 0 && (x_rows != s->s.nx || u_rows != s->s.nu || (long)x_cols != (long)s->s.N * steps ||
+                          (long)u_cols != (long)(s->s.N - 1) * steps)) {
+            tmpc::set_error("set_ref_sequence: expected nx x (N steps) and nu x ((N-1) steps)");
+            return -1;
+        }
+        return s->s.set_ref_sequence(x_ref_seq, u_ref_seq, steps);
+    });
+}
 int tinympc_get_mpc_log(tinympc_solver *s, double *x, double *u, int *iter) {
     if (!s) return -1;
     return guarded("get_mpc_log", [&] { return s->s.get_mpc_log(x, u, iter); });

@@ -72,6 +72,30 @@ const ConeEntry *find_cone_kernel(int nx, int nu, int N) {
     return nullptr;
 }
 
+const ConeEntry *mfmat_entry_6_3_50();
+const ConeEntry *mfmat_entry_6_3_10();
+
+// the transposed-sets matrix-core kernel (admm_mfmat.hip.h): every kind of solve of the shapes instantiated — one-shot,
+// warm-started, workspace-keeping, chunked, closed loop — with box bounds, the affine term and one cone per side
+const ConeEntry *find_trans_kernel(int nx, int nu, int N) {
+    static const ConeEntry *const table[] = {mfmat_entry_6_3_50(), mfmat_entry_6_3_10()};
+    for (const ConeEntry *e : table)
+        if (e->nx == nx && e->nu == nu && e->N == N) return e;
+    return nullptr;
+}
+
+int device_cu_count() {
+    static int cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    int &c = cus[dev & 63];
+    if (c <= 0) {
+        hipDeviceProp_t prop;
+        c = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return c;
+}
+
 const StreamEntry *stream4_entry_2_1();
 const StreamEntry *stream4_entry_2_2();
 const StreamEntry *stream4_entry_3_1();

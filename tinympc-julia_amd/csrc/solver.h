@@ -55,8 +55,12 @@ struct ConeEntry {
     size_t (*scratch_floats)(const Solver &);   // for the whole batch
     bool (*bounds_vary)(const Solver &);
     hipError_t (*launch)(const AdmmParams &, bool ext, size_t lds, hipStream_t);
+    bool ws = false;                            // takes every kind of solve: warm starts, kept workspace, chunks, the fused closed loop
 };
 const ConeEntry *find_cone_kernel(int nx, int nu, int N);   // N = 0: the run-time-horizon entry only
+const ConeEntry *find_trans_kernel(int nx, int nu, int N);  // the transposed-sets kernel of the shape (admm_mfmat.hip.h), or null
+// CU count of the current device (cached per device: a sharded handle launches on several)
+int device_cu_count();
 hipError_t launch_generic(const AdmmParams &, int precision, hipStream_t);
 void build_generic_coef(const Solver &, std::vector<unsigned char> &);
 void build_generic_bounds(const Solver &, std::vector<float> &);
@@ -181,6 +185,9 @@ struct Solver {
     int upload_refs();
     int set_x0(const double *x0, int cols);
     int set_ref(bool is_x, const double *ref, int cols);
+    int set_ref_sequence(const double *x_seq, const double *u_seq, int steps);
+    float *d_xref_seq = nullptr, *d_uref_seq = nullptr;  // shared references of every step of a fused closed loop
+    int ref_seq_steps = 0;
     int set_bounds(const double *xmin, const double *xmax, const double *umin, const double *umax);
     int set_fdyn(const double *f);
     int set_cones(const int *Acu_, const int *qcu_, const double *cu_, int ncu_, const int *Acx_, const int *qcx_,

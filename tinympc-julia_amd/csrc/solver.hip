@@ -224,6 +224,9 @@ void Solver::free_batch() {
     dev_free(d_mpc_x);
     dev_free(d_mpc_u);
     dev_free(d_mpc_iter);
+    dev_free(d_xref_seq);
+    dev_free(d_uref_seq);
+    ref_seq_steps = 0;
     mpc_cap = 0;
     xref_cap = uref_cap = scratch_cap = 0;
 }
@@ -371,6 +374,24 @@ int Solver::select_kernel(bool rollout) {
             k = nullptr;
             s2 = nullptr;
         }
+    }
+    // every kind of solve (one-shot, warm-started, workspace kept, chunked, the fused closed loop) of a shape that has the
+    // transposed-sets matrix-core kernel, with the affine term / at most one cone per side (box-only problems where the
+    // entry says so).  TINYMPC_HIP_NO_MFMAT: tuning / test aid; TINYMPC_HIP_MFMAT_WS_ONLY: one-shot solves stay on the
+    // three-wavefront kernels (tests hold the two families against each other)
+    const ConeEntry *ct = (std::getenv("TINYMPC_HIP_NO_MFMAT") || std::getenv("TINYMPC_HIP_NO_MFMA") || genv) ? nullptr : find_trans_kernel(nx, nu, N);
+    if (ct && ct->supports && !ct->supports(*this)) ct = nullptr;
+    if (ct && (precision != 0 || hetero || lin_active() || st.adaptive_rho || xref_kind >= 2 || uref_kind >= 2 ||
+               (refs_device_owned && ref_mode == REF_PER_INSTANCE) || st.max_iter < 1 ||
+               !(has_fdyn || cones_active() || ct->plain || std::getenv("TINYMPC_HIP_MFMAT_ALL")) ||
+               ct->lds_bytes(*this) > 160 * 1024 - 1024 || (double)batch * ex() >= 2.0e9))
+        ct = nullptr;
+    if (ct && std::getenv("TINYMPC_HIP_MFMAT_WS_ONLY") && !warm_start && chunk_iters == 0 && !rollout && c2) ct = nullptr;
+    if (ct) {
+        c2 = ct;
+        k = nullptr;
+        s2 = nullptr;
+        rollout_quad = false;
     }
     if (k != ke || s2 != se || c2 != ce) packs_dirty = true;
     ke = k;
@@ -556,8 +577,40 @@ int Solver::set_ref(bool is_x, const double *ref, int cols) {
         h.clear();
     }
     (is_x ? xref_kind : uref_kind) = kind;
+    ref_seq_steps = 0;  // (a closed loop's per-step references go with the references they replaced)
     refs_dirty = true;
     refs_device_owned = false;
+    return 0;
+}
+
+// Shared references of every step of the next fused closed loop (rocket_landing_constraints.jl:107-115 shifts x_ref by one
+// knot per step): x_seq is nx x (N steps), u_seq nu x ((N-1) steps), column-major like set_x_ref / set_u_ref, step after
+// step.  Step 0's become the solver's references; steps = 0 clears the sequence.
+int Solver::set_ref_sequence(const double *x_seq, const double *u_seq, int steps) {
+    if (steps <= 0) {
+        ref_seq_steps = 0;
+        return 0;
+    }
+    if (!x_seq || !u_seq) {
+        set_error("set_ref_sequence: null reference sequence");
+        return -1;
+    }
+    HIP_TRY(hipSetDevice(device));
+    if (wait_last_launch()) return -1;
+    const size_t EX = (size_t)ex(), EU = (size_t)eu();
+    std::vector<float> hx(EX * steps), hu(EU * steps);
+    for (size_t i = 0; i < hx.size(); ++i) hx[i] = (float)x_seq[i];
+    for (size_t i = 0; i < hu.size(); ++i) hu[i] = (float)u_seq[i];
+    if (dev_alloc(d_xref_seq, hx.size()) || dev_alloc(d_uref_seq, hu.size())) return -1;
+    HIP_TRY(hipMemcpy(d_xref_seq, hx.data(), hx.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_uref_seq, hu.data(), hu.size() * sizeof(float), hipMemcpyHostToDevice));
+    // the solver's own references = step 0's, kept in shared mode even when they are all zero (later steps need not be)
+    h_xref.assign(hx.begin(), hx.begin() + EX);
+    h_uref.assign(hu.begin(), hu.begin() + EU);
+    xref_kind = uref_kind = 1;
+    refs_dirty = true;
+    refs_device_owned = false;
+    ref_seq_steps = steps;
     return 0;
 }
 
@@ -820,7 +873,7 @@ __global__ void residual_max_kernel(const float *res, long batch, uint32_t *gsta
 int Solver::solve_async(hipStream_t stream, int mpc_steps) {
     HIP_TRY(hipSetDevice(device));
     if (select_kernel(mpc_steps > 0) || ensure_extension_buffers()) return -1;
-    const bool chunkable = chunk_iters > 0 && mpc_steps == 0 && !hetero && (ke || se) && st.check_termination > 0 &&
+    const bool chunkable = chunk_iters > 0 && mpc_steps == 0 && !hetero && (ke || se || (ce && ce->ws)) && st.check_termination > 0 &&
                            st.abs_pri_tol > 0.0 && st.abs_dua_tol > 0.0 && st.max_iter > chunk_iters;
     if (chunkable) return solve_chunked(stream);
     if (mpc_steps > 0 && ke && ke->G == 16) return rollout_steps(stream, mpc_steps);
@@ -876,8 +929,8 @@ int Solver::solve_chunked(hipStream_t stream) {
 int Solver::launch_pass(hipStream_t stream, int mpc_steps, const int *idx, int n_slots, int iter_offset, int max_iter_pass,
                         bool cold, bool save) {
     if (mpc_steps > 0) {
-        if (!ke) {
-            set_error("mpc_rollout: this problem shape has no specialised kernel (generic path does plain solves only)");
+        if (!ke && !(ce && ce->ws)) {
+            set_error("mpc_rollout: this problem shape / option set has no kernel with a fused closed loop");
             return -1;
         }
         if (!warm_start) {
@@ -968,6 +1021,14 @@ int Solver::launch_pass(hipStream_t stream, int mpc_steps, const int *idx, int n
     // the quad and stream kernels keep the status block clean themselves (fold_status); the generic kernel
     // accumulates straight into it
     P.bounds_stride = (ce && ce->bounds_vary(*this)) ? 1 : 0;
+    if (mpc_steps > 0 && ref_seq_steps > 0) {
+        if (!(ce && ce->ws) || ref_seq_steps < mpc_steps || ref_mode != REF_SHARED) {
+            set_error("mpc_rollout: per-step references need the transposed-sets kernel (mfmat) and one reference set per step");
+            return -1;
+        }
+        P.xref_seq = d_xref_seq;
+        P.uref_seq = d_uref_seq;
+    }
     if (!ke && !se && !ce) HIP_TRY(hipMemsetAsync(d_gstat, 0, GSTAT_WORDS * sizeof(uint32_t), stream));
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (profiling) {

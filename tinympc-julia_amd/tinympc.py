@@ -98,6 +98,7 @@ SIGNATURES = {
     "tinympc_solve_status": (c_int, [c_vp]),
     "tinympc_mpc_rollout": (c_int, [c_vp, c_int, c_vp]),
     "tinympc_get_mpc_log": (c_int, [c_vp, c_dp, c_dp, c_ip]),
+    "tinympc_set_ref_sequence": (c_int, [c_vp, c_dp, c_int, c_int, c_dp, c_int, c_int, c_int]),
     "tinympc_set_profiling": (c_int, [c_vp, c_int]),
     "tinympc_set_compaction": (c_int, [c_vp, c_int]),
     "tinympc_set_adaptive_rho": (c_int, [c_vp, c_int, c_dbl, c_dbl, c_int]),
@@ -702,6 +703,20 @@ class BatchSolver:
 
     def set_ref_mode(self, mode):
         self._chk(self.lib.tinympc_set_ref_mode(self.h, int(mode)), "set_ref_mode")
+
+    def set_ref_sequence(self, x_ref_seq, u_ref_seq):
+        """shared references of every step of the next closed loops: x_ref_seq (nx, N, steps), u_ref_seq (nu, N-1, steps)
+        (rocket_landing_constraints.jl:107-115 shifts them step by step); None, None drops the sequence"""
+        if x_ref_seq is None:
+            self._chk(self.lib.tinympc_set_ref_sequence(self.h, None, 0, 0, None, 0, 0, 0), "set_ref_sequence")
+            return
+        xs = np.asfortranarray(np.asarray(x_ref_seq, dtype=np.float64))
+        us = np.asfortranarray(np.asarray(u_ref_seq, dtype=np.float64))
+        steps = xs.shape[2]
+        assert xs.shape == (self.nx, self.N, steps) and us.shape == (self.nu, self.N - 1, steps)
+        xs, us = xs.reshape(-1, order="F"), us.reshape(-1, order="F")
+        self._chk(self.lib.tinympc_set_ref_sequence(self.h, _dp(xs), self.nx, self.N * steps, _dp(us), self.nu,
+                                                    (self.N - 1) * steps, steps), "set_ref_sequence")
 
     def mpc_rollout(self, steps, stream=None):
         """`steps` fused closed-loop MPC steps in one launch (plant = the family's own A, B).
