@@ -51,17 +51,37 @@ struct TransShape {
     static constexpr int NROW = NX + NU;
     static constexpr int PLEN = 16 * NROW;      // floats of one position: every row x 16 instances
     static constexpr int NG = (N + 3) / 4;      // knot groups of the sets layout
-    // coefficient pack, doubles: ConeShape's lane fields [NF][64], then row-major Pinf [NX][NX] (as mfmac), Quu [NU][NU],
-    // Quu_inv [NU][NU], Kinf [NU][NX], A [NX][NX], B [NX][NU], f [NX]
-    static constexpr int O_PINF = S::NF * 64, O_QUU = O_PINF + NX * NX, O_QUI = O_QUU + NU * NU, O_KINF = O_QUI + NU * NU,
-                         O_A = O_KINF + NU * NX, O_B = O_A + NX * NX, O_F = O_B + NX * NU, COEF_DOUBLES = O_F + NX;
+    // Two products per step instead of three.  The stacked vector [x; t] has nx + nu entries, a product takes 4 of them, and
+    // the chain of a step is its products one after the other (64 cycles each) + the way back from a result to an operand
+    // (~44): three products, 272-280 cycles (measured, also in isolation: experiments/mfma_chain_variants.hip).  Eight
+    // entries go through the matrix cores — all of x (slot 0: rows 0..3, slot 1: rows 4..nx-1) and the first MU = min(nu,
+    // 8 - nx) input components behind them in slot 1 — the other VU = nu - MU input components and the affine term are
+    // multiplied on the VALU into the step's accumulator START, off the chain (they depend on t / r alone).  The
+    // accumulator also carries the NEXT step's matrix-core input components through: tile rows nx..7 meet zero operand
+    // rows, so what the start value holds there comes out unchanged in the result registers of the lanes that own K slots
+    // nx..7 — exactly where the next step's operand is read from.
+    static constexpr int NXH = NX > 4 ? NX - 4 : 0;            // state rows in slot 1
+    static constexpr int MU = (8 - (4 + NXH)) < NU ? (8 - (4 + NXH)) : NU, VU = NU - MU, VUA = VU > 0 ? VU : 1;
+    // coefficient pack, doubles: operand lane fields [NLF][64] (forward slots 0, 1; backward slots 0, 1), the per-lane-group
+    // constants [NKC][4] (affine terms, VALU columns), then row-major Pinf [NX][NX], Quu [NU][NU], Quu_inv [NU][NU],
+    // Kinf [NU][NX], A [NX][NX], B [NX][NU], f [NX]
+    enum { L_MF0 = 0, L_MF1, L_MB0, L_MB1, NLF };
+    enum { K_FD0 = 0, K_FD1, K_APF0, K_APF1, K_BPF, K_GF0, K_GF1 = K_GF0 + VUA, K_GF2 = K_GF1 + VUA, K_GB0 = K_GF2 + VUA,
+           K_GB1 = K_GB0 + VUA, NKC = K_GB1 + VUA };
+    static constexpr int O_KC = NLF * 64, O_PINF = O_KC + NKC * 4, O_QUU = O_PINF + NX * NX, O_QUI = O_QUU + NU * NU,
+                         O_KINF = O_QUI + NU * NU, O_A = O_KINF + NU * NX, O_B = O_A + NX * NX, O_F = O_B + NX * NU,
+                         COEF_DOUBLES = O_F + NX;
     static constexpr size_t lds_floats(int nk) {
         return (size_t)PLEN * N + ((S::bounds_len(nk) + 1) & ~1) + (((size_t)NROW * N + 2) & ~(size_t)1);
     }
-    static constexpr size_t lds_bytes(int nk) { return sizeof(float) * lds_floats(nk) + sizeof(double) * (8 + 16 * NX); }
-    // registers of the sets layout per lane: duals + previous slack of every set
-    static constexpr int state_regs(int cxq, int cuq) {
-        return NG * ((NX + cxq + NU + cuq) + (NX + (cxq ? NX : 0) + NU + (cuq ? NU : 0)));
+    // registers of the sets layout per lane and knot group: duals + previous slack of every set
+    static constexpr int group_regs(int cxq, int cuq) { return (NX + cxq + NU + cuq) + (NX + (cxq ? NX : 0) + NU + (cuq ? NU : 0)); }
+    static constexpr int state_regs(int cxq, int cuq) { return NG * group_regs(cxq, cuq); }
+    // the last group's state in LDS instead: when everything together would not fit the 512-entry file
+    static constexpr bool spill_last(int cxq, int cuq) { return NG >= 2 && state_regs(cxq, cuq) + 70 > 450; }
+    static constexpr size_t lds_bytes(int nk, int cxq, int cuq) {
+        return sizeof(float) * (lds_floats(nk) + (spill_last(cxq, cuq) ? (size_t)64 * group_regs(cxq, cuq) : 0)) +
+               sizeof(double) * (8 + 16 * NX + 4 * NKC);
     }
 };
 
@@ -91,6 +111,12 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
     float *s_ref = s_bnd + ((S::bounds_len(nk) + 1) & ~1);    // [N][NROW] and one zero cell behind (even offset: fp64 cells follow)
     double *s_pterm = reinterpret_cast<double *>(s_ref + (((size_t)NROW * N + 2) & ~(size_t)1));
     double *s_plant = s_pterm + 8;                            // closed loop: the plant state of the tile's instances, [16][NX]
+    constexpr bool SPILL = T::spill_last(CXQ, CUQ);
+    // every lane's slot addresses stay inside the cells and the reference pack, and a lane without a row only ever reads
+    // finite values that meet a zero operand column: the matrix-layout phases then run without lane masks
+    constexpr bool FREE = XS == 2 && NROW >= 8 && NU >= 2;
+    double *s_kc = s_plant + 16 * NX;                          // per-lane-group constants [NKC][4]
+    float *s_last = reinterpret_cast<float *>(s_kc + 4 * T::NKC);   // SPILL: the last knot group's state, [value][64 lanes]
 
     const int l = threadIdx.x, g = l >> 4, j = l & 15;       // matrix layout: rows g, 4 + g, u row g | sets layout: knot 4 m + g
     const int n_tiles = (P.batch + 15) / 16;
@@ -105,9 +131,20 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
 
     // ---- constants ----
     const double *gc64 = reinterpret_cast<const double *>(P.coef);
-    double cf[S::NF];
+    // the same pack through the constant address space: wave-uniform reads come through the scalar cache into SGPRs (the
+    // matrices of the parking / workspace / plant arithmetic would otherwise take 20-60 VGPRs in branches that rarely run)
+    typedef const double __attribute__((address_space(4))) *cdouble_ptr;
+    const cdouble_ptr gk64 = (cdouble_ptr)(reinterpret_cast<uintptr_t>(P.coef));
+    double cf[T::NLF];
 #pragma unroll
-    for (int f = 0; f < S::NF; ++f) cf[f] = gc64[f * 64 + l];
+    for (int f = 0; f < T::NLF; ++f) cf[f] = gc64[f * 64 + l];
+    if (l < 4 * T::NKC) s_kc[l] = gc64[T::O_KC + l];
+    constexpr int NXH = T::NXH, MU = T::MU, VU = T::VU, VUA = T::VUA;
+    // this lane's input components: cA (row g of u, what the accumulator's slot 2 starts from / returns), cB (the matrix-core
+    // component behind the state rows of slot 1, lanes g >= NXH), and the VU components of the VALU columns; as cell rows
+    const bool slot1_x = g < NXH;                             // slot 1 of this lane is a state row (else a passenger)
+    const int rowA = NX + (g < NU ? g : NU - 1), rowB = NX + ((g - NXH >= 0 && g - NXH < MU) ? g - NXH : 0);
+    auto kc = [&](int field) -> double { return s_kc[field * 4 + g]; };
     auto uni = [](float v) -> float { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
     const float rho = uni(P.rho), ptol = uni(P.abs_pri_tol), dtol = uni(P.abs_dua_tol);
     float lo_s[NROW], hi_s[NROW];
@@ -125,8 +162,6 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
     const int last_check_it = ct > 0 ? (P.max_iter / ct) * ct : 0;
     const bool keep = P.save_state != 0;                      // the workspace is written back
     const bool park = keep && can_converge && ct > 0;
-    constexpr bool ONE_COL = NU <= 3;                         // the affine term rides in the products (admm_mfmac.hip.h)
-    const bool one_lane = ONE_COL && g == 3;
     const int n_steps = P.mpc_steps > 0 ? P.mpc_steps : 1;
     // The parameter block read afresh where a region needs its pointers: loaded at kernel entry (where the compiler puts
     // kernel-argument loads) the two dozen array pointers of the load / park / store regions stay live across the iteration
@@ -159,6 +194,10 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
             }
         }
     };
+    if (l < 8) s_pterm[l] = 0.0;
+    for (int i = l; i < PLEN * N; i += 64) s_cells[i] = 0.f;   // (cells no lane owns are read by the mask-free phases: keep them finite)
+    for (int i = l; i < NROW * N + 2; i += 64) s_ref[i] = 0.f;
+    __syncthreads();
     stage_refs(P.xref, P.uref);
     __syncthreads();
 
@@ -193,8 +232,59 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
     };
 
     // ---- the iterated state: registers of the sets layout (group m = knot 4 m + g of instance j) ----
-    float a1x[NG][NX], a2x[NG][NCX], vbx[NG][NX], vcx[NG][NVX];     // state rows: box dual g, cone dual gc | previous slack v, vc
-    float a1u[NG][NU], a2u[NG][NCU], vbu[NG][NU], vcu[NG][NVU];     // input rows: y, yc | z, zc
+    // Three storage classes, chosen here and not by the register allocator (left to it, the 429 values of config 4 at
+    // N = 50 travel in the 3- and 4-register tuples of the wide loads / stores / packed adds that touch them, fragment the
+    // file and end up in scratch memory — 100 reloads per iteration, and a lone wavefront sits out every one of them):
+    //   arch VGPRs  the duals of the first MD groups (what every iteration reads and writes);
+    //   AGPRs       the previous slack of every group — read only by an iteration that forms residuals, written only
+    //               where a later one reads it — and the duals of the groups behind MD; one v_accvgpr move per access;
+    //   LDS         (SPILL) the last group, where N is not a multiple of 4 and some of its lanes have no knot anyway.
+    // Shapes whose state fits the arch VGPRs of their occupancy keep everything there (AREG = false).
+    constexpr int NGR = SPILL ? NG - 1 : NG;
+    constexpr bool AREG = T::state_regs(CXQ, CUQ) + 80 > 256;
+    constexpr int DG = NX + NCX + NU + NCU;                     // duals per group
+    constexpr int MD = AREG ? (NGR < 150 / DG ? NGR : 150 / DG) : NGR;
+    constexpr int MDA = MD > 0 ? MD : 1;
+    float a1x[MDA][NX], a2x[MDA][NCX], a1u[MDA][NU], a2u[MDA][NCU];     // duals g, gc | y, yc of the groups in arch VGPRs
+    float b1x[NGR][NX], b2x[NGR][NCX], b1u[NGR][NU], b2u[NGR][NCU];     // ... of the groups behind MD (AREG: AGPRs)
+    float vbx[NGR][NX], vcx[NGR][NVX], vbu[NGR][NU], vcu[NGR][NVU];     // previous slack v, vc | z, zc (AREG: AGPRs)
+    auto aget = [](const float &areg) -> float {
+        float r;
+        asm("v_accvgpr_read_b32 %0, %1" : "=v"(r) : "a"(areg));
+        return r;
+    };
+    auto aset = [](float &areg, float v) { asm("v_accvgpr_write_b32 %0, %1" : "=a"(areg) : "v"(v)); };
+    lds_f *const sl = (lds_f *)s_last + l;
+    // value r of array ID of group m, wherever it lives (r a compile-time constant after unrolling)
+    enum { S_A1X, S_A2X, S_A1U, S_A2U, S_VBX, S_VCX, S_VBU, S_VCU };
+    auto sld = [&](auto id, auto mt, int r) -> float {
+        constexpr int ID = decltype(id)::value, m = decltype(mt)::value;
+        constexpr int LOFF[8] = {0, NX, NX + NCX, NX + NCX + NU, DG, DG + NX, DG + NX + NVX, DG + NX + NVX + NU};
+        if constexpr (SPILL && m == NG - 1) return sl[64 * (LOFF[ID] + r)];
+        else if constexpr (ID == S_A1X) { if constexpr (m < MD) return a1x[m][r]; else return aget(b1x[m][r]); }
+        else if constexpr (ID == S_A2X) { if constexpr (m < MD) return a2x[m][r]; else return aget(b2x[m][r]); }
+        else if constexpr (ID == S_A1U) { if constexpr (m < MD) return a1u[m][r]; else return aget(b1u[m][r]); }
+        else if constexpr (ID == S_A2U) { if constexpr (m < MD) return a2u[m][r]; else return aget(b2u[m][r]); }
+        else if constexpr (ID == S_VBX) { if constexpr (AREG) return aget(vbx[m][r]); else return vbx[m][r]; }
+        else if constexpr (ID == S_VCX) { if constexpr (AREG) return aget(vcx[m][r]); else return vcx[m][r]; }
+        else if constexpr (ID == S_VBU) { if constexpr (AREG) return aget(vbu[m][r]); else return vbu[m][r]; }
+        else { if constexpr (AREG) return aget(vcu[m][r]); else return vcu[m][r]; }
+    };
+    auto sst = [&](auto id, auto mt, int r, float v) {
+        constexpr int ID = decltype(id)::value, m = decltype(mt)::value;
+        constexpr int LOFF[8] = {0, NX, NX + NCX, NX + NCX + NU, DG, DG + NX, DG + NX + NVX, DG + NX + NVX + NU};
+        if constexpr (SPILL && m == NG - 1) sl[64 * (LOFF[ID] + r)] = v;
+        else if constexpr (ID == S_A1X) { if constexpr (m < MD) a1x[m][r] = v; else aset(b1x[m][r], v); }
+        else if constexpr (ID == S_A2X) { if constexpr (m < MD) a2x[m][r] = v; else aset(b2x[m][r], v); }
+        else if constexpr (ID == S_A1U) { if constexpr (m < MD) a1u[m][r] = v; else aset(b1u[m][r], v); }
+        else if constexpr (ID == S_A2U) { if constexpr (m < MD) a2u[m][r] = v; else aset(b2u[m][r], v); }
+        else if constexpr (ID == S_VBX) { if constexpr (AREG) aset(vbx[m][r], v); else vbx[m][r] = v; }
+        else if constexpr (ID == S_VCX) { if constexpr (AREG) aset(vcx[m][r], v); else vcx[m][r] = v; }
+        else if constexpr (ID == S_VBU) { if constexpr (AREG) aset(vbu[m][r], v); else vbu[m][r] = v; }
+        else { if constexpr (AREG) aset(vcu[m][r], v); else vcu[m][r] = v; }
+    };
+#define LD(ID, r) sld(std::integral_constant<int, ID>{}, mt, r)
+#define ST(ID, r, v) sst(std::integral_constant<int, ID>{}, mt, r, v)
 
     float fm0 = 0.f, fm1 = 0.f, fm2 = 0.f, fm3 = 0.f;          // over this workgroup's tiles: residual maxima, unsolved instances
     int f_unsolved = 0;
@@ -217,32 +307,33 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
     const bool warm = !P.cold_start && active;
     kparam_ptr Pi = kparams();
     mf_for<0, NG>([&](auto mt) {
+        float A1x[NX], A2x[NCX], Vbx[NX], Vcx[NVX], A1u[NU], A2u[NCU], Vbu[NU], Vcu[NVU];
         constexpr int m = decltype(mt)::value;
         const int kk = 4 * m + g;
         const bool xv = warm && kk < N, uv = warm && kk < N - 1;
         lds_f *c = cq + m * 4 * PLEN;
 #pragma unroll
-        for (int r = 0; r < NX; ++r) a1x[m][r] = 0.f, vbx[m][r] = 0.f;
+        for (int r = 0; r < NX; ++r) A1x[r] = 0.f, Vbx[r] = 0.f;
 #pragma unroll
-        for (int r = 0; r < NVX; ++r) vcx[m][r] = 0.f;
+        for (int r = 0; r < NVX; ++r) Vcx[r] = 0.f;
 #pragma unroll
-        for (int c2 = 0; c2 < NCX; ++c2) a2x[m][c2] = 0.f;
+        for (int c2 = 0; c2 < NCX; ++c2) A2x[c2] = 0.f;
 #pragma unroll
-        for (int a = 0; a < NU; ++a) a1u[m][a] = 0.f, vbu[m][a] = 0.f;
+        for (int a = 0; a < NU; ++a) A1u[a] = 0.f, Vbu[a] = 0.f;
 #pragma unroll
-        for (int a = 0; a < NVU; ++a) vcu[m][a] = 0.f;
+        for (int a = 0; a < NVU; ++a) Vcu[a] = 0.f;
 #pragma unroll
-        for (int c2 = 0; c2 < NCU; ++c2) a2u[m][c2] = 0.f;
+        for (int c2 = 0; c2 < NCU; ++c2) A2u[c2] = 0.f;
         if (xv) {
             const float *pg = Pi->sg + ox + m * 4 * NX, *pv = Pi->sv + ox + m * 4 * NX;
 #pragma unroll
-            for (int r = 0; r < NX; ++r) a1x[m][r] = pg[r], vbx[m][r] = pv[r];
+            for (int r = 0; r < NX; ++r) A1x[r] = pg[r], Vbx[r] = pv[r];
             if constexpr (CXQ > 0) {
                 const float *pgc = Pi->sgc + ox + m * 4 * NX, *pvc = Pi->svc + ox + m * 4 * NX;
 #pragma unroll
-                for (int r = 0; r < NX; ++r) vcx[m][r] = pvc[r];
+                for (int r = 0; r < NX; ++r) Vcx[r] = pvc[r];
 #pragma unroll
-                for (int c2 = 0; c2 < CXQ; ++c2) a2x[m][c2] = pgc[CXA + c2];
+                for (int c2 = 0; c2 < CXQ; ++c2) A2x[c2] = pgc[CXA + c2];
             }
         }
         double dv[NU];
@@ -251,22 +342,34 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
         if (uv) {
             const float *py = Pi->sy + ou + m * 4 * NU, *pz = Pi->sz + ou + m * 4 * NU, *pd = Pi->sd + ou + m * 4 * NU;
 #pragma unroll
-            for (int a = 0; a < NU; ++a) a1u[m][a] = py[a], vbu[m][a] = pz[a], dv[a] = (double)pd[a];
+            for (int a = 0; a < NU; ++a) A1u[a] = py[a], Vbu[a] = pz[a], dv[a] = (double)pd[a];
             if constexpr (CUQ > 0) {
                 const float *pyc = Pi->syc + ou + m * 4 * NU, *pzc = Pi->szc + ou + m * 4 * NU;
 #pragma unroll
-                for (int a = 0; a < NU; ++a) vcu[m][a] = pzc[a];
+                for (int a = 0; a < NU; ++a) Vcu[a] = pzc[a];
 #pragma unroll
-                for (int c2 = 0; c2 < CUQ; ++c2) a2u[m][c2] = pyc[CUA + c2];
+                for (int c2 = 0; c2 < CUQ; ++c2) A2u[c2] = pyc[CUA + c2];
             }
         }
+#pragma unroll
+        for (int r = 0; r < NX; ++r) ST(S_A1X, r, A1x[r]), ST(S_VBX, r, Vbx[r]);
+#pragma unroll
+        for (int r = 0; r < NVX; ++r) ST(S_VCX, r, Vcx[r]);
+#pragma unroll
+        for (int r = 0; r < NCX; ++r) ST(S_A2X, r, A2x[r]);
+#pragma unroll
+        for (int a = 0; a < NU; ++a) ST(S_A1U, a, A1u[a]), ST(S_VBU, a, Vbu[a]);
+#pragma unroll
+        for (int a = 0; a < NVU; ++a) ST(S_VCU, a, Vcu[a]);
+#pragma unroll
+        for (int a = 0; a < NCU; ++a) ST(S_A2U, a, A2u[a]);
         // the feed-forward term enters as t = Quu d (the rollout's operand carries Quu_inv, admm_mfmac.hip.h)
         if (kk < N - 1) {
 #pragma unroll
             for (int a = 0; a < NU; ++a) {
                 double acc = 0.0;
 #pragma unroll
-                for (int a2 = 0; a2 < NU; ++a2) acc = fma(gc64[T::O_QUU + a * NU + a2], dv[a2], acc);
+                for (int a2 = 0; a2 < NU; ++a2) acc = fma(gk64[T::O_QUU + a * NU + a2], dv[a2], acc);
                 c[U0 + a * 16] = (float)acc;
             }
         }
@@ -284,6 +387,14 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
         if (ok1) s_plant[j * NX + row1] = x0r[1];
     }
 
+    auto vbu0 = [&](int a) -> float { return sld(std::integral_constant<int, S_VBU>{}, std::integral_constant<int, 0>{}, a); };   // (group 0 is never the one in LDS)
+#ifdef TMPC_MFMAT_PROBE
+    // timing probe build (scripts/mfmat_cycles.py; the residuals then carry cycle counts, NOT residuals)
+    long long T_f = 0, T_s = 0, T_b = 0;
+#define TMPC_TPROBE(x) x
+#else
+#define TMPC_TPROBE(x)
+#endif
     int conv = 0, it = 0;
     float res0 = 0.f, res1 = 0.f, res2 = 0.f, res3 = 0.f;
     for (int step = 0; step < n_steps; ++step) {
@@ -301,78 +412,153 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
         const bool check = ct > 0 && itn % ct == 0;
         const bool need_res = check && (can_converge || itn == last_check_it);
         const bool last = itn == P.max_iter;
+        // the previous-slack registers take this iteration's slack where something reads it: the next iteration's
+        // residuals, or the solution (an instance can only leave at a check or at max_iter)
+        const bool check_next = ct > 0 && (itn + 1) % ct == 0 && itn < P.max_iter;
+        const bool upd_old = need_res || last || (check_next && (can_converge || itn + 1 == last_check_it));
+        TMPC_TPROBE(const long long tp0 = clock64();)
         // ================= rollout (admm.cpp:25-35), matrix layout =================
-        // x+ = (A - B Kinf) x - B Quu_inv t + f,  u = -Kinf x - Quu_inv t  with t = B'p + r kept by the backward sweep;
-        // the product with t does not depend on x: the one of step k + 1 is issued behind the x products of step k
+        // x+ = (A - B Kinf) x - B Quu_inv t + f,  u = -Kinf x - Quu_inv t  with t = B'p + r kept by the backward sweep.
+        // Step k:  c_k = [MF0 MF1] [x_k; t_k(matrix-core components)] + start_k,  start_k = f + (VALU columns) t_k(rest) with
+        // the passengers of step k + 1 in the slot-1 rows no state row owns.  The two products are issued back to back the
+        // moment the previous step's result registers — which ARE their operands — are there; then, while the matrix core
+        // runs them: the previous step's results are converted and handed to the sets (x_k, u_{k-1}), and the next step's
+        // start is formed (from cells read two steps ago) in the tuple they came from.  Two accumulator tuples swap roles
+        // from step to step; nothing is copied and no vector instruction stands between a result and the products that need it.
+        // Stores without lane masks (FREE): a lane without a row in slot 1 / 2 lands on its position's input cells / on the
+        // next position's first state cells; both are written — by the lanes that own them — AFTER it.
         {
-            auto t_product = [&](float t) -> mf_d4 {
-                mf_d4 c = {0.0, 0.0, 0.0, 0.0};
-                if constexpr (!ONE_COL) c[0] = cf[S::F_FD0], c[1] = cf[S::F_FD1];
-                return mf_mma(cf[S::F_MF2], (double)(one_lane ? 1.f : t), c);
+            constexpr int STEPS = N - 1;
+            lds_f *pp = cm;                                    // matrix-layout cell (position k, row g, instance j)
+            lds_f *const pu = (lds_f *)s_cells + j;            // + position * PLEN + row * 16
+            auto ldV = [&](int pos, float (&tv)[VUA]) {
+#pragma unroll
+                for (int v = 0; v < VU; ++v) tv[v] = pu[pos * PLEN + (NX + MU + v) * 16];
             };
-            lds_f *pp = cm;                                    // position k
-            pp[0] = (float)x0r[0];                             // knot 0 for the sets (x0 is given; the cell held the sets' sum)
-            if (ok1) pp[64] = (float)x0r[1];
-            float t0 = 0.f, t_next = 0.f;
-            if (ok2) t0 = pp[U0], t_next = pp[PLEN + U0];
-            mf_d4 cpre = t_product(t0);
-            double xa = x0r[0], xb = x0r[1];
-            for (int k = 0; k < N - 1; ++k) {
-                mf_d4 c = mf_mma(cf[S::F_MF0], xa, cpre);
-                if constexpr (XS == 2) c = mf_mma(cf[S::F_MF1], xb, c);
-                if (k + 1 < N - 1) {
-                    cpre = t_product(t_next);
-                    if (k + 2 < N - 1 && ok2) t_next = pp[2 * PLEN + U0];
-                }
-                xa = c[0], xb = c[1];
-                pp[PLEN] = (float)xa;                          // x_{k+1}
-                if (ok1) pp[PLEN + 64] = (float)xb;
-                if (ok2) pp[U0] = (float)c[2];                 // u_k (t_k is spent)
-                pp += PLEN;
+            auto ldB = [&](int pos) -> float { return pu[pos * PLEN + rowB * 16]; };
+            const double k_fd0 = kc(T::K_FD0), k_fd1 = kc(T::K_FD1);
+            double k_gf0[VUA], k_gf1[VUA], k_gf2[VUA];
+#pragma unroll
+            for (int v = 0; v < VUA; ++v) k_gf0[v] = kc(T::K_GF0 + v), k_gf1[v] = kc(T::K_GF1 + v), k_gf2[v] = kc(T::K_GF2 + v);
+            // the accumulator start of a step, written into the tuple in place (slot 3 — tile rows 12.. — stays the zero it is)
+            auto start = [&](mf_d4 &c, const double (&tvd)[VUA], double tb_next) {
+                double a0 = k_fd0, a1 = k_fd1, a2 = 0.0;
+#pragma unroll
+                for (int v = 0; v < VU; ++v) a0 = fma(k_gf0[v], tvd[v], a0), a1 = fma(k_gf1[v], tvd[v], a1), a2 = fma(k_gf2[v], tvd[v], a2);
+                if (!slot1_x) a1 = tb_next;                    // passenger: the next step's matrix-core component of t
+                c[0] = a0, c[1] = a1, c[2] = a2;
+            };
+            float tvn[VUA] = {0.f};
+            float tbn = 0.f;
+            ldV(0, tvn);
+            mf_d4 cX = {x0r[0], slot1_x ? x0r[1] : (double)ldB(0), 0.0, 0.0};
+            mf_d4 cY = {0.0, 0.0, 0.0, 0.0};
+            {
+                double tvd0[VUA];
+#pragma unroll
+                for (int v = 0; v < VUA; ++v) tvd0[v] = (double)tvn[v];
+                start(cY, tvd0, STEPS > 1 ? (double)ldB(1) : 0.0);
             }
+            if (STEPS > 1) ldV(1, tvn);
+            if (STEPS > 2) tbn = ldB(2);
+            auto handover = [&](const mf_d4 &c, bool has_u) {   // x_k (k = 0: x0 itself — the cell held the sets' sum), u_{k-1}
+                if (has_u && (FREE || ok2)) pp[U0 - PLEN] = (float)c[2];             // (t_{k-1} is spent)
+                if (FREE || ok1) pp[64] = (float)c[1];
+                pp[0] = (float)c[0];
+            };
+            // (order of a step, from experiments/mfmat_cost_probe.hip: an fp64 product holds the wavefront's issue for ~66 cycles
+            // whatever follows, and the FIRST vector / LDS instruction behind products costs a flat ~55 cycles more, the
+            // rest ~4 each — so the two products go back to back and ALL the vector work of the step in one block behind
+            // them; split around the second product it pays the flat cost twice: 281 against 255 cycles per step)
+            auto fstep = [&](int k, mf_d4 &cprev, mf_d4 &cacc) {
+                cacc = mf_mma(cf[T::L_MF0], cprev[0], cacc);
+                cacc = mf_mma(cf[T::L_MF1], cprev[1], cacc);
+                __builtin_amdgcn_sched_barrier(0);             // (left to itself the scheduler puts a hand-over in front of the products)
+                handover(cprev, k > 0);
+                if (k + 1 < STEPS) {
+                    double tvd[VUA];
+#pragma unroll
+                    for (int v = 0; v < VUA; ++v) tvd[v] = (double)tvn[v];
+                    start(cprev, tvd, (double)tbn);
+                    if (k + 2 < STEPS) ldV(k + 2, tvn);
+                    if (k + 3 < STEPS) tbn = ldB(k + 3);
+                }
+                pp += PLEN;
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            for (int k = 0; k + 1 < STEPS; k += 2) {
+                fstep(k, cX, cY);
+                fstep(k + 1, cY, cX);
+            }
+            if constexpr (STEPS % 2 == 1) {
+                fstep(STEPS - 1, cX, cY);
+                handover(cY, true);
+            } else {
+                handover(cX, true);
+            }
+            // (slot 3 of the tuples — tile rows 12.. — is never read; "used" here so that the register allocator does not
+            // park temporaries in it: a vector write into a tuple that a product in flight is about to overwrite waits for it)
+            asm volatile("" ::"v"(cX[3]), "v"(cY[3]));
         }
         __syncthreads();
+        TMPC_TPROBE(const long long tp1 = clock64(); T_f += tp1 - tp0;)
         // ================= the sets (admm.cpp:43-69) and the residual terms (admm.cpp:93-96), sets layout =================
         float pri_x = 0.f, dua_x = 0.f, pri_u = 0.f, dua_u = 0.f;
         int oxi = ox, oui = ou;
         asm volatile("" : "+v"(oxi), "+v"(oui));
         if (!conv) {                                           // a converged instance's state is frozen
             mf_for<0, NG>([&](auto mt) {
+                __builtin_amdgcn_sched_barrier(0);             // one group at a time: interleaved, their temporaries overflow the file
                 constexpr int m = decltype(mt)::value;
                 constexpr bool x_all = 4 * m + 3 < N, u_all = 4 * m + 3 < N - 1, u_any = 4 * m < N - 1;
                 const int kk = 4 * m + g;
                 lds_f *c = cq + m * 4 * PLEN;
                 if (x_all || kk < N) {
-                    float x[NX], sx[NX], vn[NX], vc[NVX];
+                    float x[NX], sx[NX], vn[NX], vc[NVX], rfx[NX], rfu[NU];
 #pragma unroll
                     for (int r = 0; r < NX; ++r) x[r] = c[r * 16];
+                    // reference parts of the linear cost (admm.cpp:77-80; the terminal knot's enters through Pinf, :81-82)
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) {
+                        rfx[r] = 0.f;
+                        if constexpr (REFS == REF_SHARED) {
+                            rfx[r] = s_ref[kk * NROW + r];
+                            if (4 * m + 3 >= N - 1 && kk == N - 1) rfx[r] = 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int a = 0; a < NU; ++a) {
+                        rfu[a] = 0.f;
+                        if constexpr (REFS == REF_SHARED) rfu[a] = s_ref[kk * NROW + NX + a];   // (the cell behind the last knot's is zero)
+                    }
 #pragma unroll
                     for (int r = 0; r < NX; ++r) {
                         const float lo = BV ? s_bnd[kk * 2 * NROW + r] : lo_s[r], hi = BV ? s_bnd[kk * 2 * NROW + NROW + r] : hi_s[r];
-                        const float w = x[r] + a1x[m][r];
+                        const float w = x[r] + LD(S_A1X, r);
                         vn[r] = __builtin_amdgcn_fmed3f(w, lo, hi);                  // admm.cpp:52-56
-                        a1x[m][r] = w - vn[r];                                       // admm.cpp:68
-                        sx[r] = vn[r] - a1x[m][r];
+                        const float an = w - vn[r];                                  // admm.cpp:68
+                        ST(S_A1X, r, an);
+                        sx[r] = vn[r] - an;
                     }
                     if constexpr (CXQ > 0) {
                         // every state row carries the cone set's slack and dual (the solver's arrays are full size); for a row
                         // outside the cone the "projection" is the identity: slack = x, the dual stays zero
-                        float w2[NCX];
+                        float w2[NCX], a2n[NCX];
 #pragma unroll
                         for (int r = 0; r < NX; ++r) vc[r] = x[r];
 #pragma unroll
-                        for (int c2 = 0; c2 < CXQ; ++c2) w2[c2] = x[CXA + c2] + a2x[m][c2], vc[CXA + c2] = w2[c2];
+                        for (int c2 = 0; c2 < CXQ; ++c2) w2[c2] = x[CXA + c2] + LD(S_A2X, c2), vc[CXA + c2] = w2[c2];
                         float sc, ax_new;
                         cone_scale(head_norm2(vc, CXA, CXQ), vc[CXA + CXQ - 1], mux, rmux, sc, ax_new);
 #pragma unroll
                         for (int c2 = 0; c2 < CXQ - 1; ++c2) vc[CXA + c2] *= sc;
                         vc[CXA + CXQ - 1] = ax_new;
 #pragma unroll
-                        for (int c2 = 0; c2 < CXQ; ++c2) a2x[m][c2] = w2[c2] - vc[CXA + c2];
+                        for (int c2 = 0; c2 < CXQ; ++c2) a2n[c2] = w2[c2] - vc[CXA + c2], ST(S_A2X, c2, a2n[c2]);
 #pragma unroll
                         for (int r = 0; r < NX; ++r) {
                             const bool in = r >= CXA && r < CXA + CXQ;
-                            sx[r] += in ? vc[r] - a2x[m][in ? r - CXA : 0] : x[r];
+                            sx[r] += in ? vc[r] - a2n[in ? r - CXA : 0] : x[r];
                         }
                     }
                     if (need_res) {
@@ -380,13 +566,13 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
 #pragma unroll
                         for (int r = 0; r < NX; ++r) {
                             gp = fmaxf(gp, fabsf(x[r] - vn[r]));
-                            gd = fmaxf(gd, fabsf(vbx[m][r] - vn[r]));
+                            gd = fmaxf(gd, fabsf(LD(S_VBX, r) - vn[r]));
                         }
                         if constexpr (CXQ > 0) {
 #pragma unroll
                             for (int r = 0; r < NX; ++r) {
                                 if (r >= CXA && r < CXA + CXQ) gp = fmaxf(gp, fabsf(x[r] - vc[r]));
-                                gd = fmaxf(gd, fabsf(vcx[m][r] - vc[r]));
+                                gd = fmaxf(gd, fabsf(LD(S_VCX, r) - vc[r]));
                             }
                         }
                         pri_x = fmaxf(pri_x, gp), dua_x = fmaxf(dua_x, gd);
@@ -394,19 +580,23 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
                             kparam_ptr Pk = kparams();
                             float *pv = Pk->sv + oxi + m * 4 * NX;
 #pragma unroll
-                            for (int r = 0; r < NX; ++r) pv[r] = vbx[m][r];
+                            for (int r = 0; r < NX; ++r) pv[r] = LD(S_VBX, r);
                             if constexpr (CXQ > 0) {
                                 float *pvc = Pk->svc + oxi + m * 4 * NX;
 #pragma unroll
-                                for (int r = 0; r < NX; ++r) pvc[r] = vcx[m][r];
+                                for (int r = 0; r < NX; ++r) pvc[r] = LD(S_VCX, r);
                             }
                         }
                     }
 #pragma unroll
                     for (int r = 0; r < NX; ++r) {
-                        vbx[m][r] = vn[r];
-                        if constexpr (CXQ > 0) vcx[m][r] = vc[r];
-                        c[r * 16] = sx[r];
+                        if (upd_old) {
+                            ST(S_VBX, r, vn[r]);
+                            if constexpr (CXQ > 0) ST(S_VCX, r, vc[r]);
+                        }
+                        // what the backward sweep needs of this row is the linear-cost term (admm.cpp:79-80), not the sum
+                        // itself: q = -(Xref Q~) - rho (sum over sets of slack - dual)
+                        c[r * 16] = rfx[r] - rho * sx[r];
                     }
                     if constexpr (u_any) {
                         if (u_all || kk < N - 1) {
@@ -417,28 +607,29 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
                             for (int a = 0; a < NU; ++a) {
                                 const float lo = BV ? s_bnd[kk * 2 * NROW + NX + a] : lo_s[NX + a],
                                             hi = BV ? s_bnd[kk * 2 * NROW + NROW + NX + a] : hi_s[NX + a];
-                                const float w = u[a] + a1u[m][a];
+                                const float w = u[a] + LD(S_A1U, a);
                                 zn[a] = __builtin_amdgcn_fmed3f(w, lo, hi);
-                                a1u[m][a] = w - zn[a];
-                                su[a] = zn[a] - a1u[m][a];
+                                const float an = w - zn[a];
+                                ST(S_A1U, a, an);
+                                su[a] = zn[a] - an;
                             }
                             if constexpr (CUQ > 0) {
-                                float w2[NCU];
+                                float w2[NCU], a2n[NCU];
 #pragma unroll
                                 for (int a = 0; a < NU; ++a) zc[a] = u[a];
 #pragma unroll
-                                for (int c2 = 0; c2 < CUQ; ++c2) w2[c2] = u[CUA + c2] + a2u[m][c2], zc[CUA + c2] = w2[c2];
+                                for (int c2 = 0; c2 < CUQ; ++c2) w2[c2] = u[CUA + c2] + LD(S_A2U, c2), zc[CUA + c2] = w2[c2];
                                 float sc, ax_new;
                                 cone_scale(head_norm2(zc, CUA, CUQ), zc[CUA + CUQ - 1], muu, rmuu, sc, ax_new);
 #pragma unroll
                                 for (int c2 = 0; c2 < CUQ - 1; ++c2) zc[CUA + c2] *= sc;
                                 zc[CUA + CUQ - 1] = ax_new;
 #pragma unroll
-                                for (int c2 = 0; c2 < CUQ; ++c2) a2u[m][c2] = w2[c2] - zc[CUA + c2];
+                                for (int c2 = 0; c2 < CUQ; ++c2) a2n[c2] = w2[c2] - zc[CUA + c2], ST(S_A2U, c2, a2n[c2]);
 #pragma unroll
                                 for (int a = 0; a < NU; ++a) {
                                     const bool in = a >= CUA && a < CUA + CUQ;
-                                    su[a] += in ? zc[a] - a2u[m][in ? a - CUA : 0] : u[a];
+                                    su[a] += in ? zc[a] - a2n[in ? a - CUA : 0] : u[a];
                                 }
                             }
                             if (need_res) {
@@ -446,13 +637,13 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
 #pragma unroll
                                 for (int a = 0; a < NU; ++a) {
                                     gp = fmaxf(gp, fabsf(u[a] - zn[a]));
-                                    gd = fmaxf(gd, fabsf(vbu[m][a] - zn[a]));
+                                    gd = fmaxf(gd, fabsf(LD(S_VBU, a) - zn[a]));
                                 }
                                 if constexpr (CUQ > 0) {
 #pragma unroll
                                     for (int a = 0; a < NU; ++a) {
                                         if (a >= CUA && a < CUA + CUQ) gp = fmaxf(gp, fabsf(u[a] - zc[a]));
-                                        gd = fmaxf(gd, fabsf(vcu[m][a] - zc[a]));
+                                        gd = fmaxf(gd, fabsf(LD(S_VCU, a) - zc[a]));
                                     }
                                 }
                                 pri_u = fmaxf(pri_u, gp), dua_u = fmaxf(dua_u, gd);
@@ -460,27 +651,29 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
                                     kparam_ptr Pk = kparams();
                                     float *pz = Pk->sz + oui + m * 4 * NU, *pd = Pk->sd + oui + m * 4 * NU;
 #pragma unroll
-                                    for (int a = 0; a < NU; ++a) pz[a] = vbu[m][a];
+                                    for (int a = 0; a < NU; ++a) pz[a] = LD(S_VBU, a);
                                     if constexpr (CUQ > 0) {
                                         float *pzc = Pk->szc + oui + m * 4 * NU;
 #pragma unroll
-                                        for (int a = 0; a < NU; ++a) pzc[a] = vcu[m][a];
+                                        for (int a = 0; a < NU; ++a) pzc[a] = LD(S_VCU, a);
                                     }
                                     // the feed-forward term this iteration's rollout used: d = -Kinf x - u (admm.cpp:29)
 #pragma unroll
                                     for (int a = 0; a < NU; ++a) {
                                         double acc = 0.0;
 #pragma unroll
-                                        for (int r = 0; r < NX; ++r) acc = fma(gc64[T::O_KINF + a * NX + r], (double)x[r], acc);
+                                        for (int r = 0; r < NX; ++r) acc = fma(gk64[T::O_KINF + a * NX + r], (double)x[r], acc);
                                         pd[a] = (float)(-acc - (double)u[a]);
                                     }
                                 }
                             }
 #pragma unroll
                             for (int a = 0; a < NU; ++a) {
-                                vbu[m][a] = zn[a];
-                                if constexpr (CUQ > 0) vcu[m][a] = zc[a];
-                                c[U0 + a * 16] = su[a];
+                                if (upd_old) {
+                                    ST(S_VBU, a, zn[a]);
+                                    if constexpr (CUQ > 0) ST(S_VCU, a, zc[a]);
+                                }
+                                c[U0 + a * 16] = rfu[a] - rho * su[a];                   // r = -(Uref R~) - rho (...), admm.cpp:77-78
                             }
                         }
                     }
@@ -488,6 +681,7 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
             });
         }
         __syncthreads();
+        TMPC_TPROBE(const long long tp2 = clock64(); T_s += tp2 - tp1;)
         // ================= termination (admm.cpp:89-107, :181-193), per instance =================
         if (!conv) it = itn;
         if (need_res) {
@@ -501,63 +695,89 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
         if (!any_left || (last && !keep)) break;               // (a one-shot solve has no use for the last backward sweep)
         // ================= fused backward sweep (admm.cpp:75-83, :13-20), matrix layout =================
         // stage kn: p_kn = q_kn + AmBKt p_{kn+1} - Kinf' r_kn (+ AmBKt Pinf f),  t_kn = B' p_{kn+1} + r_kn (+ B' Pinf f) with
-        // q_kn = -(Xref Q~) - rho s_x(kn), r_kn = -(Uref R~) - rho s_u(kn); only the products with p are on the recurrence: a
-        // stage's accumulator start {q, r} and its product with r are formed and issued one stage ahead, behind the previous
-        // stage's p products, from operands read two stages ahead
+        // q_kn = -(Xref Q~) - rho s_x(kn), r_kn = -(Uref R~) - rho s_u(kn).  As in the rollout: two products per stage on
+        // [p_{kn+1}; r_kn(matrix-core components)], the rest of r_kn and the constants in the accumulator's start, the
+        // passengers r_{kn-1} riding in it; the start of stage kn - 1 is formed under the products of stage kn from cells
+        // read a stage earlier, t_{kn+1} goes to its cell there too.
         {
-            lds_f *qp = cm + (N - 1) * PLEN;                   // position of the operands read next
-            double p[2];
+            lds_f *const pc = (lds_f *)s_cells + j;            // + position * PLEN + row * 16
+            const int row1c = slot1_x ? row1 : g;              // (a passenger lane re-reads its slot-0 row: the value is not used)
+            auto lin = [&](int kn, int row) -> float { return pc[kn * PLEN + row * 16]; };   // q / r of a row at a knot (the sets left it)
+            struct Ops {
+                float q0, q1, ra, rb, rv[VUA];
+            };
+            auto operands = [&](int kn) -> Ops {               // of the start of stage kn (passenger: r_{kn-1})
+                Ops o;
+                o.q0 = lin(kn, g), o.q1 = lin(kn, row1c), o.ra = lin(kn, rowA);
+                o.rb = kn >= 1 ? lin(kn - 1, rowB) : 0.f;
+#pragma unroll
+                for (int v = 0; v < VUA; ++v) o.rv[v] = v < VU ? lin(kn, NX + MU + v) : 0.f;
+                return o;
+            };
+            const double k_apf0 = kc(T::K_APF0), k_apf1 = kc(T::K_APF1), k_bpf = kc(T::K_BPF);
+            double k_gb0[VUA], k_gb1[VUA];
+#pragma unroll
+            for (int v = 0; v < VUA; ++v) k_gb0[v] = kc(T::K_GB0 + v), k_gb1[v] = kc(T::K_GB1 + v);
+            struct OpsD {
+                double q0, q1, ra, rb, rv[VUA];
+            };
+            auto widen = [&](const Ops &o) -> OpsD {
+                OpsD d;
+                d.q0 = (double)o.q0, d.q1 = (double)o.q1, d.ra = (double)o.ra, d.rb = (double)o.rb;
+#pragma unroll
+                for (int v = 0; v < VUA; ++v) d.rv[v] = (double)o.rv[v];
+                return d;
+            };
+            auto start = [&](mf_d4 &c, const OpsD &o) {
+                double a0 = o.q0 + k_apf0, a1 = o.q1 + k_apf1, a2 = o.ra + k_bpf;
+#pragma unroll
+                for (int v = 0; v < VU; ++v) a0 = fma(k_gb0[v], o.rv[v], a0), a1 = fma(k_gb1[v], o.rv[v], a1);
+                if (!slot1_x) a1 = o.rb;                       // passenger: the next stage's matrix-core component of r
+                c[0] = a0, c[1] = a1, c[2] = a2;
+            };
+            mf_d4 cX, cY;
             {
                 double pt0 = 0.0, pt1 = 0.0;
-                if constexpr (REFS == REF_SHARED) {
-                    pt0 = s_pterm[g];
-                    pt1 = ok1 ? s_pterm[row1] : 0.0;
-                }
-                float s0 = qp[0], s1 = 0.f;
-                if (ok1) s1 = qp[64];
-                p[0] = pt0 - (double)(rho * s0);                                     // admm.cpp:81-82
-                p[1] = pt1 - (double)(rho * s1);
+                if constexpr (REFS == REF_SHARED) pt0 = s_pterm[g], pt1 = s_pterm[row1c];
+                const double p0 = pt0 + (double)pc[(N - 1) * PLEN + g * 16];                   // admm.cpp:81-82
+                const double p1 = pt1 + (double)pc[(N - 1) * PLEN + row1c * 16];
+                cX = mf_d4{p0, slot1_x ? p1 : (double)lin(N - 2, rowB), 0.0, 0.0};
             }
-            auto stage_operands = [&](int kn, float (&sv)[3], float (&rf)[3]) {      // s and reference terms of knot kn
-                qp -= PLEN;
-                sv[0] = qp[0];
-                sv[1] = 0.f, sv[2] = 0.f;
-                if (ok1) sv[1] = qp[64];
-                if (ok2) sv[2] = qp[U0];
-                rf[0] = rf[1] = rf[2] = 0.f;
-                if constexpr (REFS == REF_SHARED) {
-                    rf[0] = s_ref[kn * NROW + g];
-                    if (ok1) rf[1] = s_ref[kn * NROW + row1];
-                    if (ok2) rf[2] = s_ref[kn * NROW + NX + g];
-                }
-            };
-            auto stage_start = [&](int kn, const float (&sv)[3], const float (&rf)[3]) -> mf_d4 {
-                const double r_in = (double)(rf[2] - rho * sv[2]);                   // admm.cpp:77-78
-                mf_d4 c = {(double)(rf[0] - rho * sv[0]), (double)(rf[1] - rho * sv[1]), r_in, 0.0};   // admm.cpp:79-80
-                if (kn == 0) c[0] = c[1] = 0.0;                                      // q_0 enters p_0 only, which nothing reads
-                if constexpr (!ONE_COL) c[0] += cf[S::F_APF0], c[1] += cf[S::F_APF1], c[2] += cf[S::F_BPF];
-                return mf_mma(cf[S::F_MB2], one_lane ? 1.0 : r_in, c);               // [-Kinf^T; 0] r
-            };
-            float sv[3], rf[3];
-            stage_operands(N - 2, sv, rf);
-            mf_d4 cpre = stage_start(N - 2, sv, rf);
-            if (N >= 3) stage_operands(N - 3, sv, rf);
-            lds_f *tw = cm + (N - 2) * PLEN + U0;                                    // where t of the stage's knot goes
-            for (int kn = N - 2; kn >= 0; --kn) {
-                mf_d4 c = mf_mma(cf[S::F_MB0], p[0], cpre);                          // + [AmBKt; B^T] p
-                if constexpr (XS == 2) c = mf_mma(cf[S::F_MB1], p[1], c);
+            cY = mf_d4{0.0, 0.0, 0.0, 0.0};
+            start(cY, widen(operands(N - 2)));
+            Ops on = operands(N >= 3 ? N - 3 : 0);
+            lds_f *const tw = cm + U0;                                               // + position * PLEN: the cell of a knot's t
+            const bool tmask = ok2 && !conv;                                         // (a converged instance keeps its feed-forward term)
+            auto bstage = [&](int kn, mf_d4 &cprev, mf_d4 &cacc) {
+                cacc = mf_mma(cf[T::L_MB0], cprev[0], cacc);                         // [AmBKt; B'] p (+ -Kinf' r)
+                cacc = mf_mma(cf[T::L_MB1], cprev[1], cacc);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kn < N - 2 && tmask) tw[(kn + 1) * PLEN] = (float)cprev[2];      // t_{kn+1}
                 if (kn >= 1) {
-                    cpre = stage_start(kn - 1, sv, rf);
-                    if (kn >= 2) stage_operands(kn - 2, sv, rf);
+                    start(cprev, widen(on));
+                    if (kn >= 2) on = operands(kn - 2);
                 }
-                p[0] = c[0], p[1] = c[1];
-                if (ok2 && !conv) *tw = (float)c[2];                                 // (a converged instance keeps its feed-forward term)
-                tw -= PLEN;
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            // (unrolled: the cell addresses are immediates and the edge conditions fold)
+#pragma unroll
+            for (int i = 0; i < (N - 1) / 2; ++i) {
+                bstage(N - 2 - 2 * i, cX, cY);
+                bstage(N - 3 - 2 * i, cY, cX);
             }
+            if constexpr ((N - 1) % 2 == 1) {
+                bstage(0, cX, cY);
+                if (tmask) tw[0] = (float)cY[2];                                     // t_0
+            } else {
+                if (tmask) tw[0] = (float)cX[2];
+            }
+            asm volatile("" ::"v"(cX[3]), "v"(cY[3]));
         }
         __syncthreads();
+        TMPC_TPROBE(T_b += clock64() - tp2;)
         if (last) break;
     }
+    TMPC_TPROBE(res0 = (float)T_f / (float)P.max_iter; res1 = (float)T_s / (float)P.max_iter; res2 = (float)T_b / (float)P.max_iter; res3 = 0.f;)
 
     // ================= results of the solve =================
     if (P.mpc_steps > 0) {
@@ -569,11 +789,11 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
             double xn[NX];
 #pragma unroll
             for (int r = 0; r < NX; ++r) {
-                double acc = gc64[T::O_F + r];
+                double acc = gk64[T::O_F + r];
 #pragma unroll
-                for (int c = 0; c < NX; ++c) acc = fma(gc64[T::O_A + r * NX + c], s_plant[j * NX + c], acc);
+                for (int c = 0; c < NX; ++c) acc = fma(gk64[T::O_A + r * NX + c], s_plant[j * NX + c], acc);
 #pragma unroll
-                for (int a = 0; a < NU; ++a) acc = fma(gc64[T::O_B + r * NU + a], (double)vbu[0][a], acc);
+                for (int a = 0; a < NU; ++a) acc = fma(gk64[T::O_B + r * NU + a], (double)vbu0(a), acc);
                 xn[r] = acc;
             }
 #pragma unroll
@@ -583,7 +803,7 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
             }
             if (active) {
 #pragma unroll
-                for (int a = 0; a < NU; ++a) Pe->mpc_u[so * NU + a] = vbu[0][a];
+                for (int a = 0; a < NU; ++a) Pe->mpc_u[so * NU + a] = vbu0(a);
                 Pe->mpc_iter[so] = conv ? it : -it;
             }
         }
@@ -601,30 +821,43 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
     // the projected slack of the last executed iteration is the solution (admm.cpp:187-188,204-205)
     kparam_ptr Pe = kparams();
     mf_for<0, NG>([&](auto mt) {
+        float A1x[NX], A2x[NCX], Vbx[NX], Vcx[NVX], A1u[NU], A2u[NCU], Vbu[NU], Vcu[NVU];
+#pragma unroll
+        for (int r = 0; r < NX; ++r) A1x[r] = LD(S_A1X, r), Vbx[r] = LD(S_VBX, r);
+#pragma unroll
+        for (int r = 0; r < NVX; ++r) Vcx[r] = LD(S_VCX, r);
+#pragma unroll
+        for (int r = 0; r < NCX; ++r) A2x[r] = LD(S_A2X, r);
+#pragma unroll
+        for (int a = 0; a < NU; ++a) A1u[a] = LD(S_A1U, a), Vbu[a] = LD(S_VBU, a);
+#pragma unroll
+        for (int a = 0; a < NVU; ++a) Vcu[a] = LD(S_VCU, a);
+#pragma unroll
+        for (int a = 0; a < NCU; ++a) A2u[a] = LD(S_A2U, a);
         constexpr int m = decltype(mt)::value;
         const int kk = 4 * m + g;
         lds_f *c = cq + m * 4 * PLEN;
         if (active && kk < N) {
             float *po = Pe->xout + ox + m * 4 * NX;
 #pragma unroll
-            for (int r = 0; r < NX; ++r) po[r] = vbx[m][r];
+            for (int r = 0; r < NX; ++r) po[r] = Vbx[r];
             if (keep) {
                 float *pg = Pe->sg + ox + m * 4 * NX;
 #pragma unroll
-                for (int r = 0; r < NX; ++r) pg[r] = a1x[m][r];
+                for (int r = 0; r < NX; ++r) pg[r] = A1x[r];
                 if constexpr (CXQ > 0) {
                     float *pgc = Pe->sgc + ox + m * 4 * NX;
 #pragma unroll
-                    for (int c2 = 0; c2 < CXQ; ++c2) pgc[CXA + c2] = a2x[m][c2];
+                    for (int c2 = 0; c2 < CXQ; ++c2) pgc[CXA + c2] = A2x[c2];
                 }
                 if (!conv) {                                   // (a converged instance parked the slack of the iteration before)
                     float *pv = Pe->sv + ox + m * 4 * NX;
 #pragma unroll
-                    for (int r = 0; r < NX; ++r) pv[r] = vbx[m][r];
+                    for (int r = 0; r < NX; ++r) pv[r] = Vbx[r];
                     if constexpr (CXQ > 0) {
                         float *pvc = Pe->svc + ox + m * 4 * NX;
 #pragma unroll
-                        for (int r = 0; r < NX; ++r) pvc[r] = vcx[m][r];
+                        for (int r = 0; r < NX; ++r) pvc[r] = Vcx[r];
                     }
                 }
             }
@@ -632,24 +865,24 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
         if (active && kk < N - 1) {
             float *po = Pe->uout + ou + m * 4 * NU;
 #pragma unroll
-            for (int a = 0; a < NU; ++a) po[a] = vbu[m][a];
+            for (int a = 0; a < NU; ++a) po[a] = Vbu[a];
             if (keep) {
                 float *py = Pe->sy + ou + m * 4 * NU;
 #pragma unroll
-                for (int a = 0; a < NU; ++a) py[a] = a1u[m][a];
+                for (int a = 0; a < NU; ++a) py[a] = A1u[a];
                 if constexpr (CUQ > 0) {
                     float *pyc = Pe->syc + ou + m * 4 * NU;
 #pragma unroll
-                    for (int c2 = 0; c2 < CUQ; ++c2) pyc[CUA + c2] = a2u[m][c2];
+                    for (int c2 = 0; c2 < CUQ; ++c2) pyc[CUA + c2] = A2u[c2];
                 }
                 if (!conv) {
                     float *pz = Pe->sz + ou + m * 4 * NU, *pd = Pe->sd + ou + m * 4 * NU;
 #pragma unroll
-                    for (int a = 0; a < NU; ++a) pz[a] = vbu[m][a];
+                    for (int a = 0; a < NU; ++a) pz[a] = Vbu[a];
                     if constexpr (CUQ > 0) {
                         float *pzc = Pe->szc + ou + m * 4 * NU;
 #pragma unroll
-                        for (int a = 0; a < NU; ++a) pzc[a] = vcu[m][a];
+                        for (int a = 0; a < NU; ++a) pzc[a] = Vcu[a];
                     }
                     double tv[NU];                             // d = Quu_inv t of the last backward sweep (admm.cpp:17)
 #pragma unroll
@@ -658,7 +891,7 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
                     for (int a = 0; a < NU; ++a) {
                         double acc = 0.0;
 #pragma unroll
-                        for (int a2 = 0; a2 < NU; ++a2) acc = fma(gc64[T::O_QUI + a * NU + a2], tv[a2], acc);
+                        for (int a2 = 0; a2 < NU; ++a2) acc = fma(gk64[T::O_QUI + a * NU + a2], tv[a2], acc);
                         pd[a] = (float)acc;
                     }
                 }
@@ -690,4 +923,7 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
     }
 }
 
+#undef LD
+#undef ST
+#undef TMPC_TPROBE
 }  // namespace tmpc

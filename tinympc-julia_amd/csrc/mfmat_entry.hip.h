@@ -6,15 +6,81 @@
 
 namespace tmpc {
 
-// lane fields + Pinf as mfmac, then Quu, Quu_inv, Kinf, A, B (row-major) and f: what the sets layout needs for the
-// workspace's feed-forward term (t = Quu d, d = Quu_inv t, d = -Kinf x - u) and the closed loop's plant step
+// The operand pack of the transposed-sets kernel (layout: TransShape).  Lane l supplies, for the 16 x 4 A operand of a
+// slot, tile row l % 16 and K column l / 16 of the slot; tile rows 0..7 are state rows, 8 + a input rows (as everywhere in
+// the matrix-core kernels); K columns 0..3 of slot 0 are x_0..x_3, those of slot 1 x_4..x_{nx-1} followed by the first MU
+// input components.  Behind the lane fields: the per-lane-group constants (affine terms; the columns of the VU input
+// components that are multiplied on the VALU), then what the sets layout needs for the workspace's feed-forward term
+// (t = Quu d, d = Quu_inv t, d = -Kinf x - u) and the closed loop's plant step.
 template <int NX, int NU, int N>
 void build_mfmat_coef(const Solver &sv, std::vector<unsigned char> &out) {
     using T = TransShape<NX, NU, N>;
-    build_mfmac_coef<NX, NU>(sv, out);
-    out.resize((size_t)T::COEF_DOUBLES * sizeof(double), 0);
+    constexpr int MU = T::MU, VU = T::VU;
+    out.assign((size_t)T::COEF_DOUBLES * sizeof(double), 0);
     double *o = reinterpret_cast<double *>(out.data());
     const Cache &c = sv.cache;
+    double Pf[NX], APf[NX], BPf[NU], ABK[NX][NX], BQ[NX][NU];
+    for (int i = 0; i < NX; ++i) {
+        Pf[i] = 0.0;
+        for (int k = 0; k < NX; ++k) Pf[i] += c.Pinf(i, k) * sv.fdyn[k];
+    }
+    for (int i = 0; i < NX; ++i) {
+        APf[i] = 0.0;
+        for (int k = 0; k < NX; ++k) APf[i] += c.AmBKt(i, k) * Pf[k];
+    }
+    for (int a = 0; a < NU; ++a) {
+        BPf[a] = 0.0;
+        for (int k = 0; k < NX; ++k) BPf[a] += sv.B(k, a) * Pf[k];
+    }
+    for (int i = 0; i < NX; ++i) {
+        for (int k = 0; k < NX; ++k) {
+            ABK[i][k] = sv.A(i, k);                    // A - B Kinf from A, B, Kinf themselves (set_cache_terms may hand in an
+            for (int a = 0; a < NU; ++a) ABK[i][k] -= sv.B(i, a) * c.Kinf(a, k);   // AmBKt that differs)
+        }
+        for (int a = 0; a < NU; ++a) {
+            BQ[i][a] = 0.0;
+            for (int b = 0; b < NU; ++b) BQ[i][a] += sv.B(i, b) * c.Quu_inv(b, a);   // B Quu_inv
+        }
+    }
+    const bool fd = sv.has_fdyn;
+    for (int l = 0; l < 64; ++l) {
+        const int m = l % 16, kq = l / 16;
+        const bool mx = m < 8 && m < NX, mu = m >= 8 && m - 8 < NU;
+        // slot 0: x_kq
+        if (kq < NX) {
+            o[T::L_MF0 * 64 + l] = mx ? ABK[m][kq] : (mu ? -c.Kinf(m - 8, kq) : 0.0);
+            o[T::L_MB0 * 64 + l] = mx ? c.AmBKt(m, kq) : (mu ? sv.B(kq, m - 8) : 0.0);
+        }
+        // slot 1: x_{4+kq}, or input component 4 + kq - NX
+        const int col = 4 + kq;
+        if (col < NX) {
+            o[T::L_MF1 * 64 + l] = mx ? ABK[m][col] : (mu ? -c.Kinf(m - 8, col) : 0.0);
+            o[T::L_MB1 * 64 + l] = mx ? c.AmBKt(m, col) : (mu ? sv.B(col, m - 8) : 0.0);
+        } else if (col - NX < MU) {
+            const int a = col - NX;
+            o[T::L_MF1 * 64 + l] = mx ? -BQ[m][a] : (mu ? -c.Quu_inv(m - 8, a) : 0.0);
+            o[T::L_MB1 * 64 + l] = mx ? -c.Kinf(a, m) : 0.0;
+        }
+    }
+    double *kc = o + T::O_KC;
+    for (int g = 0; g < 4; ++g) {
+        const bool x1 = 4 + g < NX, ug = g < NU;
+        kc[T::K_FD0 * 4 + g] = fd ? sv.fdyn[g] : 0.0;
+        kc[T::K_FD1 * 4 + g] = fd && x1 ? sv.fdyn[4 + g] : 0.0;
+        kc[T::K_APF0 * 4 + g] = fd ? APf[g] : 0.0;
+        kc[T::K_APF1 * 4 + g] = fd && x1 ? APf[4 + g] : 0.0;
+        kc[T::K_BPF * 4 + g] = fd && ug ? BPf[g] : 0.0;
+        for (int v = 0; v < VU; ++v) {
+            const int a = MU + v;
+            kc[(T::K_GF0 + v) * 4 + g] = -BQ[g][a];
+            kc[(T::K_GF1 + v) * 4 + g] = x1 ? -BQ[4 + g][a] : 0.0;
+            kc[(T::K_GF2 + v) * 4 + g] = ug ? -c.Quu_inv(g, a) : 0.0;
+            kc[(T::K_GB0 + v) * 4 + g] = -c.Kinf(a, g);
+            kc[(T::K_GB1 + v) * 4 + g] = x1 ? -c.Kinf(a, 4 + g) : 0.0;
+        }
+    }
+    for (int i = 0; i < NX; ++i)
+        for (int k = 0; k < NX; ++k) o[T::O_PINF + i * NX + k] = c.Pinf(i, k);
     // Quu = Quu_inv^-1 (Gauss-Jordan with partial pivoting, nu <= 4)
     double M[NU][2 * NU];
     for (int a = 0; a < NU; ++a)
@@ -46,9 +112,10 @@ void build_mfmat_coef(const Solver &sv, std::vector<unsigned char> &out) {
     }
 }
 
-template <int NX, int NU, int N>
+template <int NX, int NU, int N, int CXQ, int CUQ>
 size_t mfmat_lds_bytes(const Solver &sv) {
-    return TransShape<NX, NU, N>::lds_bytes(mfmac_bounds_vary(sv) ? N : 1);
+    const bool cx = sv.st.en_state_soc && sv.ncx > 0, cu = sv.st.en_input_soc && sv.ncu > 0;
+    return TransShape<NX, NU, N>::lds_bytes(mfmac_bounds_vary(sv) ? N : 1, cx ? CXQ : 0, cu ? CUQ : 0);
 }
 
 inline size_t mfmat_scratch_floats(const Solver &) { return 1; }   // nothing of the iterated state goes through HBM
@@ -104,7 +171,7 @@ hipError_t launch_mfmat(const AdmmParams &P, bool ext, size_t lds, hipStream_t s
 #define TMPC_DEFINE_MFMAT_ENTRY(NX, NU, N, CXA, CXQ, CUA, CUQ, PLAIN)                                                            \
     const ConeEntry *mfmat_entry_##NX##_##NU##_##N() {                                                                           \
         static const ConeEntry e = {NX, NU, N, &mfmat_supports<CXA, CXQ, CUA, CUQ>, PLAIN, "mfmat<" #NX "," #NU "," #N ">",          \
-                                    &build_mfmat_coef<NX, NU, N>, &build_mfmac_bounds<NX, NU>, &mfmat_lds_bytes<NX, NU, N>,         \
+                                    &build_mfmat_coef<NX, NU, N>, &build_mfmac_bounds<NX, NU>, &mfmat_lds_bytes<NX, NU, N, CXQ, CUQ>,         \
                                     [](const Solver &s) { return mfmat_scratch_floats(s); }, &mfmac_bounds_vary,                   \
                                     &launch_mfmat<NX, NU, N, CXA, CXQ, CUA, CUQ>, true};                                          \
         return &e;                                                                                                               \
