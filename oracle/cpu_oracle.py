@@ -196,6 +196,18 @@ class CpuSolver:
         a = [_f(m) for m in (d, y, g, v, z)]
         self._call("set_state", *[_dp(m) for m in a])
 
+    def get_cone_state(self):
+        """the cone sets' part of the workspace (restatement only): duals gc, yc and previous slack vc, zc"""
+        nx, nu, N = self.nx, self.nu, self.N
+        gc, vc = np.zeros((nx, N), order="F"), np.zeros((nx, N), order="F")
+        yc, zc = np.zeros((nu, N - 1), order="F"), np.zeros((nu, N - 1), order="F")
+        self._call("get_cone_state", _dp(gc), _dp(vc), _dp(yc), _dp(zc))
+        return dict(gc=gc, vc=vc, yc=yc, zc=zc)
+
+    def set_cone_state(self, gc, vc, yc, zc):
+        a = [_f(m) for m in (gc, vc, yc, zc)]
+        self._call("set_cone_state", *[_dp(m) for m in a])
+
     def get_state(self):
         nx, nu, N = self.nx, self.nu, self.N
         d = np.zeros((nu, N - 1), order="F")

@@ -54,6 +54,9 @@ extern "C" {
     void P##get_state(void *h, double *d, double *y, double *g, double *v, double *z);         \
     void P##set_state(void *h, const double *d, const double *y, const double *g,             \
                       const double *v, const double *z);                                      \
+    void P##get_cone_state(void *h, double *gc, double *vc, double *yc, double *zc);           \
+    void P##set_cone_state(void *h, const double *gc, const double *vc, const double *yc,      \
+                           const double *zc);                                                 \
     double P##solve_batch(const double *A, const double *B, const double *Q, const double *R, \
                           double rho, int nx, int nu, int N, const double *xmin,              \
                           const double *xmax, const double *umin, const double *umax,         \

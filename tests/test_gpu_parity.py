@@ -783,13 +783,19 @@ def _oracle_rocket(oracle_built, prob, x0, xr, ur, fdyn, cones, **kw):
     return r["x"], r["u"], r["iter"], r["solved"]
 
 
-@pytest.mark.parametrize("N,fdyn,cones,kernel", [(10, True, False, "stream4<6,3>"), (10, True, True, "stream4<6,3>"),
+@pytest.mark.parametrize("N,fdyn,cones,kernel", [(10, True, False, "mfmat<6,3,10>"), (10, True, True, "mfmat<6,3,10>"),
+                                                 (50, True, True, "mfmat<6,3,50>"), (10, False, True, "mfmat<6,3,10>"),
+                                                 (10, True, False, "stream4<6,3>"), (10, True, True, "stream4<6,3>"),
                                                  (50, True, True, "stream4<6,3>"), (10, False, True, "stream4<6,3>"),
                                                  (10, True, True, "generic")])
 def test_rocket_fdyn_cones_vs_oracle(hip_lib, oracle_built, monkeypatch, N, fdyn, cones, kernel):
-    """Config 4's ingredients on the GPU (generic kernel) against the fp64 restatement of the same
-    construction.  Parity with the reference is UNPINNED for these (no source here): this pins the HIP
-    path to the oracle, and tests/test_extensions_cpu.py pins the oracle by properties."""
+    """Config 4's ingredients with the reference's default calling pattern (the workspace persists between solves) on
+    the transposed-sets matrix-core kernel — what these problems run on — and on the stream and generic kernels
+    behind it, against the fp64 restatement of the same construction.  Parity with the reference is UNPINNED for
+    these (no source here): this pins the HIP path to the oracle, and tests/test_extensions_cpu.py pins the oracle
+    by properties."""
+    if not kernel.startswith("mfmat"):
+        monkeypatch.setenv("TINYMPC_HIP_NO_MFMAT", "1")
     if kernel == "generic":
         monkeypatch.setenv("TINYMPC_HIP_NO_STREAM", "1")
     B = 24
@@ -829,7 +835,7 @@ def test_rocket_fdyn_cones_vs_oracle(hip_lib, oracle_built, monkeypatch, N, fdyn
 def test_config4_one_shot_through_dropin_api(hip_lib, oracle_built):
     """config 4 on the process-global entry points a Julia host binds: setup(...; batch) -> set_warm_start(false) ->
     set_cone_constraints / bounds / references -> solve: runs on the on-chip kernel and matches the oracle; with the
-    reference's default (workspace persists) the same calls run on the stream kernel"""
+    reference's default (workspace persists) the same calls run on the same kernel (round 2: the stream kernel)"""
     N, B = 50, 40
     prob = t.problems.rocket(N)
     x0 = t.problems.rocket_x0(B, seed=3)
@@ -858,7 +864,7 @@ def test_config4_one_shot_through_dropin_api(hip_lib, oracle_built):
         else:
             assert nrel_batch(sol["controls"], first["controls"]).max() <= 3e-6   # same solve, other kernel
         t.cleanup()
-    assert names == ["mfmar<6,3,50>", "stream4<6,3>"]
+    assert names == ["mfmat<6,3,50>", "mfmat<6,3,50>"]
 
 
 def test_rocket_example_through_dropin_api(hip_lib, oracle_built):
@@ -1112,7 +1118,7 @@ def test_config4_full_size_properties(hip_lib, oracle_built):
     bs.set_u_ref(ur)
     bs.set_x0(x0)
     assert bs.solve() == 1
-    assert bs.kernel_name == "mfmar<6,3,50>"
+    assert bs.kernel_name == "mfmat<6,3,50>"
     sol = bs.get_solution()
     kw = dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=100, check_termination=1)
     ref = _oracle_loop(_rocket_oracle(oracle_built, prob, xr, ur, True, True, kw), base)
@@ -1155,7 +1161,7 @@ def test_config4_persistent_tiles_tolerance_terminated(hip_lib, oracle_built):
     bs.set_u_ref(ur)
     bs.set_x0(x0)
     status = bs.solve()
-    assert bs.kernel_name == "mfmar<6,3,50>"
+    assert bs.kernel_name == "mfmat<6,3,50>"
     sol, st = bs.get_solution(), bs.get_status()
     assert status == int(np.any(st["solved"] == 0))
     assert len(np.unique(st["iter"][:D])) > 3, np.unique(st["iter"][:D], return_counts=True)   # tiles stop at different iterations

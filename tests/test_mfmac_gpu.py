@@ -14,6 +14,13 @@ from tests.util import FP32_TOL, nrel_batch, parity_every_instance
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _three_wavefront_kernels_only(monkeypatch):
+    """since round 3 these problems run on the transposed-sets kernel (tests/test_mfmat_gpu.py); this module keeps the
+    three-wavefront kernels behind it covered"""
+    monkeypatch.setenv("TINYMPC_HIP_NO_MFMAT", "1")
+
+
 def _oracle(oracle_built, prob, kw, xr, ur, fdyn, cones):
     def make(b=None):
         o = oracle_built.CpuSolver("orc64", prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N)

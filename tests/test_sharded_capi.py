@@ -155,7 +155,7 @@ def test_sharded_persistent_and_refill_kernels_share_a_device(hip_lib):
     whole chip and take work off their own counters — results must equal the single-device solver's, bit for bit"""
     import ctypes
     lib = hip_lib
-    # (a) rocket N = 50, cones + fdyn, one-shot: mfmar on both shards
+    # (a) rocket N = 50, cones + fdyn, one-shot: mfmat on both shards
     N, B = 50, 96
     prob = t.problems.rocket(N)
     x0 = t.problems.rocket_x0(B, seed=4)
@@ -169,7 +169,7 @@ def test_sharded_persistent_and_refill_kernels_share_a_device(hip_lib):
     one.set_warm_start(False); one.set_x_ref(xr); one.set_u_ref(ur); one.set_x0(x0)
     one.solve()
     ref = one.get_solution()
-    assert one.kernel_name == "mfmar<6,3,50>"
+    assert one.kernel_name == "mfmat<6,3,50>"
     one.close()
     sh = t.ShardedBatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B, devices=[0, 0])
     _configure(sh, prob, x0, 0.0, 60)
@@ -182,7 +182,7 @@ def test_sharded_persistent_and_refill_kernels_share_a_device(hip_lib):
         assert lib.tinympc_set_cone_constraints(loc, ia([0]), ia([3]), da([0.25]), 1, ia([0]), ia([3]), da([0.5]), 1) == 0
     sh.set_warm_start(False); sh.set_x_ref(xr); sh.set_u_ref(ur)
     sh.solve()
-    assert sh.kernel_names() == ["mfmar<6,3,50>"] * 2
+    assert sh.kernel_names() == ["mfmat<6,3,50>"] * 2
     got = sh.get_solution()
     assert np.array_equal(got["states"], ref["states"]) and np.array_equal(got["controls"], ref["controls"])
     sh.close()

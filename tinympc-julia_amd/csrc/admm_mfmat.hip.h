@@ -810,7 +810,50 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
         __syncthreads();
         x0r[0] = s_plant[j * NX + g];
         x0r[1] = ok1 ? s_plant[j * NX + row1] : 0.0;
-        if (step + 1 < n_steps) continue;
+        if (step + 1 < n_steps) {
+            // An instance that converged goes into its next solve exactly as the reference does: with the slack and the
+            // feed-forward term of the iteration BEFORE its last (it parked them in the workspace arrays, see above) — the
+            // registers hold the last iteration's slack, and its t cells were overwritten by that iteration's rollout.
+            if (conv) {
+                mf_for<0, NG>([&](auto mt) {
+                    constexpr int m = decltype(mt)::value;
+                    const int kk = 4 * m + g;
+                    lds_f *c = cq + m * 4 * PLEN;
+                    if (kk < N) {
+                        const float *pv = Pe->sv + ox + m * 4 * NX;
+#pragma unroll
+                        for (int r = 0; r < NX; ++r) ST(S_VBX, r, pv[r]);
+                        if constexpr (CXQ > 0) {
+                            const float *pvc = Pe->svc + ox + m * 4 * NX;
+#pragma unroll
+                            for (int r = 0; r < NX; ++r) ST(S_VCX, r, pvc[r]);
+                        }
+                    }
+                    if (kk < N - 1) {
+                        const float *pz = Pe->sz + ou + m * 4 * NU, *pd = Pe->sd + ou + m * 4 * NU;
+#pragma unroll
+                        for (int a = 0; a < NU; ++a) ST(S_VBU, a, pz[a]);
+                        if constexpr (CUQ > 0) {
+                            const float *pzc = Pe->szc + ou + m * 4 * NU;
+#pragma unroll
+                            for (int a = 0; a < NU; ++a) ST(S_VCU, a, pzc[a]);
+                        }
+                        double dv[NU];
+#pragma unroll
+                        for (int a = 0; a < NU; ++a) dv[a] = (double)pd[a];
+#pragma unroll
+                        for (int a = 0; a < NU; ++a) {
+                            double acc = 0.0;
+#pragma unroll
+                            for (int a2 = 0; a2 < NU; ++a2) acc = fma(gk64[T::O_QUU + a * NU + a2], dv[a2], acc);
+                            c[U0 + a * 16] = (float)acc;
+                        }
+                    }
+                });
+            }
+            __syncthreads();
+            continue;
+        }
         if (active) {
             Pe->x0_out[b * NX + g] = (float)x0r[0];
             if (ok1) Pe->x0_out[b * NX + row1] = (float)x0r[1];
