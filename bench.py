@@ -205,26 +205,40 @@ def roofline_of(bs, family, precision, batch, iters_done, k_ms):
     sec = k_ms * 1e-3
     ach_gbs, ach_tf = alg_bytes / sec / 1e9, alg_flops / sec / 1e12
     cc = committed_counters(family, precision, batch, bs.kernel_name)
-    peak_tf = FP64_PEAK_TFLOPS if precision == 0 else FP32_PEAK_TFLOPS
-    roof = {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
+    hbm = {"achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS}
+    # What bounds the path is instruction issue (~430-950 FLOP/B against a machine balance of ~20), so the
+    # dominant kernel is priced in FLOP/s.  `frac` keeps SURVEY 8(d)'s definition for every round — algorithmic FLOPs (all of
+    # them, fp32 elementwise included) over the 157.3 TFLOP/s fp32 vector peak — so rounds stay comparable whatever unit
+    # executes the recurrences; the mandated HBM figure (algorithmic bytes over the kernel time) is `hbm`.
+    nx, nu, N = bs.nx, bs.nu, bs.N
+    matvec_flops = (2.0 * (N - 1) * (2 * nx * nx + 4 * nx * nu + nu * nu) + 2.0 * nx * nx) * batch * iters_done
+    roof = {"bound": "valu_fp64" if precision == 0 else "valu_fp32", "achieved": ach_tf, "peak": FP32_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": ach_tf / FP32_PEAK_TFLOPS, "hbm": hbm,
             "traffic": cc["traffic"], "traffic_source": cc["source"], "kernel_ms": k_ms,
             "algorithmic_bytes_per_launch": alg_bytes,
-            "note": "compute-bound path (SURVEY 8d: ~430-950 FLOP/B against a machine balance of ~20): see valu"}
-    valu = {"achieved_tflops": ach_tf, "peak_tflops": peak_tf,
-            "peak_is": "fp64 vector (the recurrences, ~90 % of the FLOPs, run in fp64)" if precision == 0 else "fp32 vector",
-            "frac": ach_tf / peak_tf, "algorithmic_flops_per_launch": alg_flops,
+            "note": "compute-bound path: algorithmic FLOPs over the fp32 vector peak (SURVEY 8d's definition, all rounds); "
+                    "`hbm` = algorithmic bytes over the kernel time against 8 TB/s"}
+    valu = {"achieved_tflops": ach_tf, "peak_tflops": FP32_PEAK_TFLOPS, "frac": ach_tf / FP32_PEAK_TFLOPS,
+            "frac_of_fp64_vector_peak": ach_tf / FP64_PEAK_TFLOPS,
+            # the fp64 FMAs the two recurrences cannot do without (mat-vec FLOPs of SURVEY 8a rows a2 + a7 + the terminal
+            # product) over the 78.6 TFLOP/s fp64 rate: what the VALU spends on necessary work
+            "necessary_fma_frac": matvec_flops / sec / 1e12 / FP64_PEAK_TFLOPS,
+            "necessary_fma_flops_per_launch": matvec_flops,
+            "algorithmic_flops_per_launch": alg_flops,
             "issue_utilisation": cc["valu_issue"], "counters_source": cc.get("sq_source")}
     if cc["valu_insts"]:
         # upper bound of what the VALU executed: every wave64 VALU instruction counted as one FMA on 64 lanes
         valu["executed_flops_upper_bound"] = cc["valu_insts"] * 128.0
-        valu["executed_frac"] = cc["valu_insts"] * 128.0 / sec / 1e12 / peak_tf
+        valu["executed_frac_of_fp64_vector_peak"] = cc["valu_insts"] * 128.0 / sec / 1e12 / FP64_PEAK_TFLOPS
     if bs.kernel_name.startswith("mfma"):
         roof.update({"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": ach_tf / FP64_PEAK_TFLOPS, "issue_utilisation": cc["mfma_issue"],
+                     "frac": ach_tf / FP64_PEAK_TFLOPS, "frac_of_fp32_vector_peak": ach_tf / FP32_PEAK_TFLOPS,
+                     "issue_utilisation": cc["mfma_issue"],
                      "counters_source": cc.get("sq_source"),
                      "note": "algorithmic FLOPs (SURVEY 8d) over the dense fp64 matrix-core peak; tiles are padded, so the "
                              "issued MFMA FLOPs are higher (DESIGN.md, mfma kernel)"})
     if bs.kernel_name.startswith("stream"):
+        roof.update({"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS})
         roof["note"] = ("run-time-horizon kernel: the per-instance trajectories stream through HBM once per ADMM iteration "
                         "(traffic >> algorithmic bytes, by design of that kernel; DESIGN.md 3.2)")
     return roof, valu
@@ -296,13 +310,15 @@ def cpu_baseline(prob, x0, refs, iters, seconds):
 # extra configurations (one GPU): configs 3, 4 and one shard of config 5
 # ----------------------------------------------------------------------------------------------------------------------
 def time_config(t, torch, dev, stream, name, batch, seed, iters=100, tol=0.0, check=1, steps=5, warmup=2, compaction=0,
-                adaptive=False):
+                adaptive=False, keep_workspace=False):
     import numpy as np
     prob, x0, refs, label = make_workload(t, name, batch, seed)
     bs = build_solver(t, name, prob, x0, refs, dev.index, iters, tol, check, 0, compaction)
     if adaptive:
         bs.set_adaptive_rho(True)
         label += ", adaptive rho (every 5th iteration)"
+    if keep_workspace:
+        bs.set_warm_start(True)       # the reference's default: solve() resets counters only (admm.cpp:111-115)
     try:
         def one():    # (adaptive: the adapted rho / Kinf / Pinf persist from solve to solve, as in the reference)
             bs.solve_async(stream.cuda_stream)
@@ -324,7 +340,8 @@ def time_config(t, torch, dev, stream, name, batch, seed, iters=100, tol=0.0, ch
             k_ms, launches_per_step = ms, None      # several launches + compaction kernels per solve: wall time is the figure
         roof, valu = roofline_of(bs, name, 0, batch, it_mean, k_ms if k_ms > 0 else ms)
         out = {"workload": f"{label}, batch={batch}, " + (f"tol={tol:g} check every {check}, max_iter={iters}" if tol > 0
-                                                         else f"fixed {iters} ADMM iters") + ", cold start",
+                                                         else f"fixed {iters} ADMM iters") +
+                           (", workspace kept between solves (warm start)" if keep_workspace else ", cold start"),
                "ms_per_step": ms, "solves_per_sec": batch / (ms * 1e-3), "kernel": bs.kernel_name, "kernel_ms": k_ms,
                "mean_iters": it_mean, "unsolved": int((st["solved"] == 0).sum()) if tol > 0 else None,
                "roofline": roof, "valu": valu, "steps": steps}
@@ -560,6 +577,8 @@ def main():
         ex = {}
         ex["quadrotor_65536"] = time_config(t, torch, dev, stream, "quadrotor", 65536, 1)
         ex["rocket_soc_32768"] = time_config(t, torch, dev, stream, "rocket_soc", 32768, 2)
+        ex["rocket_soc_32768_workspace_kept"] = time_config(t, torch, dev, stream, "rocket_soc", 32768, 2, keep_workspace=True)
+        ex["rocket_soc_32768_check_every_iteration"] = time_config(t, torch, dev, stream, "rocket_soc", 32768, 2, tol=1e-30)
         ex["quadrotor_131072_tol"] = time_config(t, torch, dev, stream, "quadrotor", 131072, 3, tol=1e-3, check=10)
         ex["quadrotor_131072_tol_compaction"] = time_config(t, torch, dev, stream, "quadrotor", 131072, 3, tol=1e-3,
                                                             check=10, compaction=20)

@@ -41,6 +41,21 @@ def test_gpus_3_strong_scaling_is_config5_sharded():
     assert d["config"]["batch_total"] == 2 ** 20 and d["config"]["batch_per_gpu"] == 349526   # rank 0 of a ragged split
 
 
+@pytest.mark.gpu
+def test_gpus_2_on_two_real_devices():
+    """`python bench.py --gpus 2` on hardware: two ranks, one per GPU, RCCL status fold, one JSON line with the whole-job
+    rate.  Needs two devices: skipped on the one-GPU test box, runs on the first multi-GPU lease."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f"needs 2 GPUs, {torch.cuda.device_count()} present")
+    p, lines = _run("--gpus", "2", "--steps", "5", "--warmup", "2", "--no-extras", "--no-cpu-baseline")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["batch_total"] == 131072
+    assert d["value"] > 1.0e8 and not d.get("dry")            # two GPUs' worth of the one-GPU rate (1.8e8 each)
+
+
 def test_world_size_mismatch_is_refused():
     # a launcher that started a different number of ranks than --gpus says
     p, _ = _run("--gpus", "2", "--dry", "--backend", "gloo", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})

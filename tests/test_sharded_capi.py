@@ -46,10 +46,19 @@ def _configure(bs, prob, x0, tol, max_iter, check=1):
     bs.set_x0(x0)
 
 
+def _n_devices():
+    import torch
+    return torch.cuda.device_count()          # (counting devices does not initialise the GPU)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("devices,backend", [([0], "rccl"), ([0, 0, 0], "host")])
+@pytest.mark.parametrize("devices,backend", [([0], "rccl"), ([0, 0, 0], "host"), ([0, 1], "rccl")])
 @pytest.mark.parametrize("tol,max_iter", [(0.0, 60), (1e-3, 25)])
 def test_sharded_equals_single_device(hip_lib, devices, backend, tol, max_iter):
+    if max(devices) >= _n_devices():
+        # two DISTINCT devices: ncclCommInitAll across real devices and the grouped ncclAllReduce over xGMI — runs on the
+        # first multi-GPU lease (the one-GPU test box has no second device)
+        pytest.skip(f"needs {max(devices) + 1} GPUs, {_n_devices()} present")
     prob = t.problems.cartpole(20, u_bound=0.5)
     B = 37                                                    # ragged over 3 shards: 13 + 12 + 12
     x0 = t.problems.cartpole_x0(B, seed=5)
@@ -206,3 +215,36 @@ def test_sharded_persistent_and_refill_kernels_share_a_device(hip_lib):
     assert np.array_equal(outs[0][2]["iter"], outs[1][2]["iter"]) and len(np.unique(outs[0][2]["iter"])) > 3
     assert np.array_equal(outs[0][1]["controls"], outs[1][1]["controls"])
     assert np.array_equal(outs[0][1]["states"], outs[1][1]["states"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", [[0, 0], [0, 1]])
+def test_sharded_chunked_solves_run_side_by_side(hip_lib, devices):
+    """a solve in chunks with compaction synchronises its stream on the host between chunks: the sharded handle gives each
+    shard a host thread (enqueued one after another, shard i would finish before shard i + 1 starts).  Results are the
+    single-device chunked solve's; on two real devices the wall time is about one shard's, not two."""
+    import time
+    if max(devices) >= _n_devices():
+        pytest.skip(f"needs {max(devices) + 1} GPUs, {_n_devices()} present")
+    prob = t.problems.quadrotor(30, u_bound=0.5)
+    B = 32768
+    x0 = t.problems.quadrotor_x0(B, seed=17)
+    x0[:, ::3] *= 0.1
+    outs, secs = [], []
+    for mk in (lambda: t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B, device=0),
+               lambda: t.ShardedBatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B, devices=devices)):
+        bs = mk()
+        _configure(bs, prob, x0, 1e-3, 100, check=10)
+        bs.set_compaction(20)
+        bs.solve()
+        bs.reset()
+        t0 = time.perf_counter()
+        st = bs.solve()
+        secs.append(time.perf_counter() - t0)
+        outs.append((st, bs.get_solution(), bs.get_status()))
+        bs.close()
+    assert outs[0][0] == outs[1][0]
+    assert np.array_equal(outs[0][2]["iter"], outs[1][2]["iter"]) and len(np.unique(outs[0][2]["iter"])) > 3
+    assert np.array_equal(outs[0][1]["controls"], outs[1][1]["controls"])
+    if devices[0] != devices[1]:
+        assert secs[1] <= 0.85 * secs[0], secs             # two devices, half the batch each, side by side

@@ -65,7 +65,7 @@ struct ConeShape {
     static constexpr int pos_len(int cone_rows) { return 16 * (2 * NROW + cone_rows); }
     static constexpr int PAD_LEN = 64 + 16 * NROW;  // a lane's pad cell and its A3 twin (A3_DISP further on)
     static constexpr size_t lds_bytes(int N, int nk, int cone_rows) {
-        return sizeof(float) * ((size_t)pos_len(cone_rows) * (N - 1) + PAD_LEN + bounds_len(nk) + (((size_t)NROW * N + 2) & ~(size_t)1) +
+        return sizeof(float) * ((size_t)pos_len(cone_rows) * (N - 1) + PAD_LEN + ((bounds_len(nk) + 1) & ~1) + (((size_t)NROW * N + 2) & ~(size_t)1) +
                                256 + 200) + sizeof(double) * 8;   // ... + hand-over ring + residual / flag exchange
     }
     // HBM scratch per wavefront (floats): cone slack of the iteration before a check, [pos 0..N-1][slot][lane]
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(192) void admm_mfmac_kernel(const AdmmParams P) {
     float *s_state = reinterpret_cast<float *>(s_raw_c);
     float *s_pad = s_state + (size_t)PLEN * (N - 1);          // S::PAD_LEN zeros: what lanes without a row read and write
     float *s_bnd = s_pad + S::PAD_LEN;
-    float *s_ref = s_bnd + S::bounds_len(nk);                 // [N][NROW] and one zero cell behind
+    float *s_ref = s_bnd + ((S::bounds_len(nk) + 1) & ~1);    // [N][NROW] and one zero cell behind (even offset: fp64 cells follow)
     double *s_pterm = reinterpret_cast<double *>(s_ref + (((size_t)NROW * N + 2) & ~(size_t)1));
     float *s_ring = reinterpret_cast<float *>(s_pterm + 8);   // pri_u[64] dua_u[64] (wave 2 -> 0)
     float *s_xchg = s_ring + 256;                             // pri_x[64] dua_x[64] (wave 1 -> 0), conv[64], any_left (wave 0 -> 1, 2), [196] step counter

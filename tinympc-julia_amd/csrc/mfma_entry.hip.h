@@ -92,13 +92,7 @@ hipError_t launch_mfma_refill(const AdmmParams &P, hipStream_t stream) {
     if (!(P.abs_pri_tol > 0.f && P.abs_dua_tol > 0.f) || ct <= 0 || P.max_iter % ct != 0 || P.idx != nullptr ||
         P.ref_mode == REF_PER_INSTANCE || P.x0d != nullptr || P.batch % 64 != 0 || std::getenv("TINYMPC_HIP_NO_REFILL"))
         return hipErrorNotReady;
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
+    const int cus = device_cu_count();   // (per device: a sharded handle launches on several)
 #define TMPC_MFMA_RF(REFS_)                                                                                          \
     do {                                                                                                             \
         int per_cu = 0;                                                                                              \

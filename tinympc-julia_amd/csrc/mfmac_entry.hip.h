@@ -146,13 +146,7 @@ hipError_t launch_mfmac(const AdmmParams &P_, bool ext, size_t lds, hipStream_t 
 #endif
     const int tiles = (P.batch + 15) / 16;
     // persistent workgroups (the kernel takes tiles off a counter): as many as fit on the chip at once
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
+    const int cus = device_cu_count();   // (per device: a sharded handle launches on several)
 #define TMPC_MFMAC_LAUNCH(REFS_, CX_, CU_, BV_)                                                                       \
     do {                                                                                                              \
         (void)hipFuncSetAttribute((const void *)admm_mfmac_kernel<NX, NU, REFS_, CX_, CU_, BV_>,                      \

@@ -28,13 +28,7 @@ hipError_t launch_mfmar(const AdmmParams &P_, bool ext, size_t lds, hipStream_t 
     // the termination check can end instances: every checking iteration reads the previous slack back (kernel variant PF)
     const bool live_check = P.abs_pri_tol > 0.f && P.abs_dua_tol > 0.f && P.check_termination > 0;
     // persistent workgroups (the kernel takes tiles off a counter): as many as fit on the chip at once
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
+    const int cus = device_cu_count();   // (per device: a sharded handle launches on several)
 #define TMPC_MFMAR_LAUNCH(REFS_, CX_, CU_, BV_, PF_)                                                                          \
     do {                                                                                                                 \
         (void)hipFuncSetAttribute((const void *)admm_mfmar_kernel<NX, NU, N, REFS_, CX_, CU_, BV_, PF_>,                      \

@@ -27,6 +27,8 @@
 #include <vector>
 
 #include "../../include/tinympc_hip.h"
+#include <thread>
+
 #include "solver.h"
 
 using tmpc::hip_ok;
@@ -61,6 +63,8 @@ struct Rccl {
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
         if (!CommInitAll || !CommDestroy || !AllReduce || !GroupStart || !GroupEnd || !GetErrorString) {
             set_error("librccl.so lacks an expected symbol");
+            dlclose(lib);
+            lib = nullptr;      // (a later call must not take the half-bound table for a loaded library)
             return false;
         }
         return true;
@@ -112,6 +116,11 @@ extern "C" {
 
 void tinympc_shard_range(int batch, int n_shards, int shard, int *lo, int *hi) {
     // sharding.shard_range: contiguous, sizes differ by at most one, the larger shards first
+    if (n_shards < 1 || shard < 0 || shard >= n_shards || batch < 0) {   // (reachable from ctypes / Julia with any integers)
+        if (lo) *lo = 0;
+        if (hi) *hi = 0;
+        return;
+    }
     const int base = batch / n_shards, rem = batch % n_shards;
     const int l = shard * base + std::min(shard, rem);
     if (lo) *lo = l;
@@ -251,9 +260,31 @@ int tinympc_sharded_set_u_ref(tinympc_sharded *s, const double *u_ref, int cols)
 // Enqueue every shard's solve on its device's stream, then the status fold behind it; returns without waiting.
 int tinympc_sharded_solve_async(tinympc_sharded *s) {
     if (!s) return -1;
-    for (int i = 0; i < s->n(); ++i) {
-        SH_TRY(hipSetDevice(s->dev[i]));
-        if (tinympc_solve_async(s->shard[i], s->stream[i])) return -1;
+    if (s->pending) {
+        set_error("tinympc_sharded_solve_async: the previous solve has not been waited for (tinympc_sharded_wait)");
+        return -1;
+    }
+    // A solve in chunks with compaction (tinympc_sharded_set_compaction) synchronises its stream between chunks on the
+    // host: enqueued shard after shard, shard i would run to completion before shard i + 1 is even launched and n GPUs
+    // would work one after another.  Such solves get one host thread per shard, so the devices run side by side; the call
+    // then returns when every shard's solve has finished (only the status fold is still in flight).
+    bool chunked = false;
+    for (int i = 0; i < s->n(); ++i) chunked = chunked || s->shard[i]->s.chunk_iters > 0;
+    if (chunked && s->n() > 1) {
+        std::vector<int> rc((size_t)s->n(), 0);
+        std::vector<std::thread> th;
+        for (int i = 0; i < s->n(); ++i)
+            th.emplace_back([s, i, &rc] {
+                rc[(size_t)i] = hipSetDevice(s->dev[i]) == hipSuccess ? tinympc_solve_async(s->shard[i], s->stream[i]) : -1;
+            });
+        for (std::thread &t : th) t.join();
+        for (int r : rc)
+            if (r) return -1;
+    } else {
+        for (int i = 0; i < s->n(); ++i) {
+            SH_TRY(hipSetDevice(s->dev[i]));
+            if (tinympc_solve_async(s->shard[i], s->stream[i])) return -1;
+        }
     }
     for (int i = 0; i < s->n(); ++i) {
         SH_TRY(hipSetDevice(s->dev[i]));

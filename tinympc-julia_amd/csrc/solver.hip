@@ -508,6 +508,7 @@ int Solver::get_adaptive_state(double *rho, double *Kinf, double *Pinf) {
 }
 
 int Solver::upload_packs() {
+    if (wait_last_launch()) return -1;   // (a launch still in flight on another stream reads the packs this overwrites)
     state_bounds_active = false;
     if (st.en_state_bound)
         for (size_t i = 0; i < x_min.size(); ++i)
@@ -618,6 +619,7 @@ int Solver::set_ref_sequence(const double *x_seq, const double *u_seq, int steps
 int Solver::upload_refs() {
     if (refs_device_owned || !refs_dirty) return 0;
     HIP_TRY(hipSetDevice(device));
+    if (wait_last_launch()) return -1;
     const int mode = xref_kind > uref_kind ? xref_kind : uref_kind;
     const size_t EX = (size_t)ex(), EU = (size_t)eu(), Bn = (size_t)batch;
     auto put = [&](float *&dptr, size_t &cap, const std::vector<float> &h, int kind, size_t E) -> int {
