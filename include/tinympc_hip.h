@@ -55,6 +55,12 @@ int get_states(double *states_buffer, int *rows, int *cols);
 int get_controls(double *controls_buffer, int *rows, int *cols);
 /* replaces bindings.cpp:205-208 */
 void cleanup_solver(void);
+/* Additions next to bindings.cpp:75,161,183 for hosts that keep Float32 arrays: the same three per-solve transfers without
+ * the fp64 narrowing / widening pass on the host (the device buffers are fp32; a 65 536-instance cartpole round trip is
+ * 1.3 ms through the fp64 forms, most of it that pass).  Shapes and conventions as set_x0 / get_states / get_controls. */
+int set_x0_f32(float *x0_data, int x0_rows, int x0_cols, int verbose);
+int get_states_f32(float *states_buffer, int *rows, int *cols);
+int get_controls_f32(float *controls_buffer, int *rows, int *cols);
 /* replaces bindings.cpp:336-376.  en_*_soc / en_*_linear switch the sets given to set_cone_constraints /
  * set_linear_constraints on and off (parity unpinned).  adaptive_rho != 0 turns on the per-instance rho adaptation of
  * admm.cpp:147-174 (see tinympc_set_adaptive_rho; runs on the generic kernel).  check_termination <= 0 means "never check"
@@ -205,6 +211,11 @@ int tinympc_solve_status(tinympc_solver *s);
  * describe the last solve.  Logs, instance-major: x [batch][steps][nx] (plant state after each
  * step), u [batch][steps][nu] (control applied), iter [batch][steps] (ADMM iterations of the step,
  * negated when the step hit max_iter).  Any log pointer may be NULL. */
+/* fp32 host buffers (plain copies to / from the fp32 device buffers, no conversion pass): x0 nx x 1 or nx x batch;
+ * states nx*N*batch, controls nu*(N-1)*batch floats, instance-major as the fp64 forms. */
+int tinympc_set_x0_f32(tinympc_solver *s, const float *x0, int cols);
+int tinympc_get_states_f32(tinympc_solver *s, float *buf);
+int tinympc_get_controls_f32(tinympc_solver *s, float *buf);
 int tinympc_mpc_rollout(tinympc_solver *s, int steps, void *hip_stream);
 int tinympc_get_mpc_log(tinympc_solver *s, double *x, double *u, int *iter);
 /* Shared references of EVERY step of the next closed loops — the caller pattern of

@@ -21,3 +21,25 @@ t0 = time.perf_counter(); n = 10
 for _ in range(n): once()
 dt = (time.perf_counter() - t0) / n
 print(f"PCIe-inclusive (fp64 host buffers in/out through the C-ABI): {dt*1e3:.2f} ms per 65536-solve batch = {B/dt:.3e} solves/s")
+# the same round trip through the fp32 entry points (Float32 host arrays: plain copies, buffers page-locked on first use)
+x0f = np.asfortranarray(x0.astype(np.float32))
+xsf, usf = np.zeros(4 * 20 * B, dtype=np.float32), np.zeros(19 * B, dtype=np.float32)
+fp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+def once32():
+    bs.lib.tinympc_set_x0_f32(bs.h, fp(x0f), B)
+    bs.lib.tinympc_solve(bs.h)
+    bs.lib.tinympc_get_states_f32(bs.h, fp(xsf))
+    bs.lib.tinympc_get_controls_f32(bs.h, fp(usf))
+for _ in range(3): once32()
+t0 = time.perf_counter()
+for _ in range(n): once32()
+dt32 = (time.perf_counter() - t0) / n
+parts = []
+for f in (lambda: bs.lib.tinympc_set_x0_f32(bs.h, fp(x0f), B), lambda: bs.lib.tinympc_solve(bs.h),
+          lambda: bs.lib.tinympc_get_states_f32(bs.h, fp(xsf)), lambda: bs.lib.tinympc_get_controls_f32(bs.h, fp(usf))):
+    t0 = time.perf_counter()
+    for _ in range(n): f()
+    parts.append((time.perf_counter() - t0) / n * 1e3)
+assert np.abs(xsf.astype(np.float64) - xs).max() == 0.0 and np.abs(usf.astype(np.float64) - us).max() == 0.0
+print(f"PCIe-inclusive (fp32 host buffers): {dt32*1e3:.2f} ms per 65536-solve batch = {B/dt32:.3e} solves/s   "
+      f"(set_x0 {parts[0]:.2f}, solve {parts[1]:.2f}, get_states {parts[2]:.2f}, get_controls {parts[3]:.2f} ms)")

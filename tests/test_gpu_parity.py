@@ -290,7 +290,7 @@ def test_refs_shared_and_per_instance(hip_lib, oracle_built):
     ur3 = np.repeat(ur[:, :, None], B, axis=2) + rng.standard_normal((3, 9, B))
     ref_pi = _oracle_batch(oracle_built, prob, x0, xref=xr3, uref=ur3, **kw)
     bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
-    assert bs.kernel_name.startswith("quad<6,3,10")
+    assert bs.kernel_name == "mfmat<6,3,10>"              # (shared references; per-instance ones go to the quad kernel below)
     bs.update_settings(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=60, check_termination=1)
     bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
     bs.set_warm_start(False)

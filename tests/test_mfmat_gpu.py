@@ -395,9 +395,54 @@ def test_mfmat_selection(hip_lib):
     bs.solve()
     assert bs.kernel_name == "stream4<6,3>"
     bs.close()
-    # box-only rocket at N = 10: the quad kernel keeps it (measured faster); at N = 50 the on-chip kernels take it
+    # box-only solves of the shape run here too (measured faster than the quad kernel at every compiled horizon)
     p10 = t.problems.rocket(10)
     b10 = t.BatchSolver(p10.A, p10.B, p10.Q, p10.R, p10.rho, p10.N, batch=4096)
     b10.set_bound_constraints(p10.x_min, p10.x_max, p10.u_min, p10.u_max)
-    assert b10.kernel_name.startswith("quad<6,3,10")
+    assert b10.kernel_name == "mfmat<6,3,10>"
     b10.close()
+
+
+def test_fp32_host_entry_points(hip_lib):
+    """the Float32 forms of the per-solve transfers (set_x0_f32 / get_states_f32 / get_controls_f32, handle and
+    process-global): plain copies of the fp32 device buffers — the same bits the fp64 forms widen"""
+    import ctypes
+    prob = t.problems.cartpole(20, u_bound=0.5)
+    B = 300
+    x0 = t.problems.cartpole_x0(B, seed=3)
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+    bs.update_settings(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=40, check_termination=1)
+    bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    bs.set_x0(x0)
+    bs.solve()
+    ref = bs.get_solution()
+    bs.reset()
+    bs.set_x0_f32(x0.astype(np.float32))
+    bs.solve()
+    got = bs.get_solution_f32()
+    assert got["states"].dtype == np.float32 and got["states"].shape == (4, 20, B)
+    assert np.array_equal(got["states"].astype(np.float64), ref["states"])
+    assert np.array_equal(got["controls"].astype(np.float64), ref["controls"])
+    bs.set_x0_f32(x0[:, 5].astype(np.float32))            # one state broadcast to the batch
+    bs.reset()
+    bs.solve()
+    one = bs.get_solution_f32()
+    assert np.array_equal(one["controls"][:, :, 0], one["controls"][:, :, B - 1])
+    assert np.array_equal(one["controls"][:, :, 0].astype(np.float64), ref["controls"][:, :, 5])
+    bs.close()
+    # the process-global forms a Julia host binds
+    lib = hip_lib
+    s = t.TinyMPCSolver()
+    t.setup(s, prob.A, prob.B, np.zeros(4), prob.Q, prob.R, prob.rho, 4, 1, 20, batch=B, max_iter=40, abs_pri_tol=0.0, abs_dua_tol=0.0)
+    t.set_bound_constraints(s, prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    fp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+    x32 = np.asfortranarray(x0.astype(np.float32))
+    assert lib.set_x0_f32(fp(x32), 4, B, 0) == 0
+    assert t.solve(s) == 1
+    xs, us = np.zeros(4 * 20 * B, dtype=np.float32), np.zeros(19 * B, dtype=np.float32)
+    r, c = ctypes.c_int(), ctypes.c_int()
+    assert lib.get_states_f32(fp(xs), ctypes.byref(r), ctypes.byref(c)) == 0 and (r.value, c.value) == (4, 20 * B)
+    assert lib.get_controls_f32(fp(us), ctypes.byref(r), ctypes.byref(c)) == 0 and (r.value, c.value) == (1, 19 * B)
+    assert np.array_equal(us.reshape((1, 19, B), order="F").astype(np.float64), ref["controls"])
+    assert lib.set_x0_f32(fp(x32), 3, B, 0) == -1
+    t.cleanup()

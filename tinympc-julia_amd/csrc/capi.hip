@@ -350,6 +350,41 @@ int tinympc_get_controls(tinympc_solver *s, double *buf) {
     if (!s || !buf) return -1;
     return guarded("get_controls", [&] { return s->s.get_traj(false, buf); });
 }
+// fp32 host arrays: the device buffers are fp32, so these are plain copies — no narrowing / widening pass on the host
+// (the fp64 forms spend most of a round trip on it: DESIGN.md, PCIe-inclusive rate)
+int tinympc_set_x0_f32(tinympc_solver *s, const float *x0, int cols) {
+    if (!s || !x0) return -1;
+    return guarded("set_x0_f32", [&]() -> int {
+        tmpc::Solver &v = s->s;
+        if (cols != 1 && cols != v.batch) {
+            tmpc::set_error("set_x0_f32: expected nx x 1 or nx x batch");
+            return -1;
+        }
+        if (!tmpc::hip_ok(hipSetDevice(v.device), "hipSetDevice") || v.wait_last_launch()) return -1;
+        if (cols == v.batch) {
+            v.pin_host_range(const_cast<float *>(x0), (size_t)v.batch * v.nx * sizeof(float));
+            return tmpc::hip_ok(hipMemcpy(v.d_x0, x0, (size_t)v.batch * v.nx * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy") ? 0 : -1;
+        }
+        std::vector<float> h((size_t)v.batch * v.nx);
+        for (int b = 0; b < v.batch; ++b) std::copy(x0, x0 + v.nx, h.begin() + (size_t)b * v.nx);
+        return tmpc::hip_ok(hipMemcpy(v.d_x0, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy") ? 0 : -1;
+    });
+}
+static int get_traj_f32(tinympc_solver *s, bool states, float *buf) {
+    tmpc::Solver &v = s->s;
+    if (!tmpc::hip_ok(hipSetDevice(v.device), "hipSetDevice") || v.wait_last_launch()) return -1;
+    const size_t n = (size_t)v.batch * (states ? v.ex() : v.eu());
+    v.pin_host_range(buf, n * sizeof(float));   // (a caller that reuses its buffers gets a direct DMA from the second call on)
+    return tmpc::hip_ok(hipMemcpy(buf, states ? v.d_xout : v.d_uout, n * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy") ? 0 : -1;
+}
+int tinympc_get_states_f32(tinympc_solver *s, float *buf) {
+    if (!s || !buf) return -1;
+    return guarded("get_states_f32", [&] { return get_traj_f32(s, true, buf); });
+}
+int tinympc_get_controls_f32(tinympc_solver *s, float *buf) {
+    if (!s || !buf) return -1;
+    return guarded("get_controls_f32", [&] { return get_traj_f32(s, false, buf); });
+}
 int tinympc_get_status(tinympc_solver *s, int *iter, int *solved, double *residuals4) {
     if (!s) return -1;
     return guarded("get_status", [&] { return s->s.get_status(iter, solved, residuals4); });
@@ -603,6 +638,30 @@ int get_controls(double *controls_buffer, int *rows, int *cols) {
     *cols = (g_solver->s.N - 1) * global_batch();
     if (g_sharded) return guarded("get_controls", [&] { return tinympc_sharded_get_controls(g_sharded.get(), controls_buffer); });
     return tinympc_get_controls(g_solver.get(), controls_buffer);
+}
+
+// fp32 forms of the three per-solve transfers for a Julia host that keeps Float32 arrays (not in bindings.cpp: an addition
+// next to its names; one device only — a sharded global solver takes the fp64 forms)
+int set_x0_f32(float *x0_data, int x0_rows, int x0_cols, int verbose) {
+    (void)verbose;
+    if (need_global("set_x0_f32")) return -1;
+    if (x0_rows != g_solver->s.nx || g_sharded) {
+        set_error(g_sharded ? "set_x0_f32: not available on a sharded solver" : "set_x0_f32: x0 is not the correct length");
+        return -1;
+    }
+    return tinympc_set_x0_f32(g_solver.get(), x0_data, x0_cols);
+}
+int get_states_f32(float *states_buffer, int *rows, int *cols) {
+    if (!g_solver || g_sharded || !states_buffer || !rows || !cols) return -1;
+    *rows = g_solver->s.nx;
+    *cols = g_solver->s.N * global_batch();
+    return tinympc_get_states_f32(g_solver.get(), states_buffer);
+}
+int get_controls_f32(float *controls_buffer, int *rows, int *cols) {
+    if (!g_solver || g_sharded || !controls_buffer || !rows || !cols) return -1;
+    *rows = g_solver->s.nu;
+    *cols = (g_solver->s.N - 1) * global_batch();
+    return tinympc_get_controls_f32(g_solver.get(), controls_buffer);
 }
 
 void cleanup_solver(void) {

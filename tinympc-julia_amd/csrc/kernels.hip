@@ -73,12 +73,14 @@ const ConeEntry *find_cone_kernel(int nx, int nu, int N) {
 }
 
 const ConeEntry *mfmat_entry_6_3_50();
+const ConeEntry *mfmat_entry_6_3_30();
+const ConeEntry *mfmat_entry_6_3_20();
 const ConeEntry *mfmat_entry_6_3_10();
 
 // the transposed-sets matrix-core kernel (admm_mfmat.hip.h): every kind of solve of the shapes instantiated — one-shot,
 // warm-started, workspace-keeping, chunked, closed loop — with box bounds, the affine term and one cone per side
 const ConeEntry *find_trans_kernel(int nx, int nu, int N) {
-    static const ConeEntry *const table[] = {mfmat_entry_6_3_50(), mfmat_entry_6_3_10()};
+    static const ConeEntry *const table[] = {mfmat_entry_6_3_50(), mfmat_entry_6_3_30(), mfmat_entry_6_3_20(), mfmat_entry_6_3_10()};
     for (const ConeEntry *e : table)
         if (e->nx == nx && e->nu == nu && e->N == N) return e;
     return nullptr;

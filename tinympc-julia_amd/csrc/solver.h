@@ -148,6 +148,10 @@ struct Solver {
     hipStream_t s_copy = nullptr;
     hipEvent_t ev_copy[2] = {nullptr, nullptr};
     int d2h_double(const float *d, double *out, size_t n);
+    // fp32 host buffers of the *_f32 entry points: page-locked on first sight (at most 8 ranges, of at least 1 MB) so that
+    // the copies of a caller who reuses its buffers are direct DMAs; unlocked when the solver is destroyed
+    std::vector<std::pair<void *, size_t>> pinned_ranges;
+    void pin_host_range(void *p, size_t bytes);
     int h2d_float(float *d, const double *in, size_t n);
     float *d_scratch = nullptr;
     float *d_mpc_x = nullptr, *d_mpc_u = nullptr;  // fused closed-loop logs

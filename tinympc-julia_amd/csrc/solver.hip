@@ -135,6 +135,8 @@ static void dev_free(T *&p) {
 }
 
 Solver::~Solver() {
+    for (const auto &r : pinned_ranges) (void)hipHostUnregister(r.first);
+    pinned_ranges.clear();
     free_batch();
     dev_free(d_coef);
     dev_free(d_bounds);
@@ -1232,6 +1234,15 @@ int Solver::d2h_double(const float *d, double *out, size_t n) {
     }
     return 0;
 }
+void Solver::pin_host_range(void *p, size_t bytes) {
+    if (!p || bytes < ((size_t)1 << 20)) return;
+    for (const auto &r : pinned_ranges)
+        if (r.first == p && r.second >= bytes) return;
+    if (pinned_ranges.size() >= 8) return;
+    if (hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess) pinned_ranges.emplace_back(p, bytes);
+    else (void)hipGetLastError();   // (not registrable — e.g. already pinned by its owner: the plain copy still works)
+}
+
 int Solver::h2d_float(float *d, const double *in, size_t n) {
     if (!in) return 0;
     std::vector<float> h(n);

@@ -123,6 +123,15 @@ function set_x0(solver::TinyMPCSolver, x0::AbstractVecOrMat{Float64}; verbose::B
               m, size(m, 1), size(m, 2), _flag(verbose)), "Failed to set initial state")
 end
 
+# Float32 host arrays: the device buffers are fp32, so this is a plain copy (the Float64 method narrows 65 536 x nx values on
+# the host first).  x0: (nx,) broadcast to the batch, or (nx, batch)
+function set_x0(solver::TinyMPCSolver, x0::AbstractVecOrMat{Float32}; verbose::Bool=false)
+    _need(solver)
+    m = x0 isa AbstractVector ? reshape(collect(x0), :, 1) : Matrix{Float32}(x0)
+    _ok(ccall((:set_x0_f32, _lib_path()), Int32, (Ptr{Float32}, Int32, Int32, Int32),
+              m, size(m, 1), size(m, 2), _flag(verbose)), "Failed to set initial state")
+end
+
 # x_ref: Matrix (nx, N) shared by the batch, or Array{Float64,3} (nx, N, batch)
 function set_x_ref(solver::TinyMPCSolver, x_ref::AbstractArray{Float64}; verbose::Bool=false)
     _need(solver)
@@ -156,6 +165,22 @@ function get_solution(solver::TinyMPCSolver)
     (s1 != 0 || s2 != 0) && error("Failed to get solution ($(_last_error()))")
     B == 1 && return (states=reshape(xs, nx, N), controls=reshape(us, nu, N - 1))   # the reference's shapes
     return (states=reshape(xs, nx, N, B), controls=reshape(us, nu, N - 1, B))
+end
+
+# The solution into the caller's own Float32 arrays (nx, N, batch) / (nu, N-1, batch): no allocation, no fp32 -> fp64
+# widening on the host — the per-solve round trip of a closed loop that keeps Float32 state.
+# (Device-resident callers skip the copies altogether: `device_buffers(solver)` returns the fp32 device pointers of x0,
+# the references, states, controls and the status arrays; with AMDGPU.jl wrap them with
+# `unsafe_wrap(ROCArray, convert(Ptr{Float32}, ptr), dims)`, fill x0 on the device, and call `solve_async` / `solve`.)
+function get_solution!(states::Array{Float32,3}, controls::Array{Float32,3}, solver::TinyMPCSolver)
+    _need(solver)
+    nx, nu, N, B = solver.nx, solver.nu, solver.N, solver.batch
+    (size(states) == (nx, N, B) && size(controls) == (nu, N - 1, B)) || error("get_solution!: states (nx, N, batch), controls (nu, N-1, batch)")
+    xr, xc, ur, uc = Ref{Int32}(), Ref{Int32}(), Ref{Int32}(), Ref{Int32}()
+    s1 = ccall((:get_states_f32, _lib_path()), Int32, (Ptr{Float32}, Ref{Int32}, Ref{Int32}), states, xr, xc)
+    s2 = ccall((:get_controls_f32, _lib_path()), Int32, (Ptr{Float32}, Ref{Int32}, Ref{Int32}), controls, ur, uc)
+    (s1 != 0 || s2 != 0) && error("Failed to get solution ($(_last_error()))")
+    return (states=states, controls=controls)
 end
 
 # Per-instance iteration count, solved flag and residuals (pri_state, dua_state, pri_input, dua_input)

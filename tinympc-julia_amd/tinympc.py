@@ -25,6 +25,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "lib", "libtinympc_hip.so")
 
 c_dp = ctypes.POINTER(ctypes.c_double)
+c_fp = ctypes.POINTER(ctypes.c_float)
 c_ip = ctypes.POINTER(ctypes.c_int)
 c_int = ctypes.c_int
 c_dbl = ctypes.c_double
@@ -98,6 +99,12 @@ SIGNATURES = {
     "tinympc_solve_status": (c_int, [c_vp]),
     "tinympc_mpc_rollout": (c_int, [c_vp, c_int, c_vp]),
     "tinympc_get_mpc_log": (c_int, [c_vp, c_dp, c_dp, c_ip]),
+    "tinympc_set_x0_f32": (c_int, [c_vp, c_fp, c_int]),
+    "tinympc_get_states_f32": (c_int, [c_vp, c_fp]),
+    "tinympc_get_controls_f32": (c_int, [c_vp, c_fp]),
+    "set_x0_f32": (c_int, [c_fp, c_int, c_int, c_int]),
+    "get_states_f32": (c_int, [c_fp, c_ip, c_ip]),
+    "get_controls_f32": (c_int, [c_fp, c_ip, c_ip]),
     "tinympc_set_ref_sequence": (c_int, [c_vp, c_dp, c_int, c_int, c_dp, c_int, c_int, c_int]),
     "tinympc_set_profiling": (c_int, [c_vp, c_int]),
     "tinympc_set_compaction": (c_int, [c_vp, c_int]),
@@ -703,6 +710,22 @@ class BatchSolver:
 
     def set_ref_mode(self, mode):
         self._chk(self.lib.tinympc_set_ref_mode(self.h, int(mode)), "set_ref_mode")
+
+    def set_x0_f32(self, x0):
+        """x0 as a float32 array (nx,) or (nx, B): a plain copy to the device, no fp64 pass on the host"""
+        m = np.asfortranarray(np.asarray(x0, dtype=np.float32))
+        m = m.reshape(self.nx, -1, order="F")
+        self._chk(self.lib.tinympc_set_x0_f32(self.h, m.ctypes.data_as(c_fp), m.shape[1]), "set_x0_f32")
+
+    def get_solution_f32(self, states=None, controls=None):
+        """the solution into float32 arrays (nx, N, B) / (nu, N-1, B) (allocated, or the caller's own F-ordered ones)"""
+        nx, nu, N, B = self.nx, self.nu, self.N, self.batch
+        states = np.zeros((nx, N, B), dtype=np.float32, order="F") if states is None else states
+        controls = np.zeros((nu, N - 1, B), dtype=np.float32, order="F") if controls is None else controls
+        assert states.flags.f_contiguous and controls.flags.f_contiguous and states.dtype == controls.dtype == np.float32
+        self._chk(self.lib.tinympc_get_states_f32(self.h, states.ctypes.data_as(c_fp)), "get_states_f32")
+        self._chk(self.lib.tinympc_get_controls_f32(self.h, controls.ctypes.data_as(c_fp)), "get_controls_f32")
+        return dict(states=states, controls=controls)
 
     def set_ref_sequence(self, x_ref_seq, u_ref_seq):
         """shared references of every step of the next closed loops: x_ref_seq (nx, N, steps), u_ref_seq (nu, N-1, steps)
