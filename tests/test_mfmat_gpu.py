@@ -446,3 +446,29 @@ def test_fp32_host_entry_points(hip_lib):
     assert np.array_equal(us.reshape((1, 19, B), order="F").astype(np.float64), ref["controls"])
     assert lib.set_x0_f32(fp(x32), 3, B, 0) == -1
     t.cleanup()
+
+
+@pytest.mark.parametrize("shape", ["quadrotor_N10", "quadrotor_N25", "cartpole_N15", "cartpole_N5"])
+def test_further_horizons_have_on_chip_kernels(hip_lib, oracle_built, shape):
+    """horizons beyond the examples' (quadrotor 10 / 15 / 25, cartpole 5 / 15 / 30: tests/test_codegen.jl:15 uses N = 5) used to
+    fall to the HBM-streaming run-time-horizon kernel; they now have matrix-core / lanes-per-instance instantiations —
+    against the fp64 oracle, cold and with the workspace kept, fixed-iteration and tolerance-terminated"""
+    B = 150
+    if shape.startswith("quadrotor"):
+        N = int(shape.split("N")[1])
+        prob, x0, kernel = t.problems.quadrotor(N, u_bound=0.5), t.problems.quadrotor_x0(B, seed=41), f"mfma<12,4,{N}>"
+    else:
+        N = int(shape.split("N")[1])
+        prob, x0, kernel = t.problems.cartpole(N, u_bound=0.5), t.problems.cartpole_x0(B, seed=41), f"quad<4,1,{N},g4>"
+    for kw in (dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=50, check_termination=1),
+               dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1)):
+        mk = _oracle(oracle_built, prob, kw, None, None, None, None)
+        ref = _loop(mk, x0)
+        for warm in (False, True):
+            bs = _solver(prob, B, kw, None, None, None, None, warm)
+            bs.set_x0(x0)
+            bs.solve()
+            assert bs.kernel_name == kernel, bs.kernel_name
+            parity_every_instance(bs.get_solution(), bs.get_status(), ref, mk, x0, kw, prob.rho, min_same=0.95,
+                                  tag=f"{shape} {kw['max_iter']} warm={warm}")
+            bs.close()

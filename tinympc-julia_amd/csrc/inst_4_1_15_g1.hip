@@ -1,0 +1,5 @@
+// quad kernel instantiation for nx=4 nu=1 N=15, 1 lane(s) per instance
+#include "quad_entry.hip.h"
+namespace tmpc {
+TMPC_DEFINE_QUAD_ENTRY(4, 1, 15, 1, 520, 520, 3)
+}

@@ -14,6 +14,7 @@ namespace tmpc {
 #define TMPC_ENTRY(NX, NU, NN, GG) const KernelEntry *quad_entry_##NX##_##NU##_##NN##_g##GG();
 TMPC_ENTRY(4, 1, 20, 4) TMPC_ENTRY(4, 1, 20, 2) TMPC_ENTRY(4, 1, 20, 1)
 TMPC_ENTRY(4, 1, 10, 4) TMPC_ENTRY(4, 1, 10, 2) TMPC_ENTRY(4, 1, 10, 1) TMPC_ENTRY(4, 1, 2, 4)
+TMPC_ENTRY(4, 1, 5, 4) TMPC_ENTRY(4, 1, 5, 1) TMPC_ENTRY(4, 1, 15, 4) TMPC_ENTRY(4, 1, 15, 1) TMPC_ENTRY(4, 1, 30, 4) TMPC_ENTRY(4, 1, 30, 1)
 TMPC_ENTRY(12, 4, 30, 4) TMPC_ENTRY(12, 4, 20, 4)
 TMPC_ENTRY(6, 3, 10, 4) TMPC_ENTRY(6, 3, 10, 2) TMPC_ENTRY(6, 3, 50, 4)
 #undef TMPC_ENTRY
@@ -23,6 +24,9 @@ const KernelEntry *find_quad_kernel(int nx, int nu, int N, int group) {
         quad_entry_4_1_20_g4(),  quad_entry_4_1_20_g2(),  quad_entry_4_1_20_g1(), quad_entry_4_1_10_g4(),
         quad_entry_4_1_10_g2(),  quad_entry_4_1_10_g1(),  quad_entry_4_1_2_g4(),  quad_entry_12_4_30_g4(),
         quad_entry_12_4_20_g4(), quad_entry_6_3_10_g4(),  quad_entry_6_3_10_g2(), quad_entry_6_3_50_g4(),
+        // further cartpole horizons (tests/test_codegen.jl:15 uses N = 5): without them these fall to the HBM-streaming kernel
+        quad_entry_4_1_5_g4(),   quad_entry_4_1_5_g1(),   quad_entry_4_1_15_g4(), quad_entry_4_1_15_g1(),
+        quad_entry_4_1_30_g4(),  quad_entry_4_1_30_g1(),
     };
     for (const KernelEntry *e : table)
         if (e->nx == nx && e->nu == nu && e->N == N && (group < 0 || e->G == group)) return e;
@@ -30,14 +34,18 @@ const KernelEntry *find_quad_kernel(int nx, int nu, int N, int group) {
 }
 
 const KernelEntry *mfma_entry_12_4_30();
+const KernelEntry *mfma_entry_12_4_25();
 const KernelEntry *mfma_entry_12_4_20();
+const KernelEntry *mfma_entry_12_4_15();
+const KernelEntry *mfma_entry_12_4_10();
 
 // matrix-core kernels (admm_mfma.hip.h): one-shot solves of the shapes instantiated.  The kernel is fully unrolled with its
 // state in registers: rocket N=50 (347 state floats per lane with finite state bounds) spills ~1 000 registers and runs
 // 18 ms against the quad kernel's 5.5, and rocket N=10 fills only 9 of a tile's 16 rows (1.13 ms against 0.74):
 // neither is instantiated.  Quadrotor ([A; -Kinf] is a full 16 x 12): N=30 4.13 against 11.6 ms, N=20 2.7 against 5.9
 const KernelEntry *find_mfma_kernel(int nx, int nu, int N) {
-    static const KernelEntry *const table[] = {mfma_entry_12_4_30(), mfma_entry_12_4_20()};
+    static const KernelEntry *const table[] = {mfma_entry_12_4_30(), mfma_entry_12_4_25(), mfma_entry_12_4_20(), mfma_entry_12_4_15(),
+                                               mfma_entry_12_4_10()};
     for (const KernelEntry *e : table)
         if (e->nx == nx && e->nu == nu && e->N == N) return e;
     return nullptr;

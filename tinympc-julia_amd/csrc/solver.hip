@@ -335,8 +335,11 @@ int Solver::select_kernel(bool rollout) {
     const bool mfma_ws_ok = !std::getenv("TINYMPC_HIP_MFMA_ONESHOT_ONLY");
     if (rollout && (!mfma_ws_ok || !warm_start)) rollout_quad = true;  // else: rollout_steps() on the matrix-core kernel
     else rollout_quad = false;
-    if (k && !st.adaptive_rho && !(rollout && rollout_quad) && (mfma_ws_ok || (!warm_start && chunk_iters == 0)) &&
-        precision == 0 && !genv && !std::getenv("TINYMPC_HIP_NO_MFMA"))
+    // (horizons the shape has no lanes-per-instance kernel for — quadrotor N = 10, 15, 25 — run their plain fp64 solves
+    // there too; what the matrix-core kernel does not take then goes to the stream kernel as before)
+    const bool plain_box = !(has_fdyn || cones_active() || lin_active() || hetero);
+    if ((k || plain_box) && !st.adaptive_rho && !(rollout && rollout_quad) && (mfma_ws_ok || (!warm_start && chunk_iters == 0)) &&
+        precision == 0 && !genv && !std::getenv("TINYMPC_HIP_NO_MFMA") && !std::getenv("TINYMPC_HIP_NO_QUAD"))
         if (const KernelEntry *m = find_mfma_kernel(nx, nu, N)) k = m;
     if (!k && (nx > GEN_MAX_NX || nu > GEN_MAX_NU)) {
         set_error("problem shape exceeds the generic kernel limits (nx <= 64, nu <= 32)");
