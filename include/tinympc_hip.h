@@ -116,6 +116,12 @@ int get_batch_size(void);
 int get_status(int *iter, int *solved, double *residuals4);
 /* Cold start: zero d, y, g, v, z of every instance (what tiny_setup leaves, tiny_api.cpp:73-88). */
 int reset_workspace(void);
+/* The fused closed loop on the process-global solver (tinympc_mpc_rollout / tinympc_set_ref_sequence below): `steps`
+ * repetitions of  set_x0 -> [set_x_ref / set_u_ref of the step] -> solve -> x0 = A x0 + B u0 + f  in one launch — the loop of
+ * examples/cartpole_example_mpc.jl:35-51 and examples/rocket_landing_constraints.jl:97-134.  Returns the status of the last
+ * step's solve (0 / 1) or -1; logs (any may be NULL) as tinympc_get_mpc_log. */
+int set_ref_sequence(double *x_ref_seq, int x_rows, int x_cols, double *u_ref_seq, int u_rows, int u_cols, int steps);
+int mpc_rollout(int steps, double *x_log, double *u_log, int *iter_log);
 
 /* ------------------------------------------------------------------------- */
 /* (2) handle API                                                            */

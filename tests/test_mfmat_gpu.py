@@ -472,3 +472,30 @@ def test_further_horizons_have_on_chip_kernels(hip_lib, oracle_built, shape):
             parity_every_instance(bs.get_solution(), bs.get_status(), ref, mk, x0, kw, prob.rho, min_same=0.95,
                                   tag=f"{shape} {kw['max_iter']} warm={warm}")
             bs.close()
+
+
+def test_rocket_loop_through_dropin_api(hip_lib):
+    """the fused rocket loop on the process-global entry points a Julia host binds (setup with fdyn and a batch,
+    set_bound_constraints, set_cone_constraints, set_ref_sequence, set_x0, mpc_rollout): the handle API's results, bit for bit"""
+    N, B, steps = 10, 64, 12
+    prob = t.problems.rocket(N)
+    x0 = t.problems.rocket_x0(B, seed=33)
+    xs, us = _rocket_ref_sequence(N, steps)
+    kw = dict(abs_pri_tol=2e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1)
+    bs = _solver(prob, B, kw, xs[:, :, 0], us[:, :, 0], prob.fdyn, ROCKET_CONES, True)
+    bs.set_ref_sequence(xs, us)
+    bs.set_x0(x0)
+    ref = bs.mpc_rollout(steps)
+    bs.close()
+    s = t.TinyMPCSolver()
+    t.setup(s, prob.A, prob.B, prob.fdyn, prob.Q, prob.R, prob.rho, 6, 3, N, batch=B, max_iter=100, abs_pri_tol=2e-3, abs_dua_tol=1e-3)
+    t.set_bound_constraints(s, prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    t.set_cone_constraints(s, *ROCKET_CONES)
+    t.set_ref_sequence(s, xs, us)
+    t.set_x0(s, x0)
+    got = t.mpc_rollout(s, steps)
+    assert t.kernel_name() == "mfmat<6,3,10>"
+    assert got["status"] == ref["status"]
+    for k in ("x", "u", "iter", "solved"):
+        assert np.array_equal(got[k], ref[k]), k
+    t.cleanup()

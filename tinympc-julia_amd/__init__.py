@@ -98,6 +98,8 @@ from .tinympc import (  # noqa: E402,F401
     load_library,
     print_problem_data,
     reset_workspace,
+    set_ref_sequence,
+    mpc_rollout,
     set_batch_size,
     set_bound_constraints,
     set_cache_terms,

@@ -807,5 +807,26 @@ int reset_workspace(void) {
     if (need_global("reset_workspace")) return -1;
     return each_global([&](tinympc_solver *h) { return tinympc_reset(h); });
 }
+// The fused closed loop on the process-global solver (one device): what examples/cartpole_example_mpc.jl:35-51 and
+// examples/rocket_landing_constraints.jl:97-134 do with one solve per host iteration, as one launch.
+int set_ref_sequence(double *x_ref_seq, int x_rows, int x_cols, double *u_ref_seq, int u_rows, int u_cols, int steps) {
+    if (need_global("set_ref_sequence")) return -1;
+    if (g_sharded) {
+        set_error("set_ref_sequence: not available on a sharded solver");
+        return -1;
+    }
+    return tinympc_set_ref_sequence(g_solver.get(), x_ref_seq, x_rows, x_cols, u_ref_seq, u_rows, u_cols, steps);
+}
+int mpc_rollout(int steps, double *x_log, double *u_log, int *iter_log) {
+    if (need_global("mpc_rollout")) return -1;
+    if (g_sharded) {
+        set_error("mpc_rollout: not available on a sharded solver");
+        return -1;
+    }
+    const int st = tinympc_mpc_rollout(g_solver.get(), steps, nullptr);
+    if (st < 0) return -1;
+    if ((x_log || u_log || iter_log) && tinympc_get_mpc_log(g_solver.get(), x_log, u_log, iter_log)) return -1;
+    return st;
+}
 
 }  // extern "C"

@@ -19,7 +19,7 @@ module TinyMPC
 # mirror (tinympc-julia_amd/tinympc.py) in tests/.  INTEGRATION.md shows the two-line change that
 # makes the reference's own src/TinyMPC.jl use this library without adopting this module.
 
-export TinyMPCSolver, setup, solve, get_solution, get_status, set_x0, set_x_ref, set_u_ref,
+export TinyMPCSolver, setup, solve, get_solution, get_solution!, get_status, set_x0, set_x_ref, set_u_ref, set_ref_sequence, mpc_rollout,
        set_bound_constraints, set_linear_constraints, set_equality_constraints, set_cone_constraints, update_settings,
        set_cache_terms, set_batch_size, set_gpus, get_gpus, set_warm_start, kernel_name, reset_workspace, print_problem_data,
        compute_sensitivity_autograd, set_sensitivity, get_adaptive_rho
@@ -191,6 +191,31 @@ function get_status(solver::TinyMPCSolver)
     _ok(ccall((:get_status, _lib_path()), Int32, (Ptr{Int32}, Ptr{Int32}, Ptr{Float64}), iter, solved, res),
         "Failed to get status")
     return (iter=iter, solved=solved, residuals=res)
+end
+
+# Shared references of every step of the next fused closed loops: x_ref_seq (nx, N, steps), u_ref_seq (nu, N-1, steps) —
+# what the loop of examples/rocket_landing_constraints.jl:107-115 passes to set_x_ref / set_u_ref step by step
+function set_ref_sequence(solver::TinyMPCSolver, x_ref_seq::Array{Float64,3}, u_ref_seq::Array{Float64,3})
+    _need(solver)
+    steps = size(x_ref_seq, 3)
+    (size(x_ref_seq) == (solver.nx, solver.N, steps) && size(u_ref_seq) == (solver.nu, solver.N - 1, steps)) ||
+        error("set_ref_sequence: x_ref_seq (nx, N, steps), u_ref_seq (nu, N-1, steps)")
+    _ok(ccall((:set_ref_sequence, _lib_path()), Int32, (Ptr{Float64}, Int32, Int32, Ptr{Float64}, Int32, Int32, Int32),
+              x_ref_seq, solver.nx, solver.N * steps, u_ref_seq, solver.nu, (solver.N - 1) * steps, steps),
+        "Failed to set the reference sequence")
+end
+
+# `steps` closed-loop MPC steps in ONE launch: solve -> u0 = controls[:, 1] -> x0 = A x0 + B u0 + f -> next solve, the
+# warm-start workspace staying on chip (the host loops of cartpole_example_mpc.jl:35-51, rocket_landing_constraints.jl:97-134).
+# Returns (status of the last solve, x (nx, steps, batch) plant states, u (nu, steps, batch) applied controls,
+# iter (steps, batch) ADMM iterations per step, negative where the step hit max_iter).
+function mpc_rollout(solver::TinyMPCSolver, steps::Integer)
+    _need(solver)
+    nx, nu, B = solver.nx, solver.nu, solver.batch
+    x, u, it = zeros(nx, steps, B), zeros(nu, steps, B), zeros(Int32, steps, B)
+    st = ccall((:mpc_rollout, _lib_path()), Int32, (Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}), steps, x, u, it)
+    st < 0 && error("mpc_rollout failed ($(_last_error()))")
+    return (status=st, x=x, u=u, iter=it)
 end
 
 function reset_workspace(solver::TinyMPCSolver)

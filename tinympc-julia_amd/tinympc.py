@@ -102,6 +102,8 @@ SIGNATURES = {
     "tinympc_set_x0_f32": (c_int, [c_vp, c_fp, c_int]),
     "tinympc_get_states_f32": (c_int, [c_vp, c_fp]),
     "tinympc_get_controls_f32": (c_int, [c_vp, c_fp]),
+    "set_ref_sequence": (c_int, [c_dp, c_int, c_int, c_dp, c_int, c_int, c_int]),
+    "mpc_rollout": (c_int, [c_int, c_dp, c_dp, c_ip]),
     "set_x0_f32": (c_int, [c_fp, c_int, c_int, c_int]),
     "get_states_f32": (c_int, [c_fp, c_ip, c_ip]),
     "get_controls_f32": (c_int, [c_fp, c_ip, c_ip]),
@@ -350,6 +352,31 @@ def get_status(solver):
     if load_library().get_status(it.ctypes.data_as(c_ip), so.ctypes.data_as(c_ip), _dp(res)) != 0:
         raise TinyMPCError(f"Failed to get status ({_err()})")
     return dict(iter=it, solved=so, residuals=res)
+
+
+def set_ref_sequence(solver, x_ref_seq, u_ref_seq):
+    """shared references of every step of the next closed loops, (nx, N, steps) / (nu, N-1, steps)"""
+    _need_setup(solver)
+    xs = np.asfortranarray(np.asarray(x_ref_seq, dtype=np.float64))
+    us = np.asfortranarray(np.asarray(u_ref_seq, dtype=np.float64))
+    steps = xs.shape[2]
+    xs, us = xs.reshape(-1, order="F"), us.reshape(-1, order="F")
+    if load_library().set_ref_sequence(_dp(xs), solver.nx, solver.N * steps, _dp(us), solver.nu, (solver.N - 1) * steps, steps) != 0:
+        raise TinyMPCError(f"Failed to set the reference sequence ({_err()})")
+
+
+def mpc_rollout(solver, steps):
+    """`steps` fused closed-loop steps on the global solver: dict(status, x (nx, steps, B), u (nu, steps, B), iter, solved)"""
+    _need_setup(solver)
+    nx, nu, B = solver.nx, solver.nu, solver.batch
+    x, u = np.zeros(nx * steps * B), np.zeros(nu * steps * B)
+    it = np.zeros(steps * B, dtype=np.int32)
+    st = int(load_library().mpc_rollout(int(steps), _dp(x), _dp(u), it.ctypes.data_as(c_ip)))
+    if st < 0:
+        raise TinyMPCError(f"mpc_rollout failed ({_err()})")
+    it = it.reshape((steps, B), order="F")
+    return dict(status=st, x=x.reshape((nx, steps, B), order="F"), u=u.reshape((nu, steps, B), order="F"),
+                iter=np.abs(it), solved=(it > 0).astype(np.int32))
 
 
 def reset_workspace(solver):
