@@ -507,29 +507,40 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
         int oxi = ox, oui = ou;
         asm volatile("" : "+v"(oxi), "+v"(oui));
         if (!conv) {                                           // a converged instance's state is frozen
+            // a group's cells and reference terms are read while the group before it is worked on (a lone wavefront sits
+            // out every LDS latency it has not hidden itself); lanes past the last knot read inside the allocation, unused
+            float nx_[NX], nu_[NU], nrx[NX], nru[NU];
+            auto fetch = [&](int m) {
+                lds_f *c = cq + m * 4 * PLEN;
+                const int kk = 4 * m + g;
+#pragma unroll
+                for (int r = 0; r < NX; ++r) nx_[r] = c[r * 16];
+#pragma unroll
+                for (int a = 0; a < NU; ++a) nu_[a] = c[U0 + a * 16];
+#pragma unroll
+                for (int r = 0; r < NX; ++r) nrx[r] = REFS == REF_SHARED ? s_ref[kk * NROW + r] : 0.f;
+#pragma unroll
+                for (int a = 0; a < NU; ++a) nru[a] = REFS == REF_SHARED ? s_ref[kk * NROW + NX + a] : 0.f;   // (the cell behind the last knot's is zero)
+            };
+            fetch(0);
             mf_for<0, NG>([&](auto mt) {
                 __builtin_amdgcn_sched_barrier(0);             // one group at a time: interleaved, their temporaries overflow the file
                 constexpr int m = decltype(mt)::value;
                 constexpr bool x_all = 4 * m + 3 < N, u_all = 4 * m + 3 < N - 1, u_any = 4 * m < N - 1;
                 const int kk = 4 * m + g;
                 lds_f *c = cq + m * 4 * PLEN;
+                float x[NX], u[NU], rfx[NX], rfu[NU];
+#pragma unroll
+                for (int r = 0; r < NX; ++r) x[r] = nx_[r], rfx[r] = nrx[r];
+#pragma unroll
+                for (int a = 0; a < NU; ++a) u[a] = nu_[a], rfu[a] = nru[a];
+                if constexpr (m + 1 < NG) fetch(m + 1);
                 if (x_all || kk < N) {
-                    float x[NX], sx[NX], vn[NX], vc[NVX], rfx[NX], rfu[NU];
+                    float sx[NX], vn[NX], vc[NVX];
+                    // (the terminal knot's reference enters through Pinf, admm.cpp:81-82, not through q)
+                    if constexpr (REFS == REF_SHARED && 4 * m + 3 >= N - 1) {
 #pragma unroll
-                    for (int r = 0; r < NX; ++r) x[r] = c[r * 16];
-                    // reference parts of the linear cost (admm.cpp:77-80; the terminal knot's enters through Pinf, :81-82)
-#pragma unroll
-                    for (int r = 0; r < NX; ++r) {
-                        rfx[r] = 0.f;
-                        if constexpr (REFS == REF_SHARED) {
-                            rfx[r] = s_ref[kk * NROW + r];
-                            if (4 * m + 3 >= N - 1 && kk == N - 1) rfx[r] = 0.f;
-                        }
-                    }
-#pragma unroll
-                    for (int a = 0; a < NU; ++a) {
-                        rfu[a] = 0.f;
-                        if constexpr (REFS == REF_SHARED) rfu[a] = s_ref[kk * NROW + NX + a];   // (the cell behind the last knot's is zero)
+                        for (int r = 0; r < NX; ++r) rfx[r] = kk == N - 1 ? 0.f : rfx[r];
                     }
 #pragma unroll
                     for (int r = 0; r < NX; ++r) {
@@ -600,9 +611,7 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
                     }
                     if constexpr (u_any) {
                         if (u_all || kk < N - 1) {
-                            float u[NU], su[NU], zn[NU], zc[NVU];
-#pragma unroll
-                            for (int a = 0; a < NU; ++a) u[a] = c[U0 + a * 16];
+                            float su[NU], zn[NU], zc[NVU];
 #pragma unroll
                             for (int a = 0; a < NU; ++a) {
                                 const float lo = BV ? s_bnd[kk * 2 * NROW + NX + a] : lo_s[NX + a],
