@@ -499,3 +499,57 @@ def test_rocket_loop_through_dropin_api(hip_lib):
     for k in ("x", "u", "iter", "solved"):
         assert np.array_equal(got[k], ref[k]), k
     t.cleanup()
+
+
+@pytest.mark.parametrize("N", [10, 50])
+@pytest.mark.parametrize("warm", [False, True])
+def test_mfmat_per_knot_bounds_random_family(hip_lib, oracle_built, N, warm):
+    """bounds that depend on the knot (the kernel's per-knot bound pack in LDS instead of scalars), a random stable family
+    instead of the rocket, no state bounds on half the rows: one-shot and with the workspace kept (second solve from the
+    plant's next state), every instance against the oracle"""
+    rng = np.random.default_rng(100 + N)
+    nx, nu, B = 6, 3, 45
+    A = np.eye(nx) + 0.2 * rng.standard_normal((nx, nx)) / np.sqrt(nx)
+    A *= 0.96 / np.abs(np.linalg.eigvals(A)).max()
+    prob = t.problems.Problem("rand", A, 0.5 * rng.standard_normal((nx, nu)), np.diag(rng.uniform(0.5, 5.0, nx)),
+                              np.diag(rng.uniform(0.5, 3.0, nu)), float(rng.uniform(0.5, 2.0)), N)
+    prob.x_min, prob.x_max = -rng.uniform(0.8, 2.0, (nx, 1)) * np.ones((1, N)), rng.uniform(0.8, 2.0, (nx, 1)) * np.ones((1, N))
+    prob.x_min[3:, :], prob.x_max[3:, :] = -1e17, 1e17
+    prob.x_min[:3, N // 2:] -= 0.3                          # per-knot
+    prob.u_min, prob.u_max = -rng.uniform(0.2, 0.6, (nu, 1)) * np.ones((1, N - 1)), rng.uniform(0.2, 0.6, (nu, 1)) * np.ones((1, N - 1))
+    prob.u_max[:, ::2] += 0.1
+    fdyn = 0.02 * rng.standard_normal(nx)
+    xr, ur = 0.2 * rng.standard_normal((nx, N)), 0.1 * rng.standard_normal((nu, N - 1))
+    cones = ([0], [3], [0.7], [0], [3], [1.1])
+    kw = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=60, check_termination=1)
+    x0 = np.asfortranarray(rng.uniform(-0.5, 0.5, (nx, B)))
+    mk = _oracle(oracle_built, prob, kw, xr, ur, fdyn, cones)
+    bs = _solver(prob, B, kw, xr, ur, fdyn, cones, warm)
+    orcs = [mk() for _ in range(B)]
+    x = x0.copy()
+    for k in range(2 if warm else 1):
+        ref = dict(x=np.zeros((nx, N, B)), u=np.zeros((nu, N - 1, B)), iter=np.zeros(B, dtype=int), solved=np.zeros(B, dtype=int),
+                   res=np.zeros((B, 4)))
+        pre = []
+        for b in range(B):
+            o = orcs[b]
+            o.set_x0(x[:, b])
+            pre.append((o.get_state(), o.get_cone_state()))
+            o.solve()
+            r = o.get_solution()
+            ref["x"][:, :, b], ref["u"][:, :, b], ref["iter"][b], ref["solved"][b], ref["res"][b] = r["x"], r["u"], r["iter"], r["solved"], r["res"]
+        bs.set_x0(x)
+        bs.solve()
+        assert bs.kernel_name == f"mfmat<6,3,{N}>"
+
+        def replay(b):                                       # an oracle at instance b's state BEFORE this solve
+            o = mk()
+            o.set_state(*[pre[b][0][key] for key in ("d", "y", "g", "v", "z")])
+            o.set_cone_state(**pre[b][1])
+            return o
+        parity_every_instance(bs.get_solution(), bs.get_status(), ref, replay, x, kw, prob.rho, tol=2e-5 if k else FP32_TOL,
+                              min_same=0.9, tag=f"N={N} warm={warm} solve {k}")
+        x = prob.A @ x + prob.B @ ref["u"][:, 0, :] + fdyn[:, None]
+    for o in orcs:
+        o.close()
+    bs.close()
