@@ -526,165 +526,167 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
             mf_for<0, NG>([&](auto mt) {
                 __builtin_amdgcn_sched_barrier(0);             // one group at a time: interleaved, their temporaries overflow the file
                 constexpr int m = decltype(mt)::value;
-                constexpr bool x_all = 4 * m + 3 < N, u_all = 4 * m + 3 < N - 1, u_any = 4 * m < N - 1;
+                constexpr bool x_all = 4 * m + 3 < N, u_all = 4 * m + 3 < N - 1;
                 const int kk = 4 * m + g;
                 lds_f *c = cq + m * 4 * PLEN;
+                const bool xv = x_all || kk < N, uv = u_all || kk < N - 1;   // (compile-time true except in the last group(s))
                 float x[NX], u[NU], rfx[NX], rfu[NU];
 #pragma unroll
                 for (int r = 0; r < NX; ++r) x[r] = nx_[r], rfx[r] = nrx[r];
 #pragma unroll
                 for (int a = 0; a < NU; ++a) u[a] = nu_[a], rfu[a] = nru[a];
                 if constexpr (m + 1 < NG) fetch(m + 1);
-                if (x_all || kk < N) {
-                    float sx[NX], vn[NX], vc[NVX];
-                    // (the terminal knot's reference enters through Pinf, admm.cpp:81-82, not through q)
-                    if constexpr (REFS == REF_SHARED && 4 * m + 3 >= N - 1) {
+                // (the terminal knot's reference enters through Pinf, admm.cpp:81-82, not through q)
+                if constexpr (REFS == REF_SHARED && 4 * m + 3 >= N - 1) {
 #pragma unroll
-                        for (int r = 0; r < NX; ++r) rfx[r] = kk == N - 1 ? 0.f : rfx[r];
-                    }
+                    for (int r = 0; r < NX; ++r) rfx[r] = kk == N - 1 ? 0.f : rfx[r];
+                }
+                // ---- all the arithmetic of the group first, in ONE basic block: the box and cone sets of the state rows and
+                // of the input rows are four independent chains (a cone's sqrt -> rcp -> selects chain alone is ~120 cycles of
+                // dependent issue for a lone wavefront), which the scheduler can only interleave if no branch separates them.
+                // Lanes past the last knot compute on whatever the allocation holds; only their stores and their residual
+                // terms are masked.
+                float sx[NX], vn[NX], vc[NVX], su[NU], zn[NU], zc[NVU];
+#pragma unroll
+                for (int r = 0; r < NX; ++r) {
+                    const float lo = BV ? s_bnd[(xv ? kk : 0) * 2 * NROW + r] : lo_s[r], hi = BV ? s_bnd[(xv ? kk : 0) * 2 * NROW + NROW + r] : hi_s[r];
+                    const float w = x[r] + LD(S_A1X, r);
+                    vn[r] = __builtin_amdgcn_fmed3f(w, lo, hi);                      // admm.cpp:52-56
+                    const float an = w - vn[r];                                      // admm.cpp:68
+                    ST(S_A1X, r, an);
+                    sx[r] = vn[r] - an;
+                }
+#pragma unroll
+                for (int a = 0; a < NU; ++a) {
+                    const float lo = BV ? s_bnd[(uv ? kk : 0) * 2 * NROW + NX + a] : lo_s[NX + a],
+                                hi = BV ? s_bnd[(uv ? kk : 0) * 2 * NROW + NROW + NX + a] : hi_s[NX + a];
+                    const float w = u[a] + LD(S_A1U, a);
+                    zn[a] = __builtin_amdgcn_fmed3f(w, lo, hi);
+                    const float an = w - zn[a];
+                    ST(S_A1U, a, an);
+                    su[a] = zn[a] - an;
+                }
+                if constexpr (CXQ > 0) {
+                    // every state row carries the cone set's slack and dual (the solver's arrays are full size); for a row
+                    // outside the cone the "projection" is the identity: slack = x, the dual stays zero
+                    float w2[NCX], a2n[NCX];
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) vc[r] = x[r];
+#pragma unroll
+                    for (int c2 = 0; c2 < CXQ; ++c2) w2[c2] = x[CXA + c2] + LD(S_A2X, c2), vc[CXA + c2] = w2[c2];
+                    float sc, ax_new;
+                    cone_scale(head_norm2(vc, CXA, CXQ), vc[CXA + CXQ - 1], mux, rmux, sc, ax_new);
+#pragma unroll
+                    for (int c2 = 0; c2 < CXQ - 1; ++c2) vc[CXA + c2] *= sc;
+                    vc[CXA + CXQ - 1] = ax_new;
+#pragma unroll
+                    for (int c2 = 0; c2 < CXQ; ++c2) a2n[c2] = w2[c2] - vc[CXA + c2], ST(S_A2X, c2, a2n[c2]);
 #pragma unroll
                     for (int r = 0; r < NX; ++r) {
-                        const float lo = BV ? s_bnd[kk * 2 * NROW + r] : lo_s[r], hi = BV ? s_bnd[kk * 2 * NROW + NROW + r] : hi_s[r];
-                        const float w = x[r] + LD(S_A1X, r);
-                        vn[r] = __builtin_amdgcn_fmed3f(w, lo, hi);                  // admm.cpp:52-56
-                        const float an = w - vn[r];                                  // admm.cpp:68
-                        ST(S_A1X, r, an);
-                        sx[r] = vn[r] - an;
+                        const bool in = r >= CXA && r < CXA + CXQ;
+                        sx[r] += in ? vc[r] - a2n[in ? r - CXA : 0] : x[r];
+                    }
+                }
+                if constexpr (CUQ > 0) {
+                    float w2[NCU], a2n[NCU];
+#pragma unroll
+                    for (int a = 0; a < NU; ++a) zc[a] = u[a];
+#pragma unroll
+                    for (int c2 = 0; c2 < CUQ; ++c2) w2[c2] = u[CUA + c2] + LD(S_A2U, c2), zc[CUA + c2] = w2[c2];
+                    float sc, ax_new;
+                    cone_scale(head_norm2(zc, CUA, CUQ), zc[CUA + CUQ - 1], muu, rmuu, sc, ax_new);
+#pragma unroll
+                    for (int c2 = 0; c2 < CUQ - 1; ++c2) zc[CUA + c2] *= sc;
+                    zc[CUA + CUQ - 1] = ax_new;
+#pragma unroll
+                    for (int c2 = 0; c2 < CUQ; ++c2) a2n[c2] = w2[c2] - zc[CUA + c2], ST(S_A2U, c2, a2n[c2]);
+#pragma unroll
+                    for (int a = 0; a < NU; ++a) {
+                        const bool in = a >= CUA && a < CUA + CUQ;
+                        su[a] += in ? zc[a] - a2n[in ? a - CUA : 0] : u[a];
+                    }
+                }
+                // what the backward sweep needs of a row is the linear-cost term (admm.cpp:77-80), not the sum itself:
+                // q = -(Xref Q~) - rho (sum over sets of slack - dual), r likewise
+                if (xv) {
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) c[r * 16] = rfx[r] - rho * sx[r];
+                }
+                if (uv) {
+#pragma unroll
+                    for (int a = 0; a < NU; ++a) c[U0 + a * 16] = rfu[a] - rho * su[a];
+                }
+                // ---- residual terms (admm.cpp:93-96) and, where this iteration may be the instance's last, the parking ----
+                if (need_res) {
+                    float gp = 0.f, gd = 0.f, hp = 0.f, hd = 0.f;
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) {
+                        gp = fmaxf(gp, fabsf(x[r] - vn[r]));
+                        gd = fmaxf(gd, fabsf(LD(S_VBX, r) - vn[r]));
                     }
                     if constexpr (CXQ > 0) {
-                        // every state row carries the cone set's slack and dual (the solver's arrays are full size); for a row
-                        // outside the cone the "projection" is the identity: slack = x, the dual stays zero
-                        float w2[NCX], a2n[NCX];
-#pragma unroll
-                        for (int r = 0; r < NX; ++r) vc[r] = x[r];
-#pragma unroll
-                        for (int c2 = 0; c2 < CXQ; ++c2) w2[c2] = x[CXA + c2] + LD(S_A2X, c2), vc[CXA + c2] = w2[c2];
-                        float sc, ax_new;
-                        cone_scale(head_norm2(vc, CXA, CXQ), vc[CXA + CXQ - 1], mux, rmux, sc, ax_new);
-#pragma unroll
-                        for (int c2 = 0; c2 < CXQ - 1; ++c2) vc[CXA + c2] *= sc;
-                        vc[CXA + CXQ - 1] = ax_new;
-#pragma unroll
-                        for (int c2 = 0; c2 < CXQ; ++c2) a2n[c2] = w2[c2] - vc[CXA + c2], ST(S_A2X, c2, a2n[c2]);
 #pragma unroll
                         for (int r = 0; r < NX; ++r) {
-                            const bool in = r >= CXA && r < CXA + CXQ;
-                            sx[r] += in ? vc[r] - a2n[in ? r - CXA : 0] : x[r];
+                            if (r >= CXA && r < CXA + CXQ) gp = fmaxf(gp, fabsf(x[r] - vc[r]));
+                            gd = fmaxf(gd, fabsf(LD(S_VCX, r) - vc[r]));
                         }
                     }
-                    if (need_res) {
-                        float gp = 0.f, gd = 0.f;
 #pragma unroll
-                        for (int r = 0; r < NX; ++r) {
-                            gp = fmaxf(gp, fabsf(x[r] - vn[r]));
-                            gd = fmaxf(gd, fabsf(LD(S_VBX, r) - vn[r]));
+                    for (int a = 0; a < NU; ++a) {
+                        hp = fmaxf(hp, fabsf(u[a] - zn[a]));
+                        hd = fmaxf(hd, fabsf(LD(S_VBU, a) - zn[a]));
+                    }
+                    if constexpr (CUQ > 0) {
+#pragma unroll
+                        for (int a = 0; a < NU; ++a) {
+                            if (a >= CUA && a < CUA + CUQ) hp = fmaxf(hp, fabsf(u[a] - zc[a]));
+                            hd = fmaxf(hd, fabsf(LD(S_VCU, a) - zc[a]));
                         }
+                    }
+                    if (xv) pri_x = fmaxf(pri_x, gp), dua_x = fmaxf(dua_x, gd);
+                    if (uv) pri_u = fmaxf(pri_u, hp), dua_u = fmaxf(dua_u, hd);
+                    if (park && active && xv && gp < ptol && gd * rho < dtol) {          // this iteration may be the instance's last
+                        kparam_ptr Pk = kparams();
+                        float *pv = Pk->sv + oxi + m * 4 * NX;
+#pragma unroll
+                        for (int r = 0; r < NX; ++r) pv[r] = LD(S_VBX, r);
                         if constexpr (CXQ > 0) {
+                            float *pvc = Pk->svc + oxi + m * 4 * NX;
 #pragma unroll
-                            for (int r = 0; r < NX; ++r) {
-                                if (r >= CXA && r < CXA + CXQ) gp = fmaxf(gp, fabsf(x[r] - vc[r]));
-                                gd = fmaxf(gd, fabsf(LD(S_VCX, r) - vc[r]));
-                            }
-                        }
-                        pri_x = fmaxf(pri_x, gp), dua_x = fmaxf(dua_x, gd);
-                        if (park && active && gp < ptol && gd * rho < dtol) {          // this iteration may be the instance's last
-                            kparam_ptr Pk = kparams();
-                            float *pv = Pk->sv + oxi + m * 4 * NX;
-#pragma unroll
-                            for (int r = 0; r < NX; ++r) pv[r] = LD(S_VBX, r);
-                            if constexpr (CXQ > 0) {
-                                float *pvc = Pk->svc + oxi + m * 4 * NX;
-#pragma unroll
-                                for (int r = 0; r < NX; ++r) pvc[r] = LD(S_VCX, r);
-                            }
+                            for (int r = 0; r < NX; ++r) pvc[r] = LD(S_VCX, r);
                         }
                     }
+                    if (park && active && uv && hp < ptol && hd * rho < dtol) {
+                        kparam_ptr Pk = kparams();
+                        float *pz = Pk->sz + oui + m * 4 * NU, *pd = Pk->sd + oui + m * 4 * NU;
+#pragma unroll
+                        for (int a = 0; a < NU; ++a) pz[a] = LD(S_VBU, a);
+                        if constexpr (CUQ > 0) {
+                            float *pzc = Pk->szc + oui + m * 4 * NU;
+#pragma unroll
+                            for (int a = 0; a < NU; ++a) pzc[a] = LD(S_VCU, a);
+                        }
+                        // the feed-forward term this iteration's rollout used: d = -Kinf x - u (admm.cpp:29)
+#pragma unroll
+                        for (int a = 0; a < NU; ++a) {
+                            double acc = 0.0;
+#pragma unroll
+                            for (int r = 0; r < NX; ++r) acc = fma(gk64[T::O_KINF + a * NX + r], (double)x[r], acc);
+                            pd[a] = (float)(-acc - (double)u[a]);
+                        }
+                    }
+                }
+                // ---- the previous-slack registers take this iteration's slack where something will read it ----
+                if (upd_old) {
 #pragma unroll
                     for (int r = 0; r < NX; ++r) {
-                        if (upd_old) {
-                            ST(S_VBX, r, vn[r]);
-                            if constexpr (CXQ > 0) ST(S_VCX, r, vc[r]);
-                        }
-                        // what the backward sweep needs of this row is the linear-cost term (admm.cpp:79-80), not the sum
-                        // itself: q = -(Xref Q~) - rho (sum over sets of slack - dual)
-                        c[r * 16] = rfx[r] - rho * sx[r];
+                        ST(S_VBX, r, vn[r]);
+                        if constexpr (CXQ > 0) ST(S_VCX, r, vc[r]);
                     }
-                    if constexpr (u_any) {
-                        if (u_all || kk < N - 1) {
-                            float su[NU], zn[NU], zc[NVU];
 #pragma unroll
-                            for (int a = 0; a < NU; ++a) {
-                                const float lo = BV ? s_bnd[kk * 2 * NROW + NX + a] : lo_s[NX + a],
-                                            hi = BV ? s_bnd[kk * 2 * NROW + NROW + NX + a] : hi_s[NX + a];
-                                const float w = u[a] + LD(S_A1U, a);
-                                zn[a] = __builtin_amdgcn_fmed3f(w, lo, hi);
-                                const float an = w - zn[a];
-                                ST(S_A1U, a, an);
-                                su[a] = zn[a] - an;
-                            }
-                            if constexpr (CUQ > 0) {
-                                float w2[NCU], a2n[NCU];
-#pragma unroll
-                                for (int a = 0; a < NU; ++a) zc[a] = u[a];
-#pragma unroll
-                                for (int c2 = 0; c2 < CUQ; ++c2) w2[c2] = u[CUA + c2] + LD(S_A2U, c2), zc[CUA + c2] = w2[c2];
-                                float sc, ax_new;
-                                cone_scale(head_norm2(zc, CUA, CUQ), zc[CUA + CUQ - 1], muu, rmuu, sc, ax_new);
-#pragma unroll
-                                for (int c2 = 0; c2 < CUQ - 1; ++c2) zc[CUA + c2] *= sc;
-                                zc[CUA + CUQ - 1] = ax_new;
-#pragma unroll
-                                for (int c2 = 0; c2 < CUQ; ++c2) a2n[c2] = w2[c2] - zc[CUA + c2], ST(S_A2U, c2, a2n[c2]);
-#pragma unroll
-                                for (int a = 0; a < NU; ++a) {
-                                    const bool in = a >= CUA && a < CUA + CUQ;
-                                    su[a] += in ? zc[a] - a2n[in ? a - CUA : 0] : u[a];
-                                }
-                            }
-                            if (need_res) {
-                                float gp = 0.f, gd = 0.f;
-#pragma unroll
-                                for (int a = 0; a < NU; ++a) {
-                                    gp = fmaxf(gp, fabsf(u[a] - zn[a]));
-                                    gd = fmaxf(gd, fabsf(LD(S_VBU, a) - zn[a]));
-                                }
-                                if constexpr (CUQ > 0) {
-#pragma unroll
-                                    for (int a = 0; a < NU; ++a) {
-                                        if (a >= CUA && a < CUA + CUQ) gp = fmaxf(gp, fabsf(u[a] - zc[a]));
-                                        gd = fmaxf(gd, fabsf(LD(S_VCU, a) - zc[a]));
-                                    }
-                                }
-                                pri_u = fmaxf(pri_u, gp), dua_u = fmaxf(dua_u, gd);
-                                if (park && active && gp < ptol && gd * rho < dtol) {
-                                    kparam_ptr Pk = kparams();
-                                    float *pz = Pk->sz + oui + m * 4 * NU, *pd = Pk->sd + oui + m * 4 * NU;
-#pragma unroll
-                                    for (int a = 0; a < NU; ++a) pz[a] = LD(S_VBU, a);
-                                    if constexpr (CUQ > 0) {
-                                        float *pzc = Pk->szc + oui + m * 4 * NU;
-#pragma unroll
-                                        for (int a = 0; a < NU; ++a) pzc[a] = LD(S_VCU, a);
-                                    }
-                                    // the feed-forward term this iteration's rollout used: d = -Kinf x - u (admm.cpp:29)
-#pragma unroll
-                                    for (int a = 0; a < NU; ++a) {
-                                        double acc = 0.0;
-#pragma unroll
-                                        for (int r = 0; r < NX; ++r) acc = fma(gk64[T::O_KINF + a * NX + r], (double)x[r], acc);
-                                        pd[a] = (float)(-acc - (double)u[a]);
-                                    }
-                                }
-                            }
-#pragma unroll
-                            for (int a = 0; a < NU; ++a) {
-                                if (upd_old) {
-                                    ST(S_VBU, a, zn[a]);
-                                    if constexpr (CUQ > 0) ST(S_VCU, a, zc[a]);
-                                }
-                                c[U0 + a * 16] = rfu[a] - rho * su[a];                   // r = -(Uref R~) - rho (...), admm.cpp:77-78
-                            }
-                        }
+                    for (int a = 0; a < NU; ++a) {
+                        ST(S_VBU, a, zn[a]);
+                        if constexpr (CUQ > 0) ST(S_VCU, a, zc[a]);
                     }
                 }
             });
