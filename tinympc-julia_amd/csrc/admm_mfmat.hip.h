@@ -395,6 +395,9 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
 #else
 #define TMPC_TPROBE(x)
 #endif
+#ifndef TMPC_MFMAT_SB
+#define TMPC_MFMAT_SB 2                                      // steps of the time recurrences per run of matrix-core products
+#endif
     int conv = 0, it = 0;
     float res0 = 0.f, res1 = 0.f, res2 = 0.f, res3 = 0.f;
     for (int step = 0; step < n_steps; ++step) {
@@ -448,57 +451,80 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
                 if (!slot1_x) a1 = tb_next;                    // passenger: the next step's matrix-core component of t
                 c[0] = a0, c[1] = a1, c[2] = a2;
             };
-            float tvn[VUA] = {0.f};
-            float tbn = 0.f;
-            ldV(0, tvn);
-            mf_d4 cX = {x0r[0], slot1_x ? x0r[1] : (double)ldB(0), 0.0, 0.0};
-            mf_d4 cY = {0.0, 0.0, 0.0, 0.0};
-            {
-                double tvd0[VUA];
-#pragma unroll
-                for (int v = 0; v < VUA; ++v) tvd0[v] = (double)tvn[v];
-                start(cY, tvd0, STEPS > 1 ? (double)ldB(1) : 0.0);
-            }
-            if (STEPS > 1) ldV(1, tvn);
-            if (STEPS > 2) tbn = ldB(2);
-            auto handover = [&](const mf_d4 &c, bool has_u) {   // x_k (k = 0: x0 itself — the cell held the sets' sum), u_{k-1}
-                if (has_u && (FREE || ok2)) pp[U0 - PLEN] = (float)c[2];             // (t_{k-1} is spent)
-                if (FREE || ok1) pp[64] = (float)c[1];
-                pp[0] = (float)c[0];
+            auto handover = [&](const mf_d4 &c, int k) {        // x_k (k = 0: x0 itself — the cell held the sets' sum), u_{k-1}
+                lds_f *pk = pp + k * PLEN;
+                if (k > 0 && (FREE || ok2)) pk[U0 - PLEN] = (float)c[2];             // (t_{k-1} is spent)
+                if (FREE || ok1) pk[64] = (float)c[1];
+                // (the order of a mask-free store and the owner's store to the same cell is an order between LANES, which the
+                // compiler does not see — to it the two addresses never alias, and it has moved one across the other; LDS
+                // executes a wavefront's stores in program order, so a wavefront-scope fence — no instruction — is all it takes)
+                if constexpr (FREE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                pk[0] = (float)c[0];
             };
-            // (order of a step, from experiments/mfmat_cost_probe.hip: an fp64 product holds the wavefront's issue for ~66 cycles
+            // (order of the work, from experiments/mfmat_cost_probe.hip: an fp64 product holds the wavefront's issue for ~66 cycles
             // whatever follows, and the FIRST vector / LDS instruction behind products costs a flat ~55 cycles more, the
-            // rest ~4 each — so the two products go back to back and ALL the vector work of the step in one block behind
-            // them; split around the second product it pays the flat cost twice: 281 against 255 cycles per step)
-            auto fstep = [&](int k, mf_d4 &cprev, mf_d4 &cacc) {
-                cacc = mf_mma(cf[T::L_MF0], cprev[0], cacc);
-                cacc = mf_mma(cf[T::L_MF1], cprev[1], cacc);
-                __builtin_amdgcn_sched_barrier(0);             // (left to itself the scheduler puts a hand-over in front of the products)
-                handover(cprev, k > 0);
-                if (k + 1 < STEPS) {
-                    double tvd[VUA];
-#pragma unroll
-                    for (int v = 0; v < VUA; ++v) tvd[v] = (double)tvn[v];
-                    start(cprev, tvd, (double)tbn);
-                    if (k + 2 < STEPS) ldV(k + 2, tvn);
-                    if (k + 3 < STEPS) tbn = ldB(k + 3);
-                }
-                pp += PLEN;
-                __builtin_amdgcn_sched_barrier(0);
+            // rest ~4 each — so products go back to back and the vector work in one block behind them; split around the
+            // second product of a step it pays the flat cost twice: 281 against 255 cycles per step.  And the flat cost is per
+            // block, not per step: SB steps' products — step k + 1's operands ARE step k's result registers — are issued as
+            // one run, SB + 1 accumulator tuples taking turns, and the hand-overs and next starts of all SB steps follow as one block.)
+            constexpr int SB = TMPC_MFMAT_SB, NT = SB + 1;
+            mf_d4 c[NT];
+            float tvn[SB][VUA], tbn[SB];
+            auto ld = [&](int k, int sl) {                      // what the start of step k is formed from (cells the sweep left)
+                if (k < STEPS) ldV(k, tvn[sl]);
+                tbn[sl] = k + 1 < STEPS ? ldB(k + 1) : 0.f;
             };
-            for (int k = 0; k + 1 < STEPS; k += 2) {
-                fstep(k, cX, cY);
-                fstep(k + 1, cY, cX);
-            }
-            if constexpr (STEPS % 2 == 1) {
-                fstep(STEPS - 1, cX, cY);
-                handover(cY, true);
-            } else {
-                handover(cX, true);
-            }
+            auto start_of = [&](mf_d4 &cc, int sl) {
+                double tvd[VUA];
+#pragma unroll
+                for (int v = 0; v < VUA; ++v) tvd[v] = (double)tvn[sl][v];
+                start(cc, tvd, (double)tbn[sl]);
+            };
+#pragma unroll
+            for (int t2 = 0; t2 < NT; ++t2) c[t2] = mf_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int sl = 0; sl < SB; ++sl)
+#pragma unroll
+                for (int v = 0; v < VUA; ++v) tvn[sl][v] = 0.f;
+            c[0][0] = x0r[0], c[0][1] = slot1_x ? x0r[1] : (double)ldB(0);
+            mf_for<0, SB>([&](auto st) {
+                constexpr int sl = decltype(st)::value;
+                if constexpr (sl < STEPS) {
+                    ld(sl, sl);
+                    start_of(c[sl + 1], sl);
+                }
+            });
+            mf_for<0, SB>([&](auto st) {
+                constexpr int sl = decltype(st)::value;
+                if constexpr (SB + sl < STEPS) ld(SB + sl, sl);
+            });
+            mf_for<0, (STEPS + SB - 1) / SB>([&](auto bt) {
+                constexpr int k0 = decltype(bt)::value * SB;
+                constexpr int nb = STEPS - k0 < SB ? STEPS - k0 : SB;
+                mf_for<0, nb>([&](auto st) {
+                    constexpr int k = k0 + decltype(st)::value;
+                    c[(k + 1) % NT] = mf_mma(cf[T::L_MF0], c[k % NT][0], c[(k + 1) % NT]);
+                    c[(k + 1) % NT] = mf_mma(cf[T::L_MF1], c[k % NT][1], c[(k + 1) % NT]);
+                });
+                __builtin_amdgcn_sched_barrier(0);             // (left to itself the scheduler puts a hand-over in front of the products)
+                mf_for<0, nb>([&](auto st) {
+                    constexpr int k = k0 + decltype(st)::value;
+                    handover(c[k % NT], k);
+                });
+                mf_for<0, SB>([&](auto st) {
+                    constexpr int sl = decltype(st)::value, k = k0 + SB + sl;  // a step of the next run: its tuple held x_{k - SB}, handed over above
+                    if constexpr (k < STEPS) {
+                        start_of(c[(k + 1) % NT], sl);
+                        if constexpr (k + SB < STEPS) ld(k + SB, sl);
+                    }
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            handover(c[STEPS % NT], STEPS);
             // (slot 3 of the tuples — tile rows 12.. — is never read; "used" here so that the register allocator does not
             // park temporaries in it: a vector write into a tuple that a product in flight is about to overwrite waits for it)
-            asm volatile("" ::"v"(cX[3]), "v"(cY[3]));
+#pragma unroll
+            for (int t2 = 0; t2 < NT; ++t2) asm volatile("" ::"v"(c[t2][3]));
         }
         __syncthreads();
         TMPC_TPROBE(const long long tp1 = clock64(); T_f += tp1 - tp0;)
@@ -746,43 +772,55 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
                 if (!slot1_x) a1 = o.rb;                       // passenger: the next stage's matrix-core component of r
                 c[0] = a0, c[1] = a1, c[2] = a2;
             };
-            mf_d4 cX, cY;
+            // stage index s = N - 2 - kn ascending; stage s reads the tuple s % NT (p_{kn+1}, t_{kn+1}) and accumulates into the
+            // next one; runs of SB stages as in the rollout
+            constexpr int STG = N - 1, SB = TMPC_MFMAT_SB, NT = SB + 1;
+            mf_d4 c[NT];
+#pragma unroll
+            for (int t2 = 0; t2 < NT; ++t2) c[t2] = mf_d4{0.0, 0.0, 0.0, 0.0};
             {
                 double pt0 = 0.0, pt1 = 0.0;
                 if constexpr (REFS == REF_SHARED) pt0 = s_pterm[g], pt1 = s_pterm[row1c];
                 const double p0 = pt0 + (double)pc[(N - 1) * PLEN + g * 16];                   // admm.cpp:81-82
                 const double p1 = pt1 + (double)pc[(N - 1) * PLEN + row1c * 16];
-                cX = mf_d4{p0, slot1_x ? p1 : (double)lin(N - 2, rowB), 0.0, 0.0};
+                c[0][0] = p0, c[0][1] = slot1_x ? p1 : (double)lin(N - 2, rowB);
             }
-            cY = mf_d4{0.0, 0.0, 0.0, 0.0};
-            start(cY, widen(operands(N - 2)));
-            Ops on = operands(N >= 3 ? N - 3 : 0);
+            Ops on[SB];
+            mf_for<0, SB>([&](auto st) {
+                constexpr int sl = decltype(st)::value;
+                if constexpr (sl < STG) start(c[sl + 1], widen(operands(N - 2 - sl)));
+            });
+            mf_for<0, SB>([&](auto st) {
+                constexpr int sl = decltype(st)::value;
+                on[sl] = operands(SB + sl < STG ? N - 2 - SB - sl : 0);
+            });
             lds_f *const tw = cm + U0;                                               // + position * PLEN: the cell of a knot's t
             const bool tmask = ok2 && !conv;                                         // (a converged instance keeps its feed-forward term)
-            auto bstage = [&](int kn, mf_d4 &cprev, mf_d4 &cacc) {
-                cacc = mf_mma(cf[T::L_MB0], cprev[0], cacc);                         // [AmBKt; B'] p (+ -Kinf' r)
-                cacc = mf_mma(cf[T::L_MB1], cprev[1], cacc);
+            mf_for<0, (STG + SB - 1) / SB>([&](auto bt) {
+                constexpr int s0 = decltype(bt)::value * SB;
+                constexpr int nb = STG - s0 < SB ? STG - s0 : SB;
+                mf_for<0, nb>([&](auto st) {
+                    constexpr int sg = s0 + decltype(st)::value;
+                    c[(sg + 1) % NT] = mf_mma(cf[T::L_MB0], c[sg % NT][0], c[(sg + 1) % NT]);   // [AmBKt; B'] p (+ -Kinf' r)
+                    c[(sg + 1) % NT] = mf_mma(cf[T::L_MB1], c[sg % NT][1], c[(sg + 1) % NT]);
+                });
                 __builtin_amdgcn_sched_barrier(0);
-                if (kn < N - 2 && tmask) tw[(kn + 1) * PLEN] = (float)cprev[2];      // t_{kn+1}
-                if (kn >= 1) {
-                    start(cprev, widen(on));
-                    if (kn >= 2) on = operands(kn - 2);
-                }
+                mf_for<0, nb>([&](auto st) {
+                    constexpr int sg = s0 + decltype(st)::value, kn = N - 2 - sg;
+                    if (kn < N - 2 && tmask) tw[(kn + 1) * PLEN] = (float)c[sg % NT][2];        // t_{kn+1}
+                });
+                mf_for<0, SB>([&](auto st) {
+                    constexpr int sl = decltype(st)::value, sg = s0 + SB + sl;
+                    if constexpr (sg < STG) {
+                        start(c[(sg + 1) % NT], widen(on[sl]));
+                        if constexpr (sg + SB < STG) on[sl] = operands(N - 2 - sg - SB);
+                    }
+                });
                 __builtin_amdgcn_sched_barrier(0);
-            };
-            // (unrolled: the cell addresses are immediates and the edge conditions fold)
+            });
+            if (tmask) tw[0] = (float)c[STG % NT][2];                                // t_0
 #pragma unroll
-            for (int i = 0; i < (N - 1) / 2; ++i) {
-                bstage(N - 2 - 2 * i, cX, cY);
-                bstage(N - 3 - 2 * i, cY, cX);
-            }
-            if constexpr ((N - 1) % 2 == 1) {
-                bstage(0, cX, cY);
-                if (tmask) tw[0] = (float)cY[2];                                     // t_0
-            } else {
-                if (tmask) tw[0] = (float)cX[2];
-            }
-            asm volatile("" ::"v"(cX[3]), "v"(cY[3]));
+            for (int t2 = 0; t2 < NT; ++t2) asm volatile("" ::"v"(c[t2][3]));
         }
         __syncthreads();
         TMPC_TPROBE(T_b += clock64() - tp2;)
