@@ -533,20 +533,17 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
         int oxi = ox, oui = ou;
         asm volatile("" : "+v"(oxi), "+v"(oui));
         if (!conv) {                                           // a converged instance's state is frozen
-            // a group's cells and reference terms are read while the group before it is worked on (a lone wavefront sits
-            // out every LDS latency it has not hidden itself); lanes past the last knot read inside the allocation, unused
-            float nx_[NX], nu_[NU], nrx[NX], nru[NU];
+            // a group's cells are read while the group before it is worked on (a lone wavefront sits out every LDS latency it
+            // has not hidden itself); its reference terms are needed only at the END of its arithmetic and are read at its
+            // start — a group ahead they would be nine more registers across the group with the most live values.  Lanes
+            // past the last knot read inside the allocation, unused
+            float nx_[NX], nu_[NU];
             auto fetch = [&](int m) {
                 lds_f *c = cq + m * 4 * PLEN;
-                const int kk = 4 * m + g;
 #pragma unroll
                 for (int r = 0; r < NX; ++r) nx_[r] = c[r * 16];
 #pragma unroll
                 for (int a = 0; a < NU; ++a) nu_[a] = c[U0 + a * 16];
-#pragma unroll
-                for (int r = 0; r < NX; ++r) nrx[r] = REFS == REF_SHARED ? s_ref[kk * NROW + r] : 0.f;
-#pragma unroll
-                for (int a = 0; a < NU; ++a) nru[a] = REFS == REF_SHARED ? s_ref[kk * NROW + NX + a] : 0.f;   // (the cell behind the last knot's is zero)
             };
             fetch(0);
             mf_for<0, NG>([&](auto mt) {
@@ -558,9 +555,9 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
                 const bool xv = x_all || kk < N, uv = u_all || kk < N - 1;   // (compile-time true except in the last group(s))
                 float x[NX], u[NU], rfx[NX], rfu[NU];
 #pragma unroll
-                for (int r = 0; r < NX; ++r) x[r] = nx_[r], rfx[r] = nrx[r];
+                for (int r = 0; r < NX; ++r) x[r] = nx_[r], rfx[r] = REFS == REF_SHARED ? s_ref[kk * NROW + r] : 0.f;
 #pragma unroll
-                for (int a = 0; a < NU; ++a) u[a] = nu_[a], rfu[a] = nru[a];
+                for (int a = 0; a < NU; ++a) u[a] = nu_[a], rfu[a] = REFS == REF_SHARED ? s_ref[kk * NROW + NX + a] : 0.f;   // (the cell behind the last knot's is zero)
                 if constexpr (m + 1 < NG) fetch(m + 1);
                 // (the terminal knot's reference enters through Pinf, admm.cpp:81-82, not through q)
                 if constexpr (REFS == REF_SHARED && 4 * m + 3 >= N - 1) {
