@@ -37,8 +37,12 @@
 // slack to an HBM scratch, and the checking iteration reads them back: once per solve for the fixed-iteration benchmark
 // configs, every check_termination-th iteration otherwise.
 //
+// Linear-inequality rows (LIN; `Alin_x x <= blin_x`, `Alin_u u <= blin_u` at every knot, bindings.cpp:414-450) are a third
+// set per side with ONE slack and ONE dual array like the others: its dual takes NX (NU) more rows of a position, the
+// projection is one instance sum (the row's dot product) per row, rows one after the other as the solver applies them.
+//
 // Scope: one-shot solves (cold start, workspace not kept), shared or zero references, at most 8 state / 4 input rows,
-// cones and box bounds as the C-ABI takes them; no linear-inequality rows, no per-instance families, no adaptive rho
+// box bounds, up to two cones per side and linear rows as the C-ABI takes them; no per-instance families, no adaptive rho
 // (those stay on the stream / generic kernels).  Precision as everywhere: fp64 recurrences, fp32 state.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -64,12 +68,16 @@ struct ConeShape {
     // a cone] x 16 instances, + one zero pad cell per lane for the slots a lane does not own
     static constexpr int pos_len(int cone_rows) { return 16 * (2 * NROW + cone_rows); }
     static constexpr int PAD_LEN = 64 + 16 * NROW;  // a lane's pad cell and its A3 twin (A3_DISP further on)
-    static constexpr size_t lds_bytes(int N, int nk, int cone_rows) {
-        return sizeof(float) * ((size_t)pos_len(cone_rows) * (N - 1) + PAD_LEN + ((bounds_len(nk) + 1) & ~1) + (((size_t)NROW * N + 2) & ~(size_t)1) +
-                               256 + 200) + sizeof(double) * 8;   // ... + hand-over ring + residual / flag exchange
+    // linear rows: per-lane coefficients [mlx][2 slots][64] + [mlu][64], then b and 1 / |a|^2 of every row (even count)
+    static constexpr int lin_len(int mlx, int mlu) { return (2 * mlx + mlu) * 64 + ((2 * (mlx + mlu) + 1) & ~1); }
+    // (`set_rows` = the rows that lie in a cone + the rows of the sides that have linear rows: duals beyond the box set's)
+    static constexpr size_t lds_bytes(int N, int nk, int set_rows, int mlx = 0, int mlu = 0) {
+        return sizeof(float) * ((size_t)pos_len(set_rows) * (N - 1) + PAD_LEN + ((bounds_len(nk) + 1) & ~1) + (((size_t)NROW * N + 2) & ~(size_t)1) +
+                               256 + 200 + (mlx + mlu > 0 ? lin_len(mlx, mlu) : 0)) + sizeof(double) * 8;   // ... + hand-over ring + residual / flag exchange
     }
-    // HBM scratch per wavefront (floats): cone slack of the iteration before a check, [pos 0..N-1][slot][lane]
-    static constexpr size_t scratch_floats(int N) { return (size_t)N * 3 * 64; }
+    // HBM scratch per wavefront (floats): cone slack (and behind it the linear sets' slack) of the iteration before a
+    // check, [pos 0..N-1][slot][lane]
+    static constexpr size_t scratch_floats(int N) { return (size_t)N * 3 * 64 * 2; }
 };
 
 // sum over the four lanes (16 apart) of an instance, on the VALU: v_permlane16_swap exchanges the odd 16-lane rows of
@@ -87,15 +95,20 @@ __device__ __forceinline__ float mfc_inst_sum(float v) {
     return a + b;
 }
 
-// CX / CU: one second-order cone on the state / input side (0: none).  More than one cone per side stays on the stream
-// kernel: with the cone count a compile-time constant the knot loops are straight-line code the scheduler can interleave
-// with the matrix products.
-template <int NX, int NU, int REFS, int CX, int CU, bool BV>
+// CX / CU: the number of second-order cones on the state / input side (0, 1 or 2; bindings.cpp:453-490 takes cone LISTS).
+// The cones of a side share ONE slack and ONE dual array (admm.cpp:57-64 projects each cone's block of `x + gc` into its
+// block of the slack; rows in no cone pass through), so a second cone is a second pair of instance sums over another set
+// of row weights, applied to the same two values per lane.  The count is a compile-time constant: the knot loops stay
+// straight-line code the scheduler can interleave with the matrix products.  More cones per side stay on the stream kernel.
+// (A second cone or linear rows cost LDS, and LDS is what bounds this kernel: each tile's chain wavefront is busy a
+// fraction of the time, so throughput is tiles per CU.  Rocket, N = 30: 24 floats per knot -> three tiles per CU, 27 or 30
+// -> two: 7.9 / 8.6 ms against 5.2, no faster than the stream kernel on the same problems — see Solver::select_kernel.)
+template <int NX, int NU, int REFS, int CX, int CU, bool BV, bool LIN = false>
 __global__ __launch_bounds__(192) void admm_mfmac_kernel(const AdmmParams P) {
     using S = ConeShape<NX, NU>;
     constexpr int XS = S::XS, NROW = S::NROW;
     constexpr bool EXT = CX + CU > 0;
-    static_assert(CX >= 0 && CX <= 1 && CU >= 0 && CU <= 1, "at most one cone per side");
+    static_assert(CX >= 0 && CX <= 2 && CU >= 0 && CU <= 2, "at most two cones per side");
     extern __shared__ __align__(16) unsigned char s_raw_c[];
     const int N = P.N;
     constexpr int ncx = CX, ncu = CU;
@@ -112,7 +125,9 @@ __global__ __launch_bounds__(192) void admm_mfmac_kernel(const AdmmParams P) {
     };
     int cone_rows = 0;
     for (int rho = 0; rho < NROW; ++rho) cone_rows += in_cone(rho) ? 1 : 0;
-    const int PLEN = S::pos_len(cone_rows);
+    const int mlx = LIN ? P.mlx : 0, mlu = LIN ? P.mlu : 0;   // linear rows per side
+    const int lin_rows = (mlx > 0 ? NX : 0) + (mlu > 0 ? NU : 0);
+    const int PLEN = S::pos_len(cone_rows + lin_rows);
     const int nk = BV ? N : 1;   // BV: the bounds depend on the knot (per-knot pack in LDS), else one knot's worth in registers
     float *s_state = reinterpret_cast<float *>(s_raw_c);
     float *s_pad = s_state + (size_t)PLEN * (N - 1);          // S::PAD_LEN zeros: what lanes without a row read and write
@@ -121,6 +136,8 @@ __global__ __launch_bounds__(192) void admm_mfmac_kernel(const AdmmParams P) {
     double *s_pterm = reinterpret_cast<double *>(s_ref + (((size_t)NROW * N + 2) & ~(size_t)1));
     float *s_ring = reinterpret_cast<float *>(s_pterm + 8);   // pri_u[64] dua_u[64] (wave 2 -> 0)
     float *s_xchg = s_ring + 256;                             // pri_x[64] dua_x[64] (wave 1 -> 0), conv[64], any_left (wave 0 -> 1, 2), [196] step counter
+    float *s_lin = s_xchg + 200;                              // LIN: [mlx][2][64] | [mlu][64] | b, 1 / |a|^2 per row (state rows first)
+    float *s_lb = s_lin + (2 * mlx + mlu) * 64;
     __shared__ uint4 s_cmask[8 * 4];  // [cone][lane group]: x head bits, x axis bits, u head bit, u axis bit (bit = slot)
 
     const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, g = l >> 4, j = l & 15;
@@ -185,6 +202,23 @@ __global__ __launch_bounds__(192) void admm_mfmac_kernel(const AdmmParams P) {
             s_cmask[tid] = make_uint4(hx, ax, hu, au);
         }
     }
+    if constexpr (LIN) {
+        // AdmmParams::lin: [mlx][nx] rows | b | |a|^2 | [mlu][nu] rows | b | |a|^2 -> every lane's own coefficients per slot
+        const float *gAx = P.lin, *gbx = gAx + mlx * NX, *gn2x = gbx + mlx;
+        const float *gAu = gn2x + mlx, *gbu = gAu + mlu * NU, *gn2u = gbu + mlu;
+        for (int i = tid; i < 2 * mlx * 64; i += 192) {
+            const int r = i >> 7, sl = (i >> 6) & 1, row = 4 * sl + ((i & 63) >> 4);
+            s_lin[i] = row < NX ? gAx[r * NX + row] : 0.f;
+        }
+        for (int i = tid; i < mlu * 64; i += 192) {
+            const int r = i >> 6, row = (i & 63) >> 4;
+            s_lin[2 * mlx * 64 + i] = row < NU ? gAu[r * NU + row] : 0.f;
+        }
+        for (int i = tid; i < mlx + mlu; i += 192) {
+            s_lb[2 * i] = i < mlx ? gbx[i] : gbu[i - mlx];
+            s_lb[2 * i + 1] = i < mlx ? gn2x[i] : gn2u[i - mlx];
+        }
+    }
     __syncthreads();
 
     constexpr bool soc_x = CX > 0, soc_u = CU > 0;
@@ -236,8 +270,8 @@ __global__ __launch_bounds__(192) void admm_mfmac_kernel(const AdmmParams P) {
     lds_f *const sbase = (lds_f *)s_state;
     const int rbase[3] = {0, 64, NX * 16};                     // slot row base * 16 (slot 1: rows 4 + g)
     const bool okr[3] = {ok0, ok1, ok2};
-    lds_f *a_ptr[3], *c_ptr[3];                                // A1 of position 0 (A3 = + A3_DISP), and A2
-    int a_str[3], c_str[3];                                    // floats per position: PLEN, or 0 for the pad
+    lds_f *a_ptr[3], *c_ptr[3], *l_ptr[3];                     // A1 of position 0 (A3 = + A3_DISP), A2, and the linear set's dual
+    int a_str[3], c_str[3], l_str[3];                          // floats per position: PLEN, or 0 for the pad
 #pragma unroll
     for (int sl = 0; sl < 3; ++sl) {
         const int rho_ = sl == 0 ? row0 : (sl == 1 ? row1 : NX + row2);
@@ -248,6 +282,11 @@ __global__ __launch_bounds__(192) void admm_mfmac_kernel(const AdmmParams P) {
         a_str[sl] = okr[sl] ? PLEN : 0;
         c_ptr[sl] = sbase + (cone ? (2 * NROW + crow) * 16 + j : PLEN * (N - 1) + l);
         c_str[sl] = cone ? PLEN : 0;
+        // the linear set's dual: every row of a side that has linear rows (state rows first)
+        const bool lin = okr[sl] && (sl < 2 ? mlx > 0 : mlu > 0);
+        const int lrow = sl < 2 ? rho_ : (mlx > 0 ? NX : 0) + row2;
+        l_ptr[sl] = sbase + (lin ? (2 * NROW + cone_rows + lrow) * 16 + j : PLEN * (N - 1) + l);
+        l_str[sl] = lin ? PLEN : 0;
     }
     // the affine term rides in the products: K index 11 (slot 2 of lane group 3, a row no shape uses: nu <= 3 there, else
     // it is added on the VALU) carries the constant 1 and the operand columns f / APf, BPf
@@ -260,9 +299,10 @@ __global__ __launch_bounds__(192) void admm_mfmac_kernel(const AdmmParams P) {
     // HBM scratch of this wavefront: cone slack kept around a check
     float *scr = P.scratch + l;                                // (+ the tile's block, set in the tile loop)
     auto SCR = [&](int pos, int sl) -> float & { return scr[((size_t)pos * 3 + sl) * 64]; };
+    auto SCRL = [&](int pos, int sl) -> float & { return scr[((size_t)(N + pos) * 3 + sl) * 64]; };   // the linear sets' slack
 
     double x0r[2] = {0.0, 0.0};
-    float g0[2] = {0.f, 0.f}, gc0[2] = {0.f, 0.f};  // duals of knot 0 (state side)
+    float g0[2] = {0.f, 0.f}, gc0[2] = {0.f, 0.f}, gl0[2] = {0.f, 0.f};  // duals of knot 0 (state side)
 
     int it = 0, conv = 0;
     float res0 = 0.f, res1 = 0.f, res2 = 0.f, res3 = 0.f;
@@ -270,37 +310,77 @@ __global__ __launch_bounds__(192) void admm_mfmac_kernel(const AdmmParams P) {
     const bool can_converge = P.abs_pri_tol > 0.f && P.abs_dua_tol > 0.f;
     const int last_check_it = ct > 0 ? (P.max_iter / ct) * ct : 0;
 
-    // membership of this lane's slots in the side's cone, as 0 / 1 weights, and mu, 1 / mu (registers)
-    float hxw[2] = {0.f, 0.f}, axw[2] = {0.f, 0.f}, huw = 0.f, auw = 0.f, mux = 1.f, muu = 1.f, rmux = 1.f, rmuu = 1.f;
-    if constexpr (EXT) {
-        const uint4 mk = s_cmask[g];
-        if constexpr (CX > 0) {
-            mux = P.cx[0], rmux = 1.f / P.cx[0];
+    // membership of this lane's slots in each of the side's cones, as 0 / 1 weights, and mu, 1 / mu (registers)
+    constexpr int CXA = CX > 0 ? CX : 1, CUA = CU > 0 ? CU : 1;
+    float hxw[CXA][2], axw[CXA][2], huw[CUA], auw[CUA], mux[CXA], muu[CUA], rmux[CXA], rmuu[CUA];
 #pragma unroll
-            for (int sl = 0; sl < 2; ++sl) hxw[sl] = (float)((mk.x >> sl) & 1u), axw[sl] = (float)((mk.y >> sl) & 1u);
+    for (int c = 0; c < CXA; ++c) hxw[c][0] = hxw[c][1] = axw[c][0] = axw[c][1] = 0.f, mux[c] = rmux[c] = 1.f;
+#pragma unroll
+    for (int c = 0; c < CUA; ++c) huw[c] = auw[c] = 0.f, muu[c] = rmuu[c] = 1.f;
+    if constexpr (EXT) {
+#pragma unroll
+        for (int c = 0; c < CX; ++c) {
+            const uint4 mk = s_cmask[c * 4 + g];
+            mux[c] = P.cx[c], rmux[c] = 1.f / P.cx[c];
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) hxw[c][sl] = (float)((mk.x >> sl) & 1u), axw[c][sl] = (float)((mk.y >> sl) & 1u);
         }
-        if constexpr (CU > 0) {
-            muu = P.cu[0], rmuu = 1.f / P.cu[0];
-            huw = (float)(mk.z & 1u), auw = (float)(mk.w & 1u);
+#pragma unroll
+        for (int c = 0; c < CU; ++c) {
+            const uint4 mk = s_cmask[c * 4 + g];
+            muu[c] = P.cu[c], rmuu[c] = 1.f / P.cu[c];
+            huw[c] = (float)(mk.z & 1u), auw[c] = (float)(mk.w & 1u);
         }
     }
     auto cone_apply = [&](float v, float hw, float aw, float sc, float ax_new) -> float {
         v = hw != 0.f ? v * sc : v;
         return aw != 0.f ? ax_new : v;
     };
+    // (the cones of a side own disjoint rows: every cone's sums are taken from the values as they came, so the cones'
+    // dependency chains — two instance sums, sqrt, rcp, selects: ~150 cycles each for a lone wavefront — are independent
+    // and interleave; applied one after the other they would not be, to the compiler, which cannot see the rows are disjoint)
     auto project_x = [&](float (&v)[2]) {
-        const float a2 = mfc_inst_sum(fmaf(hxw[0] * v[0], v[0], hxw[1] * v[1] * v[1]));
-        const float axv = mfc_inst_sum(fmaf(axw[0], v[0], axw[1] * v[1]));
-        float sc, ax_new;
-        cone_scale(a2, axv, mux, rmux, sc, ax_new);
-        v[0] = cone_apply(v[0], hxw[0], axw[0], sc, ax_new);
-        v[1] = cone_apply(v[1], hxw[1], axw[1], sc, ax_new);
+        float sc[CXA], ax_new[CXA];
+#pragma unroll
+        for (int c = 0; c < CX; ++c) {
+            const float a2 = mfc_inst_sum(fmaf(hxw[c][0] * v[0], v[0], hxw[c][1] * v[1] * v[1]));
+            const float axv = mfc_inst_sum(fmaf(axw[c][0], v[0], axw[c][1] * v[1]));
+            cone_scale(a2, axv, mux[c], rmux[c], sc[c], ax_new[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < CX; ++c) {
+            v[0] = cone_apply(v[0], hxw[c][0], axw[c][0], sc[c], ax_new[c]);
+            v[1] = cone_apply(v[1], hxw[c][1], axw[c][1], sc[c], ax_new[c]);
+        }
     };
     auto project_u = [&](float &v) {
-        const float a2 = mfc_inst_sum(huw * v * v), axv = mfc_inst_sum(auw * v);
-        float sc, ax_new;
-        cone_scale(a2, axv, muu, rmuu, sc, ax_new);
-        v = cone_apply(v, huw, auw, sc, ax_new);
+        float sc[CUA], ax_new[CUA];
+#pragma unroll
+        for (int c = 0; c < CU; ++c) {
+            const float a2 = mfc_inst_sum(huw[c] * v * v), axv = mfc_inst_sum(auw[c] * v);
+            cone_scale(a2, axv, muu[c], rmuu[c], sc[c], ax_new[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < CU; ++c) v = cone_apply(v, huw[c], auw[c], sc[c], ax_new[c]);
+    };
+
+    // z <- projection onto {a_k . z <= b_k}, one row after the other (the solver's order); the dot product is summed over
+    // the instance's lanes, the correction is a select (the branch would diverge between instances)
+    auto halfspaces_x = [&](float (&v)[2]) {
+        for (int r = 0; r < mlx; ++r) {
+            const float c0 = s_lin[(2 * r) * 64 + l], c1 = s_lin[(2 * r + 1) * 64 + l], bb = s_lb[2 * r], n2 = s_lb[2 * r + 1];
+            const float dot = mfc_inst_sum(fmaf(c0, v[0], c1 * v[1]));
+            const float tt = (dot > bb && n2 > 0.f) ? (dot - bb) / n2 : 0.f;
+            v[0] -= tt * c0, v[1] -= tt * c1;
+        }
+    };
+    auto halfspaces_u = [&](float &v) {
+        for (int r = 0; r < mlu; ++r) {
+            const float c0 = s_lin[(2 * mlx + r) * 64 + l], bb = s_lb[2 * (mlx + r)], n2 = s_lb[2 * (mlx + r) + 1];
+            const float dot = mfc_inst_sum(c0 * v);
+            const float tt = (dot > bb && n2 > 0.f) ? (dot - bb) / n2 : 0.f;
+            v -= tt * c0;
+        }
     };
 
     // ---- three wavefronts per 16 instances ----
@@ -345,7 +425,7 @@ __global__ __launch_bounds__(192) void admm_mfmac_kernel(const AdmmParams P) {
     scr = P.scratch + (size_t)tile * S::scratch_floats(N) + l;
     x0r[0] = (active && ok0) ? (double)P.x0[b * NX + row0] : 0.0;
     x0r[1] = (active && ok1) ? (double)P.x0[b * NX + row1] : 0.0;
-    g0[0] = g0[1] = gc0[0] = gc0[1] = 0.f;
+    g0[0] = g0[1] = gc0[0] = gc0[1] = gl0[0] = gl0[1] = 0.f;
     it = 0, conv = 0, any_left = 1;
     res0 = res1 = res2 = res3 = 0.f;
     // cold start = the zero workspace tiny_setup leaves (tiny_api.cpp:73-88)
@@ -375,7 +455,7 @@ __global__ __launch_bounds__(192) void admm_mfmac_kernel(const AdmmParams P) {
         if (wave == 1) {
             // ================= state side of the forward sweep (admm.cpp:43-59, :65-69, :93-96) =================
             // slack / dual of both sets for this lane's two state slots at knot kn (position spos of the cone scratch)
-            auto state_knot = [&](auto full_tag, const float (&xf)[2], int kn, int spos, float (&a1)[2], float (&a2)[2], float (&sx)[2]) {
+            auto state_knot = [&](auto full_tag, const float (&xf)[2], int kn, int spos, float (&a1)[2], float (&a2)[2], float (&a4)[2], float (&sx)[2]) {
                 constexpr bool FULL = decltype(full_tag)::value;
                 float vn[2], vc[2];
 #pragma unroll
@@ -424,39 +504,67 @@ __global__ __launch_bounds__(192) void admm_mfmac_kernel(const AdmmParams P) {
                         }
                     }
                 }
+                if constexpr (LIN) {
+                    if (mlx > 0) {
+                        float vl[2] = {xf[0] + a4[0], xf[1] + a4[1]};
+                        halfspaces_x(vl);
+#pragma unroll
+                        for (int sl = 0; sl < 2; ++sl) {
+                            a4[sl] = (a4[sl] + xf[sl]) - vl[sl];
+                            sx[sl] += vl[sl] - a4[sl];
+                        }
+                        if constexpr (FULL) {
+                            if (need_res) {
+#pragma unroll
+                                for (int sl = 0; sl < XS; ++sl) {
+                                    const float old = read_old ? SCRL(spos, sl) : 0.f;
+                                    pri_x = fmaxf(pri_x, fabsf(xf[sl] - vl[sl]));
+                                    dua_x = fmaxf(dua_x, fabsf(old - vl[sl]));
+                                }
+                            }
+                            if (write_old) {
+#pragma unroll
+                                for (int sl = 0; sl < XS; ++sl) SCRL(spos, sl) = vl[sl];
+                            }
+                        }
+                    }
+                }
             };
             auto state_sweep = [&](auto full_tag) {
                 {
                     const float xf0[2] = {(float)x0r[0], XS == 2 ? (float)x0r[1] : 0.f};
                     float sx0[2];
-                    state_knot(full_tag, xf0, 0, N - 1, g0, gc0, sx0);   // knot 0: its fused value feeds nothing (q_0 only enters p_0)
+                    state_knot(full_tag, xf0, 0, N - 1, g0, gc0, gl0, sx0);   // knot 0: its fused value feeds nothing (q_0 only enters p_0)
                 }
-                lds_f *pc[2] = {c_ptr[0], c_ptr[1]};
-                float nA1[2] = {*pa[0], *pa[1]}, nA2[2] = {soc_x ? *pc[0] : 0.f, soc_x ? *pc[1] : 0.f};
+                lds_f *pc[2] = {c_ptr[0], c_ptr[1]}, *pl[2] = {l_ptr[0], l_ptr[1]};
+                float nA1[2] = {*pa[0], *pa[1]}, nA2[2] = {soc_x ? *pc[0] : 0.f, soc_x ? *pc[1] : 0.f}, nA4[2] = {LIN ? *pl[0] : 0.f, LIN ? *pl[1] : 0.f};
                 for (int k = 0; k < N - 1; ++k) {
-                    float a1x[2] = {nA1[0], nA1[1]}, a2x[2] = {nA2[0], nA2[1]};
-                    lds_f *const wa[2] = {pa[0], pa[1]}, *const wc[2] = {pc[0], pc[1]};
+                    float a1x[2] = {nA1[0], nA1[1]}, a2x[2] = {nA2[0], nA2[1]}, a4x[2] = {nA4[0], nA4[1]};
+                    lds_f *const wa[2] = {pa[0], pa[1]}, *const wc[2] = {pc[0], pc[1]}, *const wl[2] = {pl[0], pl[1]};
 #pragma unroll
                     for (int sl = 0; sl < 2; ++sl) {
                         pa[sl] += a_str[sl];
                         pc[sl] += c_str[sl];
+                        pl[sl] += l_str[sl];
                     }
                     if (k + 1 < N - 1) {                                         // next position's duals, before the wait
 #pragma unroll
                         for (int sl = 0; sl < 2; ++sl) {
                             nA1[sl] = *pa[sl];
                             nA2[sl] = soc_x ? *pc[sl] : 0.f;
+                            nA4[sl] = LIN ? *pl[sl] : 0.f;
                         }
                     }
                     wait_step(k);                                                // x_{k+1} is in the A3 cells of position k
                     const float xf[2] = {*(lds_vf *)(wa[0] + A3_DISP), XS == 2 ? *(lds_vf *)(wa[1] + A3_DISP) : 0.f};
                     float sx[2] = {0.f, 0.f};
-                    if (!(dbg & 2)) state_knot(full_tag, xf, k + 1, k, a1x, a2x, sx);
+                    if (!(dbg & 2)) state_knot(full_tag, xf, k + 1, k, a1x, a2x, a4x, sx);
 #pragma unroll
                     for (int sl = 0; sl < XS; ++sl) {
                         *wa[sl] = a1x[sl];
                         wa[sl][A3_DISP] = sx[sl];
                         if constexpr (soc_x) *wc[sl] = a2x[sl];
+                        if constexpr (LIN) *wl[sl] = a4x[sl];
                     }
                 }
             };
@@ -470,16 +578,18 @@ __global__ __launch_bounds__(192) void admm_mfmac_kernel(const AdmmParams P) {
             // ================= input side of the forward sweep (admm.cpp:43-51, :60-64, :93-96) =================
             auto input_sweep = [&](auto full_tag) {
                 constexpr bool FULL = decltype(full_tag)::value;
-                lds_f *pc2 = c_ptr[2];
-                float nA1u = *pa[2], nA2u = soc_u ? *pc2 : 0.f;
+                lds_f *pc2 = c_ptr[2], *pl2 = l_ptr[2];
+                float nA1u = *pa[2], nA2u = soc_u ? *pc2 : 0.f, nA4u = LIN ? *pl2 : 0.f;
                 for (int k = 0; k < N - 1; ++k) {
-                    float a1u = nA1u, a2u = nA2u;
-                    lds_f *const wa2 = pa[2], *const wc2 = pc2;
+                    float a1u = nA1u, a2u = nA2u, a4u = nA4u;
+                    lds_f *const wa2 = pa[2], *const wc2 = pc2, *const wl2 = pl2;
                     pa[2] += a_str[2];
                     pc2 += c_str[2];
+                    pl2 += l_str[2];
                     if (k + 1 < N - 1) {
                         nA1u = *pa[2];
                         nA2u = soc_u ? *pc2 : 0.f;
+                        nA4u = LIN ? *pl2 : 0.f;
                     }
                     wait_step(k);                                                // u_k is in the A3 cell of position k
                     const float uf = *(lds_vf *)(wa2 + A3_DISP);
@@ -510,6 +620,23 @@ __global__ __launch_bounds__(192) void admm_mfmac_kernel(const AdmmParams P) {
                             if (write_old) SCR(k, 2) = zc;
                         }
                         *wc2 = a2u;
+                    }
+                    if constexpr (LIN) {
+                        if (mlu > 0) {
+                            float zl = uf + a4u;
+                            halfspaces_u(zl);
+                            a4u = (a4u + uf) - zl;
+                            su += zl - a4u;
+                            if constexpr (FULL) {
+                                if (need_res) {
+                                    const float old = read_old ? SCRL(k, 2) : 0.f;
+                                    pri_u = fmaxf(pri_u, fabsf(uf - zl));
+                                    dua_u = fmaxf(dua_u, fabsf(old - zl));
+                                }
+                                if (write_old) SCRL(k, 2) = zl;
+                            }
+                        }
+                        *wl2 = a4u;
                     }
                     *wa2 = a1u;
                     wa2[A3_DISP] = su;

@@ -130,7 +130,9 @@ void build_mfmac_bounds(const Solver &sv, std::vector<float> &out) {
 
 template <int NX, int NU>
 size_t mfmac_lds_bytes(const Solver &sv) {
-    return ConeShape<NX, NU>::lds_bytes(sv.N, mfmac_bounds_vary(sv) ? sv.N : 1, mfmac_cone_rows<NX, NU>(sv));
+    const int mlx = sv.st.en_state_linear ? sv.mlx : 0, mlu = sv.st.en_input_linear ? sv.mlu : 0;
+    const int lin_rows = (mlx > 0 ? NX : 0) + (mlu > 0 ? NU : 0);
+    return ConeShape<NX, NU>::lds_bytes(sv.N, mfmac_bounds_vary(sv) ? sv.N : 1, mfmac_cone_rows<NX, NU>(sv) + lin_rows, mlx, mlu);
 }
 
 template <int NX, int NU>
@@ -147,31 +149,41 @@ hipError_t launch_mfmac(const AdmmParams &P_, bool ext, size_t lds, hipStream_t 
     const int tiles = (P.batch + 15) / 16;
     // persistent workgroups (the kernel takes tiles off a counter): as many as fit on the chip at once
     const int cus = device_cu_count();   // (per device: a sharded handle launches on several)
-#define TMPC_MFMAC_LAUNCH(REFS_, CX_, CU_, BV_)                                                                       \
+#define TMPC_MFMAC_LAUNCH(REFS_, CX_, CU_, BV_, LIN_)                                                                     \
     do {                                                                                                              \
-        (void)hipFuncSetAttribute((const void *)admm_mfmac_kernel<NX, NU, REFS_, CX_, CU_, BV_>,                      \
+        (void)hipFuncSetAttribute((const void *)admm_mfmac_kernel<NX, NU, REFS_, CX_, CU_, BV_, LIN_>,                      \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
         int per_cu = 0;                                                                                               \
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, admm_mfmac_kernel<NX, NU, REFS_, CX_, CU_, BV_>,    \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, admm_mfmac_kernel<NX, NU, REFS_, CX_, CU_, BV_, LIN_>,    \
                                                          192, lds) != hipSuccess || per_cu <= 0)                      \
             per_cu = 1;                                                                                               \
         const int grid = tiles < per_cu * cus ? tiles : per_cu * cus;                                                 \
-        hipLaunchKernelGGL((admm_mfmac_kernel<NX, NU, REFS_, CX_, CU_, BV_>), dim3(grid), dim3(192), lds, stream, P);  \
+        hipLaunchKernelGGL((admm_mfmac_kernel<NX, NU, REFS_, CX_, CU_, BV_, LIN_>), dim3(grid), dim3(192), lds, stream, P);  \
     } while (0)
 #define TMPC_MFMAC_LAUNCH_BV(REFS_, CX_, CU_)                                                                         \
     do {                                                                                                              \
-        if (P.bounds_stride) TMPC_MFMAC_LAUNCH(REFS_, CX_, CU_, true); else TMPC_MFMAC_LAUNCH(REFS_, CX_, CU_, false); \
+        if (P.mlx + P.mlu > 0) {                                                                                      \
+            if (P.bounds_stride) TMPC_MFMAC_LAUNCH(REFS_, CX_, CU_, true, true); else TMPC_MFMAC_LAUNCH(REFS_, CX_, CU_, false, true); \
+        } else {                                                                                                      \
+            if (P.bounds_stride) TMPC_MFMAC_LAUNCH(REFS_, CX_, CU_, true, false); else TMPC_MFMAC_LAUNCH(REFS_, CX_, CU_, false, false); \
+        }                                                                                                             \
+    } while (0)
+#define TMPC_MFMAC_LAUNCH_CU(REFS_, CX_)                                                    \
+    do {                                                                                   \
+        if (P.ncu > 1) TMPC_MFMAC_LAUNCH_BV(REFS_, CX_, 2);                                \
+        else if (P.ncu > 0) TMPC_MFMAC_LAUNCH_BV(REFS_, CX_, 1);                           \
+        else TMPC_MFMAC_LAUNCH_BV(REFS_, CX_, 0);                                          \
     } while (0)
 #define TMPC_MFMAC_LAUNCH_C(REFS_)                                                         \
     do {                                                                                   \
-        if (P.ncx > 0 && P.ncu > 0) TMPC_MFMAC_LAUNCH_BV(REFS_, 1, 1);                     \
-        else if (P.ncx > 0) TMPC_MFMAC_LAUNCH_BV(REFS_, 1, 0);                             \
-        else if (P.ncu > 0) TMPC_MFMAC_LAUNCH_BV(REFS_, 0, 1);                             \
-        else TMPC_MFMAC_LAUNCH_BV(REFS_, 0, 0);                                            \
+        if (P.ncx > 1) TMPC_MFMAC_LAUNCH_CU(REFS_, 2);                                     \
+        else if (P.ncx > 0) TMPC_MFMAC_LAUNCH_CU(REFS_, 1);                                \
+        else TMPC_MFMAC_LAUNCH_CU(REFS_, 0);                                               \
     } while (0)
     (void)ext;
     if (P.ref_mode == REF_ZERO) TMPC_MFMAC_LAUNCH_C(REF_ZERO); else TMPC_MFMAC_LAUNCH_C(REF_SHARED);
 #undef TMPC_MFMAC_LAUNCH_C
+#undef TMPC_MFMAC_LAUNCH_CU
 #undef TMPC_MFMAC_LAUNCH_BV
 #undef TMPC_MFMAC_LAUNCH
     return hipGetLastError();

@@ -14,6 +14,8 @@ size_t mfmar_lds_bytes(const Solver &sv) {
 // the state cone's rows must be rows of slot 0 (0 .. 3): wave 1 owns them together with their box set
 inline bool mfmar_supports(const Solver &sv) {
     if (sv.st.en_state_soc && sv.ncx > 0 && sv.Acx[0] + sv.qcx[0] > 4) return false;
+    if ((sv.st.en_state_soc && sv.ncx > 1) || (sv.st.en_input_soc && sv.ncu > 1)) return false;   // one cone per side
+    if (sv.lin_active()) return false;                                                            // no linear rows
     return true;
 }
 

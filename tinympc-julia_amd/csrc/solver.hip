@@ -367,14 +367,20 @@ int Solver::select_kernel(bool rollout) {
     const ConeEntry *cn = std::getenv("TINYMPC_HIP_NO_MFMAR") ? nullptr : find_cone_kernel(nx, nu, N);
     if (cn && cn->supports && !cn->supports(*this)) cn = nullptr;
     const bool plain_ok = std::getenv("TINYMPC_HIP_MFMAC_ALL") != nullptr || (cn != nullptr && cn->plain);
-    if ((s2 || (k && plain_ok)) && !warm_start && chunk_iters == 0 && !rollout && precision == 0 && !hetero && !lin_active() &&
-        !st.adaptive_rho && (has_fdyn || cones_active() || plain_ok) && xref_kind < 2 && uref_kind < 2 &&
+    if ((s2 || (k && plain_ok)) && !warm_start && chunk_iters == 0 && !rollout && precision == 0 && !hetero &&
+        !st.adaptive_rho && (has_fdyn || cones_active() || lin_active() || plain_ok) && xref_kind < 2 && uref_kind < 2 &&
         !(refs_device_owned && ref_mode == REF_PER_INSTANCE) && !std::getenv("TINYMPC_HIP_NO_MFMAC") && !genv &&
         !std::getenv("TINYMPC_HIP_NO_MFMA")) {
         c2 = cn;                                                             // horizon compiled in
         if (!c2) c2 = find_cone_kernel(nx, nu, 0);
         if (c2 && c2->lds_bytes(*this) > 160 * 1024 - 1024) c2 = nullptr;   // horizon too long for one tile's LDS
-        if ((st.en_state_soc && ncx > 1) || (st.en_input_soc && ncu > 1)) c2 = nullptr;   // one cone per side
+        // (the compiled-horizon kernels take one cone per side and no linear rows — their `supports` says so — the LDS
+        // kernel two cones per side and linear rows.  It is correct on those (tests/test_mfmac_gpu.py) but not faster than
+        // the stream kernel: the extra duals cost it a tile per CU — rocket N = 30, 32 768 instances: 7.9 ms against 7.7
+        // with two state cones, 8.6 against 7.9 with a linear row, scripts/lin_rows_time.py — so they go there only when
+        // asked: TINYMPC_HIP_MFMAC_WIDE=1)
+        const bool wide = (st.en_state_soc && ncx > 1) || (st.en_input_soc && ncu > 1) || lin_active();
+        if ((st.en_state_soc && ncx > 2) || (st.en_input_soc && ncu > 2) || (wide && !std::getenv("TINYMPC_HIP_MFMAC_WIDE"))) c2 = nullptr;
         if (c2) {
             k = nullptr;
             s2 = nullptr;
