@@ -372,7 +372,7 @@ def test_mfmat_config4_every_instance(hip_lib, oracle_built):
 
 def test_mfmat_selection(hip_lib):
     """what runs where: the transposed-sets kernel takes the affine term / one cone per side of the rocket's layout in every
-    calling pattern; other cone layouts, linear rows, per-instance references, fp32 recurrences stay where they were"""
+    calling pattern, with shared, zero or per-instance references; other cone layouts, linear rows, fp32 recurrences stay where they were"""
     prob = t.problems.rocket(10)
     xr, ur = t.problems.rocket_refs(10)
     kw = SETTINGS["tol"]
@@ -393,7 +393,10 @@ def test_mfmat_selection(hip_lib):
     bs.set_u_ref(np.repeat(ur[:, :, None], 8, axis=2))
     bs.set_x0(t.problems.rocket_x0(8, seed=1))
     bs.solve()
-    assert bs.kernel_name == "stream4<6,3>"
+    assert bs.kernel_name == "mfmat<6,3,10>"                       # (round 3: a second set of LDS cells per tile)
+    bs.set_linear_constraints(np.array([[0.0, 0.0, -1.0, 0.0, 0.0, 0.3]]), [0.5], np.zeros((0, 3)), [])
+    bs.solve()
+    assert bs.kernel_name == "stream4<6,3>"                        # linear rows: not here
     bs.close()
     # box-only solves of the shape run here too (measured faster than the quad kernel at every compiled horizon)
     p10 = t.problems.rocket(10)
@@ -550,6 +553,63 @@ def test_mfmat_per_knot_bounds_random_family(hip_lib, oracle_built, N, warm):
         parity_every_instance(bs.get_solution(), bs.get_status(), ref, replay, x, kw, prob.rho, tol=2e-5 if k else FP32_TOL,
                               min_same=0.9, tag=f"N={N} warm={warm} solve {k}")
         x = prob.A @ x + prob.B @ ref["u"][:, 0, :] + fdyn[:, None]
+    for o in orcs:
+        o.close()
+    bs.close()
+
+
+@pytest.mark.parametrize("N", [10, 50])
+def test_mfmat_per_instance_references(hip_lib, oracle_built, N):
+    """every instance tracks its OWN reference trajectory (`set_x_ref` / `set_u_ref` with [nx, N, B] / [nu, N-1, B] arrays):
+    a second set of LDS cells per tile and the terminal term per instance; one-shot with the termination check live, then
+    two workspace-carrying fixed-iteration solves against persistent oracles"""
+    B = 37
+    rng = np.random.default_rng(31 + N)
+    prob = t.problems.rocket(N)
+    xr, ur = t.problems.rocket_refs(N)
+    xr3 = xr[:, :, None] * (1.0 + 0.15 * rng.standard_normal((1, 1, B))) + 0.3 * rng.standard_normal((prob.A.shape[0], 1, B))
+    ur3 = ur[:, :, None] + 0.5 * rng.standard_normal((prob.B.shape[1], N - 1, B))
+    x0 = t.problems.rocket_x0(B, seed=4)
+
+    def oracle(kw):
+        def make(b):
+            return _configure(oracle_built.CpuSolver("orc64", prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N), prob, kw,
+                              np.asfortranarray(xr3[:, :, b]), np.asfortranarray(ur3[:, :, b]), prob.fdyn, ROCKET_CONES)
+        return make
+
+    # --- one-shot, tolerance-terminated ---
+    kw = SETTINGS["tol"]
+    mk = oracle(kw)
+    ref = _loop(mk, x0)
+    bs = _solver(prob, B, kw, np.asfortranarray(xr3), np.asfortranarray(ur3), prob.fdyn, ROCKET_CONES, False)
+    bs.set_x0(x0)
+    bs.solve()
+    assert bs.kernel_name == f"mfmat<6,3,{N}>"
+    parity_every_instance(bs.get_solution(), bs.get_status(), ref, mk, x0, kw, prob.rho, tag=f"per-instance refs N={N}")
+    # (the references matter: against instance 0's for everybody the solutions differ visibly)
+    assert nrel(bs.get_solution()["controls"][:, :, 1:], np.repeat(ref["u"][:, :, :1], B - 1, axis=2)) > 1e-3
+    bs.close()
+
+    # --- the workspace kept over two solves, fixed iterations: persistent oracles beside it ---
+    kw = SETTINGS["fixed60"]
+    mk = oracle(kw)
+    orcs = [mk(b) for b in range(B)]
+    bs = _solver(prob, B, kw, np.asfortranarray(xr3), np.asfortranarray(ur3), prob.fdyn, ROCKET_CONES, True)
+    xs = x0.copy()
+    for solve in range(2):
+        bs.set_x0(xs)
+        bs.solve()
+        assert bs.kernel_name == f"mfmat<6,3,{N}>"
+        sol = bs.get_solution()
+        X, U = np.zeros_like(sol["states"]), np.zeros_like(sol["controls"])
+        for b in range(B):
+            orcs[b].set_x0(xs[:, b])
+            orcs[b].solve()
+            r = orcs[b].get_solution()
+            X[:, :, b], U[:, :, b] = r["x"], r["u"]
+        assert nrel_batch(sol["states"], X).max() <= FP32_TOL and nrel_batch(sol["controls"], U).max() <= FP32_TOL, \
+            (solve, nrel_batch(sol["states"], X).max(), nrel_batch(sol["controls"], U).max())
+        xs = np.asfortranarray(prob.A @ xs + prob.B @ U[:, 0, :] + prob.fdyn[:, None])
     for o in orcs:
         o.close()
     bs.close()

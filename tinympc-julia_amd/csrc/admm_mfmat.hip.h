@@ -71,17 +71,18 @@ struct TransShape {
     static constexpr int O_KC = NLF * 64, O_PINF = O_KC + NKC * 4, O_QUU = O_PINF + NX * NX, O_QUI = O_QUU + NU * NU,
                          O_KINF = O_QUI + NU * NU, O_A = O_KINF + NU * NX, O_B = O_A + NX * NX, O_F = O_B + NX * NU,
                          COEF_DOUBLES = O_F + NX;
-    static constexpr size_t lds_floats(int nk) {
-        return (size_t)PLEN * N + ((S::bounds_len(nk) + 1) & ~1) + (((size_t)NROW * N + 2) & ~(size_t)1);
+    // (`pi`: per-instance references — a second set of cells, [knot][row][instance], and the terminal term per instance)
+    static constexpr size_t lds_floats(int nk, bool pi = false) {
+        return (size_t)PLEN * N + ((S::bounds_len(nk) + 1) & ~1) + (pi ? (size_t)PLEN * N : (((size_t)NROW * N + 2) & ~(size_t)1));
     }
     // registers of the sets layout per lane and knot group: duals + previous slack of every set
     static constexpr int group_regs(int cxq, int cuq) { return (NX + cxq + NU + cuq) + (NX + (cxq ? NX : 0) + NU + (cuq ? NU : 0)); }
     static constexpr int state_regs(int cxq, int cuq) { return NG * group_regs(cxq, cuq); }
     // the last group's state in LDS instead: when everything together would not fit the 512-entry file
     static constexpr bool spill_last(int cxq, int cuq) { return NG >= 2 && state_regs(cxq, cuq) + 70 > 450; }
-    static constexpr size_t lds_bytes(int nk, int cxq, int cuq) {
-        return sizeof(float) * (lds_floats(nk) + (spill_last(cxq, cuq) ? (size_t)64 * group_regs(cxq, cuq) : 0)) +
-               sizeof(double) * (8 + 16 * NX + 4 * NKC);
+    static constexpr size_t lds_bytes(int nk, int cxq, int cuq, bool pi = false) {
+        return sizeof(float) * (lds_floats(nk, pi) + (spill_last(cxq, cuq) ? (size_t)64 * group_regs(cxq, cuq) : 0)) +
+               sizeof(double) * ((pi ? 16 * NX : 8) + 16 * NX + 4 * NKC);
     }
 };
 
@@ -108,9 +109,12 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
     constexpr int nk = BV ? N : 1;   // BV: the bounds depend on the knot (per-knot pack in LDS), else scalars
     float *s_cells = reinterpret_cast<float *>(s_raw_t);
     float *s_bnd = s_cells + (size_t)PLEN * N;
-    float *s_ref = s_bnd + ((S::bounds_len(nk) + 1) & ~1);    // [N][NROW] and one zero cell behind (even offset: fp64 cells follow)
-    double *s_pterm = reinterpret_cast<double *>(s_ref + (((size_t)NROW * N + 2) & ~(size_t)1));
-    double *s_plant = s_pterm + 8;                            // closed loop: the plant state of the tile's instances, [16][NX]
+    // shared references: [N][NROW] and one zero cell behind (even offset: fp64 cells follow); per-instance references: a
+    // second set of cells [N][NROW][16], staged per tile
+    constexpr bool PI = REFS == REF_PER_INSTANCE;
+    float *s_ref = s_bnd + ((S::bounds_len(nk) + 1) & ~1);
+    double *s_pterm = reinterpret_cast<double *>(s_ref + (PI ? (size_t)PLEN * N : (((size_t)NROW * N + 2) & ~(size_t)1)));   // [NX] (PI: [NX][16])
+    double *s_plant = s_pterm + (PI ? 16 * NX : 8);           // closed loop: the plant state of the tile's instances, [16][NX]
     constexpr bool SPILL = T::spill_last(CXQ, CUQ);
     // every lane's slot addresses stay inside the cells and the reference pack, and a lane without a row only ever reads
     // finite values that meet a zero operand column: the matrix-layout phases then run without lane masks
@@ -194,9 +198,9 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
             }
         }
     };
-    if (l < 8) s_pterm[l] = 0.0;
+    for (int i = l; i < (PI ? 16 * NX : 8); i += 64) s_pterm[i] = 0.0;
     for (int i = l; i < PLEN * N; i += 64) s_cells[i] = 0.f;   // (cells no lane owns are read by the mask-free phases: keep them finite)
-    for (int i = l; i < NROW * N + 2; i += 64) s_ref[i] = 0.f;
+    for (int i = l; i < (PI ? PLEN * N : NROW * N + 2); i += 64) s_ref[i] = 0.f;
     __syncthreads();
     stage_refs(P.xref, P.uref);
     __syncthreads();
@@ -302,6 +306,36 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
     // 32-bit, and opaque inside the iteration loop: left to itself the compiler forms the 64-bit address of every (array,
     // group) of the parking stores once, outside the loop — 200 registers of addresses that it then spills
     const int ox = (int)(b * EX) + g * NX, ou = (int)(b * EU) + g * NU;
+
+    if constexpr (PI) {
+        // per-instance references of the tile -> LDS, as the shared ones: -(Xref .* Q~), -(Uref .* R~) (admm.cpp:77-80) in
+        // the cells' own layout [knot][row][instance], and -(Xref_{N-1}' Pinf)' per instance (admm.cpp:81-82).  One flat
+        // loop over the tile's 16 x (EX + EU) values: consecutive lanes read consecutive floats of an instance.
+        kparam_ptr Pr = kparams();
+        const float *xref = Pr->xref, *uref = Pr->uref, *qd = Pr->bounds + 2 * NROW * nk;
+        const int bi = (int)b;
+#pragma unroll 4
+        for (int i = l; i < 16 * (int)EX; i += 64) {
+            const int jj = i / (int)EX, e = i - jj * (int)EX, k = e / NX, r = e - k * NX;
+            const long bj = __shfl(bi, jj, 64);
+            s_ref[k * PLEN + r * 16 + jj] = -(xref[bj * EX + e] * qd[r]);
+        }
+#pragma unroll 4
+        for (int i = l; i < 16 * (int)EU; i += 64) {
+            const int jj = i / (int)EU, e = i - jj * (int)EU, k = e / NU, a = e - k * NU;
+            const long bj = __shfl(bi, jj, 64);
+            s_ref[k * PLEN + (NX + a) * 16 + jj] = -(uref[bj * EU + e] * qd[NX + a]);
+        }
+        const double *Pinf = gc64 + T::O_PINF;
+        for (int i = l; i < 16 * NX; i += 64) {
+            const int row = i >> 4, jj = i & 15;
+            const long bj = __shfl(bi, jj, 64);
+            double acc = 0.0;
+            for (int c = 0; c < NX; ++c) acc = fma(Pinf[c * NX + row], (double)xref[bj * EX + (N - 1) * NX + c], acc);
+            s_pterm[row * 16 + jj] = -acc;
+        }
+        __syncthreads();
+    }
 
     // ---- load the workspace (or the zero workspace tiny_setup leaves, tiny_api.cpp:73-88) ----
     const bool warm = !P.cold_start && active;
@@ -558,9 +592,16 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
                 for (int r = 0; r < NX; ++r) x[r] = nx_[r], rfx[r] = REFS == REF_SHARED ? s_ref[kk * NROW + r] : 0.f;
 #pragma unroll
                 for (int a = 0; a < NU; ++a) u[a] = nu_[a], rfu[a] = REFS == REF_SHARED ? s_ref[kk * NROW + NX + a] : 0.f;   // (the cell behind the last knot's is zero)
+                if constexpr (PI) {                            // this instance's own: the reference cells mirror the cells (the last knot's input rows stay zero)
+                    const lds_f *rc = (const lds_f *)s_ref + (x_all ? kk : (kk < N ? kk : N - 1)) * PLEN + j;
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) rfx[r] = rc[r * 16];
+#pragma unroll
+                    for (int a = 0; a < NU; ++a) rfu[a] = rc[U0 + a * 16];
+                }
                 if constexpr (m + 1 < NG) fetch(m + 1);
                 // (the terminal knot's reference enters through Pinf, admm.cpp:81-82, not through q)
-                if constexpr (REFS == REF_SHARED && 4 * m + 3 >= N - 1) {
+                if constexpr (REFS != REF_ZERO && 4 * m + 3 >= N - 1) {
 #pragma unroll
                     for (int r = 0; r < NX; ++r) rfx[r] = kk == N - 1 ? 0.f : rfx[r];
                 }
@@ -778,6 +819,7 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
             {
                 double pt0 = 0.0, pt1 = 0.0;
                 if constexpr (REFS == REF_SHARED) pt0 = s_pterm[g], pt1 = s_pterm[row1c];
+                if constexpr (PI) pt0 = s_pterm[g * 16 + j], pt1 = s_pterm[row1c * 16 + j];
                 const double p0 = pt0 + (double)pc[(N - 1) * PLEN + g * 16];                   // admm.cpp:81-82
                 const double p1 = pt1 + (double)pc[(N - 1) * PLEN + row1c * 16];
                 c[0][0] = p0, c[0][1] = slot1_x ? p1 : (double)lin(N - 2, rowB);

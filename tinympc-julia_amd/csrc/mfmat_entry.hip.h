@@ -115,7 +115,7 @@ void build_mfmat_coef(const Solver &sv, std::vector<unsigned char> &out) {
 template <int NX, int NU, int N, int CXQ, int CUQ>
 size_t mfmat_lds_bytes(const Solver &sv) {
     const bool cx = sv.st.en_state_soc && sv.ncx > 0, cu = sv.st.en_input_soc && sv.ncu > 0;
-    return TransShape<NX, NU, N>::lds_bytes(mfmac_bounds_vary(sv) ? N : 1, cx ? CXQ : 0, cu ? CUQ : 0);
+    return TransShape<NX, NU, N>::lds_bytes(mfmac_bounds_vary(sv) ? N : 1, cx ? CXQ : 0, cu ? CUQ : 0, sv.refs_per_instance());
 }
 
 inline size_t mfmat_scratch_floats(const Solver &) { return 1; }   // nothing of the iterated state goes through HBM
@@ -159,7 +159,9 @@ hipError_t launch_mfmat(const AdmmParams &P, bool ext, size_t lds, hipStream_t s
         else TMPC_MFMAT_LAUNCH_BV(REFS_, 0, 0);                                                 \
     } while (0)
     (void)ext;
-    if (P.ref_mode == REF_ZERO) TMPC_MFMAT_LAUNCH_C(REF_ZERO); else TMPC_MFMAT_LAUNCH_C(REF_SHARED);
+    if (P.ref_mode == REF_ZERO) TMPC_MFMAT_LAUNCH_C(REF_ZERO);
+    else if (P.ref_mode == REF_PER_INSTANCE) TMPC_MFMAT_LAUNCH_C(REF_PER_INSTANCE);
+    else TMPC_MFMAT_LAUNCH_C(REF_SHARED);
 #undef TMPC_MFMAT_LAUNCH_C
 #undef TMPC_MFMAT_LAUNCH_BV
 #undef TMPC_MFMAT_LAUNCH

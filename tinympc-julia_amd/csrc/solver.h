@@ -123,6 +123,8 @@ struct Solver {
     int xref_kind = 0, uref_kind = 0;
     bool refs_dirty = true;
     bool refs_device_owned = false;  // caller writes d_xref/d_uref itself (tinympc_set_ref_mode)
+    // the references the next launch will see are per instance ([B][N][nx] / [B][N-1][nu], upload_refs)
+    bool refs_per_instance() const { return refs_device_owned ? ref_mode == REF_PER_INSTANCE : (xref_kind >= 2 || uref_kind >= 2); }
     int ref_mode = REF_ZERO;
     bool warm_start = true;
     bool cache_overridden = false;  // set_cache_terms replaced the host Riccati's terms

@@ -392,8 +392,9 @@ int Solver::select_kernel(bool rollout) {
     // three-wavefront kernels (tests hold the two families against each other)
     const ConeEntry *ct = (std::getenv("TINYMPC_HIP_NO_MFMAT") || std::getenv("TINYMPC_HIP_NO_MFMA") || genv) ? nullptr : find_trans_kernel(nx, nu, N);
     if (ct && ct->supports && !ct->supports(*this)) ct = nullptr;
-    if (ct && (precision != 0 || hetero || lin_active() || st.adaptive_rho || xref_kind >= 2 || uref_kind >= 2 ||
-               (refs_device_owned && ref_mode == REF_PER_INSTANCE) || st.max_iter < 1 ||
+    // (per-instance references: a second set of LDS cells per tile; the per-step reference shift of the closed loop is for
+    // shared references)
+    if (ct && (precision != 0 || hetero || lin_active() || st.adaptive_rho || (refs_per_instance() && ref_seq_steps > 0) || st.max_iter < 1 ||
                !(has_fdyn || cones_active() || ct->plain || std::getenv("TINYMPC_HIP_MFMAT_ALL")) ||
                ct->lds_bytes(*this) > 160 * 1024 - 1024 || (double)batch * ex() >= 2.0e9))
         ct = nullptr;
