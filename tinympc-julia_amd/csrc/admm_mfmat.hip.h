@@ -314,13 +314,11 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
         kparam_ptr Pr = kparams();
         const float *xref = Pr->xref, *uref = Pr->uref, *qd = Pr->bounds + 2 * NROW * nk;
         const int bi = (int)b;
-#pragma unroll 4
         for (int i = l; i < 16 * (int)EX; i += 64) {
             const int jj = i / (int)EX, e = i - jj * (int)EX, k = e / NX, r = e - k * NX;
             const long bj = __shfl(bi, jj, 64);
             s_ref[k * PLEN + r * 16 + jj] = -(xref[bj * EX + e] * qd[r]);
         }
-#pragma unroll 4
         for (int i = l; i < 16 * (int)EU; i += 64) {
             const int jj = i / (int)EU, e = i - jj * (int)EU, k = e / NU, a = e - k * NU;
             const long bj = __shfl(bi, jj, 64);

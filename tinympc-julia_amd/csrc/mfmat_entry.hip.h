@@ -168,6 +168,24 @@ hipError_t launch_mfmat(const AdmmParams &P, bool ext, size_t lds, hipStream_t s
     return hipGetLastError();
 }
 
+// The eight kernels of one reference mode (cones on both / one / no side x bounds per knot or not), as explicit
+// instantiation definitions (EXT empty) or declarations (EXT = extern): an entry's 24 kernels are compiled in three
+// translation units, one per reference mode, and the entry's own unit only launches them — the N = 50 family alone is
+// eight minutes of compiler time in one unit.
+#define TMPC_MFMAT_KERNELS(EXT, NX, NU, N, REFS, CXA, CXQ, CUA, CUQ)                                              \
+    EXT template __global__ void admm_mfmat_kernel<NX, NU, N, REFS, CXA, CXQ, CUA, CUQ, false>(const AdmmParams); \
+    EXT template __global__ void admm_mfmat_kernel<NX, NU, N, REFS, CXA, CXQ, CUA, CUQ, true>(const AdmmParams);  \
+    EXT template __global__ void admm_mfmat_kernel<NX, NU, N, REFS, CXA, CXQ, 0, 0, false>(const AdmmParams);     \
+    EXT template __global__ void admm_mfmat_kernel<NX, NU, N, REFS, CXA, CXQ, 0, 0, true>(const AdmmParams);      \
+    EXT template __global__ void admm_mfmat_kernel<NX, NU, N, REFS, 0, 0, CUA, CUQ, false>(const AdmmParams);     \
+    EXT template __global__ void admm_mfmat_kernel<NX, NU, N, REFS, 0, 0, CUA, CUQ, true>(const AdmmParams);      \
+    EXT template __global__ void admm_mfmat_kernel<NX, NU, N, REFS, 0, 0, 0, 0, false>(const AdmmParams);         \
+    EXT template __global__ void admm_mfmat_kernel<NX, NU, N, REFS, 0, 0, 0, 0, true>(const AdmmParams);
+#define TMPC_MFMAT_KERNELS_EXTERN(NX, NU, N, CXA, CXQ, CUA, CUQ)                  \
+    TMPC_MFMAT_KERNELS(extern, NX, NU, N, REF_ZERO, CXA, CXQ, CUA, CUQ)           \
+    TMPC_MFMAT_KERNELS(extern, NX, NU, N, REF_SHARED, CXA, CXQ, CUA, CUQ)         \
+    TMPC_MFMAT_KERNELS(extern, NX, NU, N, REF_PER_INSTANCE, CXA, CXQ, CUA, CUQ)
+
 // CXA, CXQ / CUA, CUQ: the state / input cone the entry is compiled for (first row, dimension; dimension 0: none);
 // problems without a cone on a side use the same entry
 #define TMPC_DEFINE_MFMAT_ENTRY(NX, NU, N, CXA, CXQ, CUA, CUQ, PLAIN)                                                            \
