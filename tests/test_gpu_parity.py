@@ -1473,10 +1473,13 @@ def test_adaptive_rho_vs_reference_golden(hip_lib, monkeypatch, name, kernel):
     B = g["batch"]
     if kernel in ("stream", "generic"):
         monkeypatch.setenv("TINYMPC_HIP_NO_QUAD_ADP", "1")
+        monkeypatch.setenv("TINYMPC_HIP_NO_MFMA_ADP", "1")
     if kernel == "generic":
         monkeypatch.setenv("TINYMPC_HIP_NO_STREAM_ADP", "1")
     quad = kernel == "default" and (prob.nx, prob.nu) == (4, 1)
-    expect = "generic" if kernel == "generic" else (f"quad<4,1,{prob.N},g4>" if quad else f"stream4<{prob.nx},{prob.nu}>")
+    mfma = kernel == "default" and (prob.nx, prob.nu) == (12, 4) and prob.N in (10, 15, 20, 25, 30)   # (round 3: the matrix-core ADP variant)
+    expect = "generic" if kernel == "generic" else (f"quad<4,1,{prob.N},g4>" if quad else
+                                                    (f"mfma<12,4,{prob.N}>" if mfma else f"stream4<{prob.nx},{prob.nu}>"))
     bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
     bs.update_settings(**g["settings"])
     if prob.has_bounds():

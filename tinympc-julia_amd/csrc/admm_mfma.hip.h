@@ -52,8 +52,12 @@ template <int NX, int NU, int N>
 struct MfmaShape {
     static_assert(NX >= 1 && NX <= 12 && NU >= 1 && NU <= 4, "mfma kernel: nx <= 12, nu <= 4");
     static constexpr int VX = (NX + 3) / 4;             // state rows (registers) per lane
-    static constexpr int NF = 3 * VX + 3;               // operand doubles per lane: Mf[VX] Bf Mb[VX] KTn QI PT[VX]
-    static constexpr int O_MF = 0, O_BF = VX, O_MB = VX + 1, O_KT = 2 * VX + 1, O_QI = 2 * VX + 2, O_PT = 2 * VX + 3;
+    static constexpr int NF = 4 * VX + 3;               // operand doubles per lane: Mf[VX] Bf Mb[VX] KTn QI PT[VX] AT[VX]
+    static constexpr int O_MF = 0, O_BF = VX, O_MB = VX + 1, O_KT = 2 * VX + 1, O_QI = 2 * VX + 2, O_PT = 2 * VX + 3,
+                         O_AT = 3 * VX + 3;             // AT: [A^T; B^T] (adaptive rho: the norms' A'g, B'g)
+    // behind the lane fields: the family's Kinf, row-major [NU][NX] (adaptive rho: an instance's own Kinf enters as a
+    // correction to the products formed with this one)
+    static constexpr int O_K0 = NF * 64, COEF_DOUBLES = O_K0 + NU * NX;
     // bounds pack (fp32): xmin[N][NX] xmax[N][NX] umin[N-1][NU] umax[N-1][NU] Qd[NX] Rd[NU]
     static constexpr int B_XMIN = 0, B_XMAX = N * NX, B_UMIN = 2 * N * NX, B_UMAX = 2 * N * NX + (N - 1) * NU,
                          B_QD = 2 * N * NX + 2 * (N - 1) * NU, B_RD = B_QD + NX, BOUNDS_LEN = B_RD + NU;
@@ -84,6 +88,40 @@ __device__ __forceinline__ float mf_inst_max(float m) {
     return m;
 }
 
+// ---- exchanges between the four lanes (16 apart) of an instance, on the VALU (adaptive rho) ----
+// v_permlane32_swap exchanges the upper 32 lanes of its first operand with the lower 32 of its second, v_permlane16_swap
+// the odd 16-lane rows of the first with the even rows of the second (inline asm: experiments/permlane_probe.hip; the
+// s_nop covers the VALU-write -> permlane-read hazard).
+__device__ __forceinline__ void mf_swap32(unsigned &a, unsigned &b) { asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void mf_swap16(unsigned &a, unsigned &b) { asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+// reduce-scatter: every lane holds a partial sum for each of the instance's four lane groups; lane group g gets the total
+// of component g.  swap32 on (pe0, pe2): the lower half keeps its pe0 and receives the upper half's pe0, the upper half
+// keeps pe2 and receives pe2 — their sum is the pair total in both; likewise (pe1, pe3); then swap16 on the two totals.
+__device__ __forceinline__ double mf_reduce_scatter4(double p0, double p1, double p2, double p3) {
+    unsigned a0 = (unsigned)__double2loint(p0), a1 = (unsigned)__double2hiint(p0), b0 = (unsigned)__double2loint(p2), b1 = (unsigned)__double2hiint(p2);
+    mf_swap32(a0, b0), mf_swap32(a1, b1);
+    const double t0 = __hiloint2double((int)a1, (int)a0) + __hiloint2double((int)b1, (int)b0);
+    unsigned c0 = (unsigned)__double2loint(p1), c1 = (unsigned)__double2hiint(p1), d0 = (unsigned)__double2loint(p3), d1 = (unsigned)__double2hiint(p3);
+    mf_swap32(c0, d0), mf_swap32(c1, d1);
+    const double t1 = __hiloint2double((int)c1, (int)c0) + __hiloint2double((int)d1, (int)d0);
+    unsigned e0 = (unsigned)__double2loint(t0), e1 = (unsigned)__double2hiint(t0), f0 = (unsigned)__double2loint(t1), f1 = (unsigned)__double2hiint(t1);
+    mf_swap16(e0, f0), mf_swap16(e1, f1);
+    return __hiloint2double((int)e1, (int)e0) + __hiloint2double((int)f1, (int)f0);
+}
+// all-gather of a float: out[a] = the value lane group a holds, in every lane of the instance
+__device__ __forceinline__ void mf_all_gather4(float v, float (&out)[4]) {
+    unsigned a = __float_as_uint(v), b = a;
+    mf_swap32(a, b);                       // (a, b) = (value of group g % 2, value of group g % 2 + 2) in every lane
+    unsigned p = a, q = a, r = b, t = b;
+    mf_swap16(p, q), mf_swap16(r, t);      // (p, q) = (group 0, group 1), (r, t) = (group 2, group 3)
+    out[0] = __uint_as_float(p), out[1] = __uint_as_float(q), out[2] = __uint_as_float(r), out[3] = __uint_as_float(t);
+}
+__device__ __forceinline__ double mf_inst_max_d(double m) {
+    m = fmax(m, __shfl_xor(m, 16, 64));
+    m = fmax(m, __shfl_xor(m, 32, 64));
+    return m;
+}
+
 // dynamic LDS of the WS variant: the parked slack of the workgroup's 64 instances
 template <int NX, int NU, int N>
 constexpr size_t mfma_ws_lds_bytes() {
@@ -105,9 +143,25 @@ constexpr int mfma_blocks_per_cu() {
 // instance of its wavefront (config 5's shard: mean 46 of 100 iterations, yet nearly every wavefront holds an instance
 // that runs to max_iter).  Needs max_iter % check_termination == 0, so that a slot is only ever refilled on a check
 // iteration and every instance's own check schedule coincides with the launch's.
-template <int NX, int NU, int N, int REFS, bool XB, bool WS = false, bool RF = false>
-__global__ __launch_bounds__(256, (mfma_blocks_per_cu<NX, NU, N, REFS, XB, WS>())) void admm_mfma_kernel(const AdmmParams P) {
+//
+// ADP: adaptive rho (admm.cpp:147-174 with rho_benchmark.cpp:44-213) — what the reference builds for exactly this shape
+// (its sensitivity tables are the quadrotor's, tiny_api.cpp:269-329).  Every instance carries its own rho, Kinf and Pinf
+// (the solver's adaptive state, AdmmParams::adapt), re-predicted on the iterations i > 0, i % 5 == 0 from norms gathered
+// during that iteration's forward sweep; AmBKt and Quu_inv stay the family's, as in the reference.  A per-instance Kinf
+// does not fit a product whose matrix operand is shared by the 16 instances, so it enters as a correction: with
+// dK = Kinf_b - Kinf_0 (12 doubles per lane: dK[:, the lane's three state rows])
+//     forward : d' = d + dK x_k (partial products in every lane, a reduce-scatter over the instance's four lanes), then the
+//               same products with d' — x+ = (A - B Kinf_0) x - B d' = A x + B u, u = -Kinf_0 x - d' = -Kinf_b x - d.  The
+//               product with d' now closes the chain instead of opening it.
+//     backward: -dK' r is added to the accumulator's start on the VALU (r gathered over the instance's lanes; off the chain).
+// Pinf_b is only needed at the terminal knot (its norm rows on adapting iterations, the reference term when there are
+// references) and stays in HBM; the reference term Pinf_b' xref is kept per lane and updated with delta * (dPinf' xref).
+// The norms of rho_benchmark.cpp are gathered as in the quad kernel's ADP variant (admm_quad.hip.h: rows of knot k - 1 at
+// knot k, the terminal knot's own), A'g / B'g by three more products with [A'; B'].
+template <int NX, int NU, int N, int REFS, bool XB, bool WS = false, bool RF = false, bool ADP = false>
+__global__ __launch_bounds__(256, (ADP ? 1 : mfma_blocks_per_cu<NX, NU, N, REFS, XB, WS>())) void admm_mfma_kernel(const AdmmParams P) {
     static_assert(!RF || (!WS && REFS != REF_PER_INSTANCE), "refill: one-shot solves, shared or zero references");
+    static_assert(!ADP || !RF, "adaptive rho: not with refill");
     // XB = false with WS: the caller guarantees that the workspace's state dual is zero and stays zero (no finite
     // state bound now, none since the last reset) — g is then neither loaded, carried nor written.
     using S = MfmaShape<NX, NU, N>;
@@ -143,7 +197,8 @@ __global__ __launch_bounds__(256, (mfma_blocks_per_cu<NX, NU, N, REFS, XB, WS>()
     float qd[VX], rd = uok ? s_bnd[S::B_RD + g] : 0.f;
 #pragma unroll
     for (int v = 0; v < VX; ++v) qd[v] = xok[v] ? s_bnd[S::B_QD + 4 * v + g] : 0.f;
-    const float rho = P.rho;
+    float rho = P.rho;            // (ADP: this instance's own, re-predicted every 5th iteration)
+    double rho_d = (double)P.rho;
 
     // per-instance state of this lane: its rows of the state dual, of vnew (in place of v), and its input row's
     // y, znew (in place of z), d.  No state dual without an active state bound (identically zero in a cold one-shot solve).
@@ -190,6 +245,23 @@ __global__ __launch_bounds__(256, (mfma_blocks_per_cu<NX, NU, N, REFS, XB, WS>()
             res0 = P.res[b * 4 + 0], res1 = P.res[b * 4 + 1], res2 = P.res[b * 4 + 2], res3 = P.res[b * 4 + 3];
         }
     }
+    // ---- ADP: the instance's adaptive state (rho, Kinf as dK against the family's, the terminal reference term) ----
+    constexpr int VA = ADP ? VX : 1;
+    double dk[4][VA], accP[VA], spx[VA];
+    const long AB = ADP ? P.adapt_stride : 0;
+    double *const ad = ADP ? P.adapt + b : nullptr;
+    if constexpr (ADP) {
+        const double *K0 = gc + S::O_K0;
+#pragma unroll
+        for (int v = 0; v < VX; ++v) {
+            accP[v] = spx[v] = 0.0;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                dk[a][v] = (active && xok[v] && a < NU) ? ad[(long)(1 + a + (4 * v + g) * NU) * AB] - K0[a * NX + 4 * v + g] : 0.0;
+        }
+        if (active) rho_d = ad[0], rho = (float)rho_d;
+    }
+
     auto ref_x = [&](auto kk, int v) -> float {
         constexpr int K = decltype(kk)::value;
         if constexpr (REFS == REF_SHARED) return xok[v] ? s_ref[K * NX + 4 * v + g] : 0.f;
@@ -203,6 +275,22 @@ __global__ __launch_bounds__(256, (mfma_blocks_per_cu<NX, NU, N, REFS, XB, WS>()
         else return 0.f;
     };
     constexpr float kInf = __builtin_inff();
+    if constexpr (ADP && REFS != REF_ZERO) {
+        // the terminal reference term Pinf_b' xref_{N-1} of this lane's rows, and what a unit step of rho adds to it
+        const double *sP = P.sens + NU * NX;
+#pragma unroll
+        for (int v = 0; v < VX; ++v)
+            if (active && xok[v]) {
+                const int r = 4 * v + g;
+                double a0 = 0.0, a1 = 0.0;
+                for (int jj = 0; jj < NX; ++jj) {
+                    const double xrj = REFS == REF_SHARED ? (double)s_ref[(N - 1) * NX + jj] : (double)P.xref[b * EX + (N - 1) * NX + jj];
+                    a0 = fma(ad[(long)(1 + NU * NX + jj + r * NX) * AB], xrj, a0);
+                    a1 = fma(sP[jj + r * NX], xrj, a1);
+                }
+                accP[v] = a0, spx[v] = a1;
+            }
+    }
 
     int it = 0, conv = 0;
     const int ct = P.check_termination;
@@ -260,6 +348,15 @@ __global__ __launch_bounds__(256, (mfma_blocks_per_cu<NX, NU, N, REFS, XB, WS>()
         double x[VX], c3_pend = 0.0, nd_pend = 0.0;
 #pragma unroll
         for (int v = 0; v < VX; ++v) x[v] = x0[v];
+        // ADP: the iterations that adapt (admm.cpp:147, the loop index before it is bumped) gather the norms on the way
+        const bool adapt_now = ADP && i > 0 && i % 5 == 0;
+        const float rho_lin = rho;   // the linear cost of this iteration is formed before the adaptation (admm.cpp:139 vs :147)
+        double a_pri = 0.0, a_axm = 0.0, a_zm = 0.0, a_dres = 0.0, a_pxm = 0.0, a_atym = 0.0, a_qm = 0.0;
+        double a_xp[VA], a_up = 0.0, a_yp = 0.0, accP_new[VA];
+        float a_gp[VA];
+#pragma unroll
+        for (int v = 0; v < VA; ++v) a_xp[v] = 0.0, a_gp[v] = 0.f, accP_new[v] = accP[v];
+        auto upmax = [](double &m, double v) { v = v < 0.0 ? -v : v; m = v > m ? v : m; };
         mf_for<0, N>([&](auto kk) {
             constexpr int k = decltype(kk)::value;
             asm volatile("" ::: "memory");  // LDS constants (bounds, shared references) are re-read per knot, not hoisted
@@ -270,7 +367,7 @@ __global__ __launch_bounds__(256, (mfma_blocks_per_cu<NX, NU, N, REFS, XB, WS>()
             // accumulator (an inline operand), so no register tuple is initialised or copied between knots.
             mf_d4 c = {0.0, 0.0, 0.0, 0.0};
             double nd = 0.0;
-            if constexpr (k < N - 1) {
+            if constexpr (k < N - 1 && !ADP) {
                 nd = -(double)sd[k];
                 c = mf_mma(cf[S::O_BF], nd, c);                                // [B; 0] (-d)
                 mf_for<0, VX>([&](auto ss) {
@@ -278,7 +375,22 @@ __global__ __launch_bounds__(256, (mfma_blocks_per_cu<NX, NU, N, REFS, XB, WS>()
                     c = mf_mma(cf[S::O_MF + s], x[s], c);                      // + [A - B Kinf; -Kinf] x
                 });
             }
+            if constexpr (k < N - 1 && ADP) {
+                // this instance's own Kinf: d' = d + dK x_k, summed over the instance's lanes while the x products run
+                mf_for<0, VX>([&](auto ss) {
+                    constexpr int s = decltype(ss)::value;
+                    c = mf_mma(cf[S::O_MF + s], x[s], c);                      // [A - B Kinf_0; -Kinf_0] x
+                });
+                double pe[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int a = 0; a < NU; ++a)
+#pragma unroll
+                    for (int v = 0; v < VX; ++v) pe[a] = fma(dk[a][v], x[v], pe[a]);
+                nd = -(double)sd[k] - mf_reduce_scatter4(pe[0], pe[1], pe[2], pe[3]);
+                c = mf_mma(cf[S::O_BF], nd, c);                                // + [B; 0] (-d')
+            }
             // slack / dual of the state rows at this knot (the matrix core works on the products meanwhile)
+            float a_xf[VA], a_vn[VA], a_gn[VA];                               // ADP: this knot's x (as the sets see it), slack, new dual
 #pragma unroll
             for (int v = 0; v < VX; ++v) {
                 const float xf = (float)x[v];
@@ -290,6 +402,7 @@ __global__ __launch_bounds__(256, (mfma_blocks_per_cu<NX, NU, N, REFS, XB, WS>()
                     vn = fminf(hi, fmaxf(lo, vn));
                     sg[XB ? k : 0][v] = (gk + xf) - vn;
                 }
+                if constexpr (ADP) a_xf[v] = xf, a_vn[v] = vn, a_gn[v] = XB ? (gk + xf) - vn : 0.f;
                 if (need_res) {
                     pri_x = fmaxf(pri_x, fabsf(xf - vn));
                     dua_x = fmaxf(dua_x, fabsf(sw[k][v] - vn));
@@ -315,6 +428,73 @@ __global__ __launch_bounds__(256, (mfma_blocks_per_cu<NX, NU, N, REFS, XB, WS>()
                 if constexpr (WS)
                     if (uok) s_old[(N * NX + j * NU + g) * 64 + inst] = szw[j];
                 szw[j] = zn;
+                if constexpr (ADP) {
+                    if (adapt_now) {
+                        upmax(a_pri, (double)uf - (double)zn);
+                        upmax(a_axm, (double)uf);
+                        upmax(a_zm, (double)zn);
+                        a_up = (double)uf, a_yp = (double)((yk + uf) - zn);
+                    }
+                }
+            }
+            if constexpr (ADP) {
+                if (adapt_now) {   // norm rows of knot k - 1 (they needed g_k), the terminal knot's own (admm_quad.hip.h, admm_streamg.hip.h)
+                    if constexpr (k >= 1) {
+                        double atx[VX], btg = 0.0;
+#pragma unroll
+                        for (int v = 0; v < VX; ++v) atx[v] = 0.0;
+                        if constexpr (XB) {
+                            mf_d4 t = {0.0, 0.0, 0.0, 0.0};
+                            mf_for<0, VX>([&](auto ss) {
+                                constexpr int s = decltype(ss)::value;
+                                t = mf_mma(cf[S::O_AT + s], (double)a_gn[s], t);   // [A'; B'] g_k
+                            });
+#pragma unroll
+                            for (int v = 0; v < VX; ++v) atx[v] = t[v] - (k >= 2 ? (double)a_gp[v] : 0.0);
+                            btg = t[3];
+                        }
+#pragma unroll
+                        for (int v = 0; v < VX; ++v) {
+                            const double qv = (double)qd[v] * a_xp[v];
+                            upmax(a_dres, qv + qv + atx[v]);
+                            upmax(a_pxm, qv);
+                            upmax(a_qm, qv);
+                            upmax(a_atym, atx[v]);
+                            upmax(a_pri, (double)a_vn[v]);   // A x + B u - x_k vanishes against the rollout's own x_k
+                            upmax(a_zm, (double)a_vn[v]);
+                        }
+                        const double px = (double)rd * a_up, aty = a_yp + btg;
+                        upmax(a_dres, px + px + aty);
+                        upmax(a_pxm, px);
+                        upmax(a_qm, px);
+                        upmax(a_atym, aty);
+                    }
+                    if constexpr (k == N - 1) {   // Pinf_b x + Q~ x - g of the terminal knot: Pinf_b from the solver's adaptive state
+                        float xs[VX][4];
+#pragma unroll
+                        for (int v = 0; v < VX; ++v) mf_all_gather4(a_xf[v], xs[v]);
+#pragma unroll
+                        for (int v = 0; v < VX; ++v) {
+                            double px = 0.0;
+                            if (active && xok[v]) {
+                                const int r = 4 * v + g;
+#pragma unroll
+                                for (int v2 = 0; v2 < VX; ++v2)
+#pragma unroll
+                                    for (int a2 = 0; a2 < 4; ++a2)
+                                        if (4 * v2 + a2 < NX)
+                                            px = fma(ad[(long)(1 + NU * NX + (4 * v2 + a2) + r * NX) * AB], (double)xs[v2][a2], px);
+                            }
+                            const double qv = (double)qd[v] * (double)a_xf[v], aty = -(double)a_gn[v];
+                            upmax(a_dres, px + qv + aty);
+                            upmax(a_pxm, px);
+                            upmax(a_qm, qv);
+                            upmax(a_atym, aty);
+                        }
+                    }
+#pragma unroll
+                    for (int v = 0; v < VX; ++v) a_xp[v] = (double)a_xf[v], a_gp[v] = a_gn[v];
+                }
             }
             if constexpr (k < N - 1) {
                 c3_pend = c[3];
@@ -331,6 +511,43 @@ __global__ __launch_bounds__(256, (mfma_blocks_per_cu<NX, NU, N, REFS, XB, WS>()
             }
         });
         it += 1;
+        if constexpr (ADP) {
+            if (adapt_now) {
+                // predict_rho (rho_benchmark.cpp:173-195), then the first-order update of Kinf, Pinf (admm.cpp:160-172)
+                const double pri = mf_inst_max_d(a_pri), axm = mf_inst_max_d(a_axm), zm = mf_inst_max_d(a_zm), dres = mf_inst_max_d(a_dres),
+                             pxm = mf_inst_max_d(a_pxm), atym = mf_inst_max_d(a_atym), qm = mf_inst_max_d(a_qm);
+                if (active && !conv) {   // (a finished instance idles: its adaptive state is what it finished with)
+                    const double eps = 1e-10, prin = axm > zm ? axm : zm;
+                    double duan = pxm > atym ? pxm : atym;
+                    duan = qm > duan ? qm : duan;
+                    const double ratio = (pri / (prin + eps)) / (dres / (duan + eps) + eps);
+                    double nrho = rho_d * sqrt(ratio);
+                    if (P.rho_clip) nrho = nrho < (double)P.rho_min ? (double)P.rho_min : (nrho > (double)P.rho_max ? (double)P.rho_max : nrho);
+                    const double delta = nrho - rho_d;
+                    const double *sK = P.sens, *sP = P.sens + NU * NX, *K0 = gc + S::O_K0;
+#pragma unroll
+                    for (int v = 0; v < VX; ++v)
+                        if (xok[v]) {
+                            const int r = 4 * v + g;
+#pragma unroll
+                            for (int a = 0; a < NU; ++a) {   // column r of Kinf: the solver's state and this lane's correction
+                                const long e = (long)(1 + a + r * NU) * AB;
+                                const double kb = ad[e] + delta * sK[a + r * NU];
+                                ad[e] = kb;
+                                dk[a][v] = kb - K0[a * NX + r];
+                            }
+                            for (int jj = 0; jj < NX; ++jj) {   // column r of Pinf
+                                const long e = (long)(1 + NU * NX + jj + r * NX) * AB;
+                                ad[e] = ad[e] + delta * sP[jj + r * NX];
+                            }
+                            accP_new[v] = accP[v] + delta * spx[v];
+                        }
+                    if (g == 0) ad[0] = nrho;
+                    rho_d = nrho;
+                    rho = (float)nrho;
+                }
+            }
+        }
         bool newly = false;
         if (need_res) {
             const float r0 = mf_inst_max(pri_x), r1 = mf_inst_max(dua_x) * rho, r2 = mf_inst_max(pri_u),
@@ -394,14 +611,18 @@ __global__ __launch_bounds__(256, (mfma_blocks_per_cu<NX, NU, N, REFS, XB, WS>()
         double p[VX];
         {
             mf_d4 c = {0.0, 0.0, 0.0, 0.0};
-            if constexpr (REFS != REF_ZERO) {
+            if constexpr (REFS != REF_ZERO && !ADP) {
                 mf_for<0, VX>([&](auto ss) {
                     constexpr int s = decltype(ss)::value;
                     c = mf_mma(cf[S::O_PT + s], (double)ref_x(std::integral_constant<int, N - 1>{}, s), c);  // Pinf^T xref
                 });
             }
+            if constexpr (ADP) {                                               // the instance's own Pinf, as of this iteration's linear cost
 #pragma unroll
-            for (int v = 0; v < VX; ++v) p[v] = -c[v] - (double)(rho * (sw[N - 1][v] - (XB ? sg[XB ? N - 1 : 0][v] : 0.f)));
+                for (int v = 0; v < VX; ++v) c[v] = accP[v], accP[v] = accP_new[v];
+            }
+#pragma unroll
+            for (int v = 0; v < VX; ++v) p[v] = -c[v] - (double)(rho_lin * (sw[N - 1][v] - (XB ? sg[XB ? N - 1 : 0][v] : 0.f)));
         }
         // p- = q + AmBKt p - Kinf^T r and d = Quu_inv (B^T p + r), again ordered for the matrix core: the product that
         // does not depend on p opens the chain, and the d product of a knot is issued one knot later, when its operand
@@ -411,14 +632,23 @@ __global__ __launch_bounds__(256, (mfma_blocks_per_cu<NX, NU, N, REFS, XB, WS>()
             constexpr int k = N - 2 - decltype(kk)::value;
             constexpr std::integral_constant<int, k> kc{};
             asm volatile("" ::: "memory");
-            const double r = (double)(-(ref_u(kc) * rd) - rho * (szw[k] - sy[k]));
+            const float rf = -(ref_u(kc) * rd) - rho_lin * (szw[k] - sy[k]);
+            const double r = (double)rf;
             mf_d4 c;
 #pragma unroll
             for (int v = 0; v < 3; ++v)
                 c[v] = v < VX ? (double)(-(ref_x(kc, v < VX ? v : 0) * qd[v < VX ? v : 0]) -
-                                         rho * (sw[k][v < VX ? v : 0] - (XB ? sg[XB ? k : 0][v < VX ? v : 0] : 0.f)))
+                                         rho_lin * (sw[k][v < VX ? v : 0] - (XB ? sg[XB ? k : 0][v < VX ? v : 0] : 0.f)))
                               : 0.0;
             c[3] = r;
+            if constexpr (ADP) {                                               // - dK' r: the instance's own Kinf in - Kinf' r
+                float ra[4];
+                mf_all_gather4(rf, ra);
+#pragma unroll
+                for (int a = 0; a < NU; ++a)
+#pragma unroll
+                    for (int v = 0; v < VX; ++v) c[v] = fma(-dk[a][v], (double)ra[a], c[v]);
+            }
             c = mf_mma(cf[S::O_KT], r, c);                                     // {q, r} + [-Kinf^T; 0] r
             if constexpr (k < N - 2) {
                 mf_d4 dq = {0.0, 0.0, 0.0, 0.0};

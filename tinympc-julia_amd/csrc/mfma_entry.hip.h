@@ -13,7 +13,7 @@ namespace tmpc {
 template <int NX, int NU, int N>
 void build_mfma_coef(const Solver &sv, std::vector<unsigned char> &out) {
     using S = MfmaShape<NX, NU, N>;
-    out.assign((size_t)S::NF * 64 * sizeof(double), 0);
+    out.assign((size_t)S::COEF_DOUBLES * sizeof(double), 0);
     double *o = reinterpret_cast<double *>(out.data());
     const Cache &c = sv.cache;
     for (int l = 0; l < 64; ++l) {
@@ -23,8 +23,9 @@ void build_mfma_coef(const Solver &sv, std::vector<unsigned char> &out) {
         const bool urow = a >= 0 && a < NU;
         for (int s = 0; s < S::VX; ++s) {
             const int col = 4 * s + kq;             // state index the slice's column stands for
-            double mf = 0.0, mb = 0.0, pt = 0.0;
+            double mf = 0.0, mb = 0.0, pt = 0.0, at = 0.0;
             if (col < NX) {
+                at = xrow ? sv.A(col, i) : (urow ? sv.B(col, a) : 0.0);   // ([A'; B'])[i][col]: A'g, B'g of the adaptive-rho norms
                 if (xrow) {
                     mf = sv.A(i, col);              // (A - B Kinf)[i][col], from A, B, Kinf themselves (set_cache_terms may
                     for (int a2 = 0; a2 < NU; ++a2) mf -= sv.B(i, a2) * c.Kinf(a2, col);   // hand in an AmBKt that differs)
@@ -38,11 +39,14 @@ void build_mfma_coef(const Solver &sv, std::vector<unsigned char> &out) {
             o[(S::O_MF + s) * 64 + l] = mf;
             o[(S::O_MB + s) * 64 + l] = mb;
             o[(S::O_PT + s) * 64 + l] = pt;
+            o[(S::O_AT + s) * 64 + l] = at;
         }
         o[S::O_BF * 64 + l] = (xrow && kq < NU) ? sv.B(i, kq) : 0.0;
         o[S::O_KT * 64 + l] = (xrow && kq < NU) ? -c.Kinf(kq, i) : 0.0;   // -(Kinf^T)[i][kq]
         o[S::O_QI * 64 + l] = (urow && kq < NU) ? c.Quu_inv(a, kq) : 0.0;
     }
+    for (int a = 0; a < NU; ++a)
+        for (int r = 0; r < NX; ++r) o[S::O_K0 + a * NX + r] = c.Kinf(a, r);
 }
 
 template <int NX, int NU, int N>
@@ -111,8 +115,34 @@ hipError_t launch_mfma_refill(const AdmmParams &P, hipStream_t stream) {
 // precision is ignored: the matrix cores run the recurrences in fp64 (the kernel is only selected for precision 0).
 // A launch that reads or keeps the workspace takes the WS variant (old slack parked in LDS).  `state_bounds_active`
 // here also covers "the workspace's state dual may be non-zero" (Solver::launch_pass) — only then is g carried.
+// adaptive rho (admm.cpp:147-174): the ADP variants — one-shot or workspace-carrying, no refill
+template <int NX, int NU, int N, bool XB, bool WS>
+hipError_t launch_mfma_adp(const AdmmParams &P, hipStream_t stream) {
+    const int grid = (P.batch + 63) / 64;
+    const size_t lds = WS ? mfma_ws_lds_bytes<NX, NU, N>() : 0;
+#define TMPC_MFMA_LAUNCH_ADP(REFS_)                                                                                 \
+    do {                                                                                                            \
+        if (lds > 48 * 1024)                                                                                        \
+            (void)hipFuncSetAttribute((const void *)admm_mfma_kernel<NX, NU, N, REFS_, XB, WS, false, true>,        \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
+        hipLaunchKernelGGL((admm_mfma_kernel<NX, NU, N, REFS_, XB, WS, false, true>), dim3(grid), dim3(256), lds, stream, P); \
+    } while (0)
+    switch (P.ref_mode) {
+        case REF_ZERO: TMPC_MFMA_LAUNCH_ADP(REF_ZERO); break;
+        case REF_SHARED: TMPC_MFMA_LAUNCH_ADP(REF_SHARED); break;
+        default: TMPC_MFMA_LAUNCH_ADP(REF_PER_INSTANCE); break;
+    }
+#undef TMPC_MFMA_LAUNCH_ADP
+    return hipGetLastError();
+}
+
 template <int NX, int NU, int N>
 hipError_t launch_mfma(const AdmmParams &P, int /*precision*/, bool state_bounds_active, hipStream_t stream) {
+    if (P.adaptive_rho) {
+        const bool ws = !P.cold_start || P.save_state;
+        if (state_bounds_active) return ws ? launch_mfma_adp<NX, NU, N, true, true>(P, stream) : launch_mfma_adp<NX, NU, N, true, false>(P, stream);
+        return ws ? launch_mfma_adp<NX, NU, N, false, true>(P, stream) : launch_mfma_adp<NX, NU, N, false, false>(P, stream);
+    }
     if (!P.cold_start || P.save_state)
         return state_bounds_active ? launch_mfma_xb<NX, NU, N, true, true>(P, stream)
                                    : launch_mfma_xb<NX, NU, N, false, true>(P, stream);
@@ -126,7 +156,7 @@ hipError_t launch_mfma(const AdmmParams &P, int /*precision*/, bool state_bounds
 #define TMPC_DEFINE_MFMA_ENTRY(NX, NU, NN)                                                                 \
     const KernelEntry *mfma_entry_##NX##_##NU##_##NN() {                                                   \
         static const KernelEntry e = {NX, NU, NN, 16, "mfma<" #NX "," #NU "," #NN ">", &build_mfma_coef<NX, NU, NN>, \
-                                      &build_mfma_bounds<NX, NU, NN>, &launch_mfma<NX, NU, NN>};           \
+                                      &build_mfma_bounds<NX, NU, NN>, &launch_mfma<NX, NU, NN>, true};     \
         return &e;                                                                                         \
     }
 

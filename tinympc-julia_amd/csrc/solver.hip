@@ -328,6 +328,12 @@ int Solver::select_kernel(bool rollout) {
         const bool quad_adp_ok = ka && ka->adp && !has_fdyn && !cones_active() && !lin_active() && chunk_iters == 0 &&
                                  !rollout && !cache_overridden;
         k = quad_adp_ok ? ka : nullptr;
+        // the matrix-core kernel's ADP variant (round 3; the quadrotor shapes — what the reference's adaptive rho is built
+        // for): an instance's own Kinf as a correction to the shared products.  TINYMPC_HIP_NO_MFMA_ADP: tuning / test aid
+        if (!k && precision == 0 && !has_fdyn && !cones_active() && !lin_active() && chunk_iters == 0 && !rollout && !cache_overridden &&
+            !genv && !std::getenv("TINYMPC_HIP_NO_MFMA") && !std::getenv("TINYMPC_HIP_NO_MFMA_ADP") && !std::getenv("TINYMPC_HIP_NO_QUAD"))
+            if (const KernelEntry *m = find_mfma_kernel(nx, nu, N))
+                if (m->adp) k = m;
     }
     if (std::getenv("TINYMPC_HIP_NO_QUAD")) k = nullptr;    // tuning aid: time the fallback kernels on any shape
     // plain solves with fp64 recurrences: the matrix-core kernel of the shape (the fused closed loop stays on the quad
