@@ -1,5 +1,5 @@
-"""Randomised sweep of the adaptive-rho kernels (quad ADP for the cartpole shapes, stream ADP for every other instantiated
-(nx, nu)) against the generic kernel, which the compiled-reference fixtures G9a-d pin: same iteration counts, rho within
+"""Randomised sweep of the adaptive-rho kernels (quad ADP for the cartpole shapes, the matrix-core ADP variant for the quadrotor
+shape at its compiled horizons — MFMA=1 restricts the sweep to it —, stream ADP for every other instantiated (nx, nu)) against the generic kernel, which the compiled-reference fixtures G9a-d pin: same iteration counts, rho within
 1e-5 relative, solutions within 1e-5."""
 import numpy as np, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,10 +7,10 @@ import tinympc_julia_amd as t
 from tests.util import nrel_batch
 
 def run(prob, x0, kw, clip, refs, generic):
-    for v in ("TINYMPC_HIP_NO_QUAD_ADP", "TINYMPC_HIP_NO_STREAM_ADP"):
+    for v in ("TINYMPC_HIP_NO_QUAD_ADP", "TINYMPC_HIP_NO_STREAM_ADP", "TINYMPC_HIP_NO_MFMA_ADP"):
         os.environ.pop(v, None)
     if generic:
-        os.environ["TINYMPC_HIP_NO_QUAD_ADP"] = os.environ["TINYMPC_HIP_NO_STREAM_ADP"] = "1"
+        os.environ["TINYMPC_HIP_NO_QUAD_ADP"] = os.environ["TINYMPC_HIP_NO_STREAM_ADP"] = os.environ["TINYMPC_HIP_NO_MFMA_ADP"] = "1"
     bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=x0.shape[1])
     bs.update_settings(**kw)
     bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
@@ -35,6 +35,8 @@ for seed in range(s0, s0 + n):
     else:
         nx, nu = [(2, 1), (3, 2), (4, 2), (6, 3), (8, 2), (12, 4), (4, 1)][int(rng.integers(0, 7))]
         N = int(rng.integers(3, 26))
+    if os.environ.get("MFMA"):               # the matrix-core ADP variant (round 3): the quadrotor shape at its compiled horizons
+        nx, nu, N = 12, 4, int(rng.choice([10, 15, 20, 25, 30]))
     B = int(rng.integers(3, 40))
     A = np.eye(nx) + 0.2 * rng.standard_normal((nx, nx)) / np.sqrt(nx)
     A *= rng.uniform(0.9, 0.995) / np.abs(np.linalg.eigvals(A)).max()

@@ -261,6 +261,10 @@ __global__ __launch_bounds__(256, (ADP ? 1 : mfma_blocks_per_cu<NX, NU, N, REFS,
         }
         if (active) rho_d = ad[0], rho = (float)rho_d;
     }
+    // The solver's Kinf / Pinf of the instance are first-order in rho with constant tables, so the whole solve's change is
+    // (rho_now - rho_entry) x table: the lane's dK is kept current in registers, HBM gets Kinf and Pinf once, when the
+    // instance finishes (store_adapt) — not a read-modify-write of 192 doubles per instance at every adaptation.
+    const double rho_entry = rho_d;
 
     auto ref_x = [&](auto kk, int v) -> float {
         constexpr int K = decltype(kk)::value;
@@ -336,6 +340,31 @@ __global__ __launch_bounds__(256, (ADP ? 1 : mfma_blocks_per_cu<NX, NU, N, REFS,
                 P.sy[b * EU + k * NU + g] = sy[k];
                 P.sz[b * EU + k * NU + g] = parked ? s_old[(N * NX + k * NU + g) * 64 + inst] : szw[k];
                 P.sd[b * EU + k * NU + g] = sd[k];
+            }
+        }
+    };
+
+    // ADP: the instance's adaptive state as the reference leaves it (rho, Kinf, Pinf: admm.cpp:160-172 accumulated)
+    auto store_adapt = [&]() {
+        if constexpr (ADP) {
+            const double dr = rho_d - rho_entry;
+            if (dr != 0.0) {
+                const double *sK = P.sens, *sP = P.sens + NU * NX;
+#pragma unroll
+                for (int v = 0; v < VX; ++v)
+                    if (xok[v]) {
+                        const int r = 4 * v + g;
+#pragma unroll
+                        for (int a = 0; a < NU; ++a) {
+                            const long e = (long)(1 + a + r * NU) * AB;
+                            ad[e] = ad[e] + dr * sK[a + r * NU];
+                        }
+                        for (int jj = 0; jj < NX; ++jj) {
+                            const long e = (long)(1 + NU * NX + jj + r * NX) * AB;
+                            ad[e] = ad[e] + dr * sP[jj + r * NX];
+                        }
+                    }
+                if (g == 0) ad[0] = rho_d;
             }
         }
     };
@@ -483,7 +512,9 @@ __global__ __launch_bounds__(256, (ADP ? 1 : mfma_blocks_per_cu<NX, NU, N, REFS,
 #pragma unroll
                                     for (int a2 = 0; a2 < 4; ++a2)
                                         if (4 * v2 + a2 < NX)
-                                            px = fma(ad[(long)(1 + NU * NX + (4 * v2 + a2) + r * NX) * AB], (double)xs[v2][a2], px);
+                                            px = fma(ad[(long)(1 + NU * NX + (4 * v2 + a2) + r * NX) * AB] +
+                                                         (rho_d - rho_entry) * (P.sens + NU * NX)[(4 * v2 + a2) + r * NX],
+                                                     (double)xs[v2][a2], px);
                             }
                             const double qv = (double)qd[v] * (double)a_xf[v], aty = -(double)a_gn[v];
                             upmax(a_dres, px + qv + aty);
@@ -524,25 +555,15 @@ __global__ __launch_bounds__(256, (ADP ? 1 : mfma_blocks_per_cu<NX, NU, N, REFS,
                     double nrho = rho_d * sqrt(ratio);
                     if (P.rho_clip) nrho = nrho < (double)P.rho_min ? (double)P.rho_min : (nrho > (double)P.rho_max ? (double)P.rho_max : nrho);
                     const double delta = nrho - rho_d;
-                    const double *sK = P.sens, *sP = P.sens + NU * NX, *K0 = gc + S::O_K0;
+                    const double *sK = P.sens;
 #pragma unroll
                     for (int v = 0; v < VX; ++v)
                         if (xok[v]) {
                             const int r = 4 * v + g;
 #pragma unroll
-                            for (int a = 0; a < NU; ++a) {   // column r of Kinf: the solver's state and this lane's correction
-                                const long e = (long)(1 + a + r * NU) * AB;
-                                const double kb = ad[e] + delta * sK[a + r * NU];
-                                ad[e] = kb;
-                                dk[a][v] = kb - K0[a * NX + r];
-                            }
-                            for (int jj = 0; jj < NX; ++jj) {   // column r of Pinf
-                                const long e = (long)(1 + NU * NX + jj + r * NX) * AB;
-                                ad[e] = ad[e] + delta * sP[jj + r * NX];
-                            }
+                            for (int a = 0; a < NU; ++a) dk[a][v] += delta * sK[a + r * NU];   // column r of Kinf, as this lane's correction
                             accP_new[v] = accP[v] + delta * spx[v];
                         }
-                    if (g == 0) ad[0] = nrho;
                     rho_d = nrho;
                     rho = (float)nrho;
                 }
@@ -601,6 +622,7 @@ __global__ __launch_bounds__(256, (ADP ? 1 : mfma_blocks_per_cu<NX, NU, N, REFS,
             if (__builtin_amdgcn_ballot_w64(newly)) {
                 if (newly && active) {
                     store_solution();
+                    store_adapt();
                     if constexpr (WS)
                         if (P.save_state) store_workspace(true);
                 }
@@ -686,6 +708,7 @@ __global__ __launch_bounds__(256, (ADP ? 1 : mfma_blocks_per_cu<NX, NU, N, REFS,
     if constexpr (!RF) {
         if (active && !conv) {
             store_solution();
+            store_adapt();
             if constexpr (WS)
                 if (P.save_state) store_workspace(false);
         }
