@@ -584,6 +584,8 @@ def main():
                                                             check=10, compaction=20)
         # the headline workload with the reference's adaptive rho switched on
         ex["cartpole_65536_adaptive_rho"] = time_config(t, torch, dev, stream, "cartpole", 65536, 0, adaptive=True)
+        # ... and the shape the reference's adaptive rho is built for (its tables are the quadrotor's, tiny_api.cpp:269-329)
+        ex["quadrotor_65536_adaptive_rho"] = time_config(t, torch, dev, stream, "quadrotor", 65536, 1, adaptive=True)
         out["configs"] = ex
     if rank == 0:
         print(json.dumps(out), flush=True)
