@@ -339,6 +339,14 @@ def time_config(t, torch, dev, stream, name, batch, seed, iters=100, tol=0.0, ch
         if compaction > 0 and tol > 0.0:
             k_ms, launches_per_step = ms, None      # several launches + compaction kernels per solve: wall time is the figure
         roof, valu = roofline_of(bs, name, 0, batch, it_mean, k_ms if k_ms > 0 else ms)
+        if adaptive or keep_workspace or tol != 0.0:
+            # the committed counter passes are of the plain cold fixed-iteration launch of the family: another kernel variant /
+            # calling pattern moves other bytes and issues other instructions
+            roof["traffic"], roof["traffic_source"] = None, "not profiled in this calling pattern"
+            if isinstance(valu, dict):
+                for kk in ("issue_utilisation", "counters_source", "executed_flops_upper_bound", "executed_frac_of_fp64_vector_peak"):
+                    if kk in valu:
+                        valu[kk] = None
         out = {"workload": f"{label}, batch={batch}, " + (f"tol={tol:g} check every {check}, max_iter={iters}" if tol > 0
                                                          else f"fixed {iters} ADMM iters") +
                            (", workspace kept between solves (warm start)" if keep_workspace else ", cold start"),
