@@ -52,9 +52,10 @@ template <int NX, int NU, int N>
 struct MfmaShape {
     static_assert(NX >= 1 && NX <= 12 && NU >= 1 && NU <= 4, "mfma kernel: nx <= 12, nu <= 4");
     static constexpr int VX = (NX + 3) / 4;             // state rows (registers) per lane
-    static constexpr int NF = 4 * VX + 3;               // operand doubles per lane: Mf[VX] Bf Mb[VX] KTn QI PT[VX] AT[VX]
+    static constexpr int NF = 5 * VX + 3;               // operand doubles per lane: Mf[VX] Bf Mb[VX] KTn QI PT[VX] AT[VX] SP[VX]
     static constexpr int O_MF = 0, O_BF = VX, O_MB = VX + 1, O_KT = 2 * VX + 1, O_QI = 2 * VX + 2, O_PT = 2 * VX + 3,
-                         O_AT = 3 * VX + 3;             // AT: [A^T; B^T] (adaptive rho: the norms' A'g, B'g)
+                         O_AT = 3 * VX + 3,             // AT: [A^T; B^T] (adaptive rho: the norms' A'g, B'g)
+                         O_SP = 4 * VX + 3;             // SP: (dPinf/drho)^T (adaptive rho: the terminal knot's Pinf_b x)
     // behind the lane fields: the family's Kinf, row-major [NU][NX] (adaptive rho: an instance's own Kinf enters as a
     // correction to the products formed with this one)
     static constexpr int O_K0 = NF * 64, COEF_DOUBLES = O_K0 + NU * NX;
@@ -380,12 +381,14 @@ __global__ __launch_bounds__(256, (ADP ? 1 : mfma_blocks_per_cu<NX, NU, N, REFS,
         // ADP: the iterations that adapt (admm.cpp:147, the loop index before it is bumped) gather the norms on the way
         const bool adapt_now = ADP && i > 0 && i % 5 == 0;
         const float rho_lin = rho;   // the linear cost of this iteration is formed before the adaptation (admm.cpp:139 vs :147)
-        double a_pri = 0.0, a_axm = 0.0, a_zm = 0.0, a_dres = 0.0, a_pxm = 0.0, a_atym = 0.0, a_qm = 0.0;
+        // (|P x| and |q| take the same values on every row but the terminal knot's, |A x - z| and |z| the same on the state rows:
+        // one running maximum each for the shared part — a_pq, a_vnm — a third of the maxima less per knot)
+        double a_pri = 0.0, a_axm = 0.0, a_zm = 0.0, a_dres = 0.0, a_pxm = 0.0, a_atym = 0.0, a_qm = 0.0, a_pq = 0.0, a_vnm = 0.0;
         double a_xp[VA], a_up = 0.0, a_yp = 0.0, accP_new[VA];
         float a_gp[VA];
 #pragma unroll
         for (int v = 0; v < VA; ++v) a_xp[v] = 0.0, a_gp[v] = 0.f, accP_new[v] = accP[v];
-        auto upmax = [](double &m, double v) { v = v < 0.0 ? -v : v; m = v > m ? v : m; };
+        auto upmax = [](double &m, double v) { m = __builtin_fmax(m, __builtin_fabs(v)); };   // (one v_max_f64 with |.| on its operand)
         mf_for<0, N>([&](auto kk) {
             constexpr int k = decltype(kk)::value;
             asm volatile("" ::: "memory");  // LDS constants (bounds, shared references) are re-read per knot, not hoisted
@@ -459,6 +462,7 @@ __global__ __launch_bounds__(256, (ADP ? 1 : mfma_blocks_per_cu<NX, NU, N, REFS,
                 szw[j] = zn;
                 if constexpr (ADP) {
                     if (adapt_now) {
+                        asm volatile("" ::: "memory");
                         upmax(a_pri, (double)uf - (double)zn);
                         upmax(a_axm, (double)uf);
                         upmax(a_zm, (double)zn);
@@ -468,6 +472,9 @@ __global__ __launch_bounds__(256, (ADP ? 1 : mfma_blocks_per_cu<NX, NU, N, REFS,
             }
             if constexpr (ADP) {
                 if (adapt_now) {   // norm rows of knot k - 1 (they needed g_k), the terminal knot's own (admm_quad.hip.h, admm_streamg.hip.h)
+                    // (the block has no side effects, and left alone the compiler runs it — three products and ~60 fp64
+                    // instructions per knot — on EVERY iteration and selects at the end)
+                    asm volatile("" ::: "memory");
                     if constexpr (k >= 1) {
                         double atx[VX], btg = 0.0;
 #pragma unroll
@@ -486,25 +493,28 @@ __global__ __launch_bounds__(256, (ADP ? 1 : mfma_blocks_per_cu<NX, NU, N, REFS,
                         for (int v = 0; v < VX; ++v) {
                             const double qv = (double)qd[v] * a_xp[v];
                             upmax(a_dres, qv + qv + atx[v]);
-                            upmax(a_pxm, qv);
-                            upmax(a_qm, qv);
+                            upmax(a_pq, qv);                 // |P x| and |q| of the row
                             upmax(a_atym, atx[v]);
-                            upmax(a_pri, (double)a_vn[v]);   // A x + B u - x_k vanishes against the rollout's own x_k
-                            upmax(a_zm, (double)a_vn[v]);
+                            upmax(a_vnm, (double)a_vn[v]);   // |A x - z| and |z|: A x + B u - x_k vanishes against the rollout's own x_k
                         }
                         const double px = (double)rd * a_up, aty = a_yp + btg;
                         upmax(a_dres, px + px + aty);
-                        upmax(a_pxm, px);
-                        upmax(a_qm, px);
+                        upmax(a_pq, px);
                         upmax(a_atym, aty);
                     }
                     if constexpr (k == N - 1) {   // Pinf_b x + Q~ x - g of the terminal knot: Pinf_b from the solver's adaptive state
                         float xs[VX][4];
 #pragma unroll
                         for (int v = 0; v < VX; ++v) mf_all_gather4(a_xf[v], xs[v]);
+                        // Pinf_b = Pinf_entry + (rho_now - rho_entry) dPinf: the entry state from HBM, the table's part as a product
+                        mf_d4 spx4 = {0.0, 0.0, 0.0, 0.0};
+                        mf_for<0, VX>([&](auto ss) {
+                            constexpr int s2 = decltype(ss)::value;
+                            spx4 = mf_mma(cf[S::O_SP + s2], (double)a_xf[s2], spx4);
+                        });
 #pragma unroll
                         for (int v = 0; v < VX; ++v) {
-                            double px = 0.0;
+                            double px = (rho_d - rho_entry) * spx4[v];
                             if (active && xok[v]) {
                                 const int r = 4 * v + g;
 #pragma unroll
@@ -512,9 +522,7 @@ __global__ __launch_bounds__(256, (ADP ? 1 : mfma_blocks_per_cu<NX, NU, N, REFS,
 #pragma unroll
                                     for (int a2 = 0; a2 < 4; ++a2)
                                         if (4 * v2 + a2 < NX)
-                                            px = fma(ad[(long)(1 + NU * NX + (4 * v2 + a2) + r * NX) * AB] +
-                                                         (rho_d - rho_entry) * (P.sens + NU * NX)[(4 * v2 + a2) + r * NX],
-                                                     (double)xs[v2][a2], px);
+                                            px = fma(ad[(long)(1 + NU * NX + (4 * v2 + a2) + r * NX) * AB], (double)xs[v2][a2], px);
                             }
                             const double qv = (double)qd[v] * (double)a_xf[v], aty = -(double)a_gn[v];
                             upmax(a_dres, px + qv + aty);
@@ -545,8 +553,9 @@ __global__ __launch_bounds__(256, (ADP ? 1 : mfma_blocks_per_cu<NX, NU, N, REFS,
         if constexpr (ADP) {
             if (adapt_now) {
                 // predict_rho (rho_benchmark.cpp:173-195), then the first-order update of Kinf, Pinf (admm.cpp:160-172)
-                const double pri = mf_inst_max_d(a_pri), axm = mf_inst_max_d(a_axm), zm = mf_inst_max_d(a_zm), dres = mf_inst_max_d(a_dres),
-                             pxm = mf_inst_max_d(a_pxm), atym = mf_inst_max_d(a_atym), qm = mf_inst_max_d(a_qm);
+                const double pri = mf_inst_max_d(fmax(a_pri, a_vnm)), axm = mf_inst_max_d(a_axm), zm = mf_inst_max_d(fmax(a_zm, a_vnm)),
+                             dres = mf_inst_max_d(a_dres), pxm = mf_inst_max_d(fmax(a_pxm, a_pq)), atym = mf_inst_max_d(a_atym),
+                             qm = mf_inst_max_d(fmax(a_qm, a_pq));
                 if (active && !conv) {   // (a finished instance idles: its adaptive state is what it finished with)
                     const double eps = 1e-10, prin = axm > zm ? axm : zm;
                     double duan = pxm > atym ? pxm : atym;

@@ -23,8 +23,10 @@ void build_mfma_coef(const Solver &sv, std::vector<unsigned char> &out) {
         const bool urow = a >= 0 && a < NU;
         for (int s = 0; s < S::VX; ++s) {
             const int col = 4 * s + kq;             // state index the slice's column stands for
-            double mf = 0.0, mb = 0.0, pt = 0.0, at = 0.0;
+            double mf = 0.0, mb = 0.0, pt = 0.0, at = 0.0, sp = 0.0;
             if (col < NX) {
+                // (dPinf/drho)^T [i][col]: row i of the product = sum_col dPinf[col][i] x_col, like Pinf^T above
+                if (xrow && sv.sens.size() == (size_t)NU * NX + (size_t)NX * NX) sp = sv.sens[(size_t)NU * NX + col + (size_t)i * NX];
                 at = xrow ? sv.A(col, i) : (urow ? sv.B(col, a) : 0.0);   // ([A'; B'])[i][col]: A'g, B'g of the adaptive-rho norms
                 if (xrow) {
                     mf = sv.A(i, col);              // (A - B Kinf)[i][col], from A, B, Kinf themselves (set_cache_terms may
@@ -40,6 +42,7 @@ void build_mfma_coef(const Solver &sv, std::vector<unsigned char> &out) {
             o[(S::O_MB + s) * 64 + l] = mb;
             o[(S::O_PT + s) * 64 + l] = pt;
             o[(S::O_AT + s) * 64 + l] = at;
+            o[(S::O_SP + s) * 64 + l] = sp;
         }
         o[S::O_BF * 64 + l] = (xrow && kq < NU) ? sv.B(i, kq) : 0.0;
         o[S::O_KT * 64 + l] = (xrow && kq < NU) ? -c.Kinf(kq, i) : 0.0;   // -(Kinf^T)[i][kq]

@@ -498,6 +498,7 @@ int Solver::set_sensitivity(const double *dK, const double *dP) {
     std::copy(dP, dP + (size_t)nx * nx, sens.begin() + (size_t)nu * nx);
     sens_set = true;
     sens_dirty = true;
+    packs_dirty = true;   // (the matrix-core kernel's adaptive variant carries dPinf' as an operand)
     return 0;
 }
 
