@@ -26,6 +26,7 @@ for fam in ("cartpole", "quadrotor"):
         bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
         bs.update_settings(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=100, check_termination=1)
         bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        os.environ["TINYMPC_HIP_STRICT_FP32"] = "1"   # precision 1 means the fp32 kernels here, also where the matrix cores would be faster
         bs.set_precision(prec); bs.set_warm_start(False); bs.set_x0(x0)
         bs.solve()
         sol = bs.get_solution()

@@ -1373,8 +1373,10 @@ def test_matrix_core_kernel_vs_oracle(hip_lib, oracle_built, monkeypatch, case):
     bs.close()
 
 
-def test_kernel_selection_by_batch(hip_lib):
-    """Lanes per instance follow the batch size; shapes outside the unrolled table use the stream kernel."""
+def test_kernel_selection_by_batch(hip_lib, monkeypatch):
+    """Lanes per instance follow the batch size; shapes outside the unrolled table use the stream kernel.  precision = 1 (fp32
+    recurrences, asked for to save time) stays on the fp64 matrix cores where the shape has them — faster there than the fp32
+    lanes-per-instance kernel (quadrotor N = 30: 4.3 ms against 7.2) — unless TINYMPC_HIP_STRICT_FP32 insists."""
     prob = t.problems.cartpole(20, u_bound=0.5)
     for batch, tag in ((100, "g4>"), (16384, "g4>"), (30000, "g1>"), (65536, "g1>")):
         bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=batch)
@@ -1383,8 +1385,11 @@ def test_kernel_selection_by_batch(hip_lib):
     q = t.problems.quadrotor(30)
     bs = t.BatchSolver(q.A, q.B, q.Q, q.R, q.rho, q.N, batch=8)
     assert bs.kernel_name == "mfma<12,4,30>"
-    bs.set_precision(1)                                   # all-fp32 recurrences: not what the fp64 matrix cores run
+    bs.set_precision(1)
     bs.set_x0(np.zeros((12, 8)))
+    bs.solve()
+    assert bs.kernel_name == "mfma<12,4,30>"
+    monkeypatch.setenv("TINYMPC_HIP_STRICT_FP32", "1")    # all-fp32 recurrences: not what the fp64 matrix cores run
     bs.solve()
     assert bs.kernel_name == "quad<12,4,30,g4>"
     bs.close()

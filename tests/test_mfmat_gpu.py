@@ -370,9 +370,9 @@ def test_mfmat_config4_every_instance(hip_lib, oracle_built):
         bs.close()
 
 
-def test_mfmat_selection(hip_lib):
+def test_mfmat_selection(hip_lib, monkeypatch):
     """what runs where: the transposed-sets kernel takes the affine term / one cone per side of the rocket's layout in every
-    calling pattern, with shared, zero or per-instance references; other cone layouts, linear rows, fp32 recurrences stay where they were"""
+    calling pattern, with shared, zero or per-instance references; other cone layouts and linear rows stay where they were (fp32 recurrences only if TINYMPC_HIP_STRICT_FP32 insists)"""
     prob = t.problems.rocket(10)
     xr, ur = t.problems.rocket_refs(10)
     kw = SETTINGS["tol"]
@@ -385,7 +385,11 @@ def test_mfmat_selection(hip_lib):
     bs.set_x0(t.problems.rocket_x0(8, seed=1))
     bs.set_precision(1)                                            # (the kernel is chosen when a solve is launched)
     bs.solve()
+    assert bs.kernel_name == "mfmat<6,3,10>"                       # fp32 recurrences are asked for to save time: no saving here
+    monkeypatch.setenv("TINYMPC_HIP_STRICT_FP32", "1")
+    bs.solve()
     assert bs.kernel_name == "stream4<6,3>"
+    monkeypatch.delenv("TINYMPC_HIP_STRICT_FP32")
     bs.set_precision(0)
     bs.solve()
     assert bs.kernel_name == "mfmat<6,3,10>"

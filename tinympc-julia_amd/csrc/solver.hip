@@ -314,6 +314,11 @@ int Solver::init_families(const double *A_, const double *B_, const double *Q_, 
 // variant (tuning aid); shapes without a specialised kernel run on the generic one.
 int Solver::select_kernel(bool rollout) {
     const char *genv = std::getenv("TINYMPC_HIP_GROUP");
+    // precision = 1 asks for fp32 recurrences to save time.  Where the shape has a matrix-core kernel that is no saving —
+    // quadrotor N = 30: 7.2 ms on the fp32 lanes-per-instance kernel (which spills at that shape) against 4.3 on the fp64
+    // matrix cores, rocket N = 50 box 3.8 / 8.8 (workspace kept) against 2.8 — so such solves run on the matrix cores too
+    // (more digits, less time).  TINYMPC_HIP_STRICT_FP32=1 keeps them on the fp32 kernels (tests, tuning).
+    const bool strict_fp32 = precision != 0 && std::getenv("TINYMPC_HIP_STRICT_FP32") != nullptr;
     const KernelEntry *k = genv ? find_quad_kernel(nx, nu, N, std::atoi(genv)) : nullptr;
     if (!k) k = select_quad_kernel(nx, nu, N, batch);
     if (has_fdyn || cones_active() || lin_active() || hetero) k = nullptr;  // extensions run on the stream / generic kernels
@@ -330,7 +335,7 @@ int Solver::select_kernel(bool rollout) {
         k = quad_adp_ok ? ka : nullptr;
         // the matrix-core kernel's ADP variant (round 3; the quadrotor shapes — what the reference's adaptive rho is built
         // for): an instance's own Kinf as a correction to the shared products.  TINYMPC_HIP_NO_MFMA_ADP: tuning / test aid
-        if (!k && precision == 0 && !has_fdyn && !cones_active() && !lin_active() && chunk_iters == 0 && !rollout && !cache_overridden &&
+        if (!k && !strict_fp32 && !has_fdyn && !cones_active() && !lin_active() && chunk_iters == 0 && !rollout && !cache_overridden &&
             !genv && !std::getenv("TINYMPC_HIP_NO_MFMA") && !std::getenv("TINYMPC_HIP_NO_MFMA_ADP") && !std::getenv("TINYMPC_HIP_NO_QUAD"))
             if (const KernelEntry *m = find_mfma_kernel(nx, nu, N))
                 if (m->adp) k = m;
@@ -345,7 +350,7 @@ int Solver::select_kernel(bool rollout) {
     // there too; what the matrix-core kernel does not take then goes to the stream kernel as before)
     const bool plain_box = !(has_fdyn || cones_active() || lin_active() || hetero);
     if ((k || plain_box) && !st.adaptive_rho && !(rollout && rollout_quad) && (mfma_ws_ok || (!warm_start && chunk_iters == 0)) &&
-        precision == 0 && !genv && !std::getenv("TINYMPC_HIP_NO_MFMA") && !std::getenv("TINYMPC_HIP_NO_QUAD"))
+        !strict_fp32 && !genv && !std::getenv("TINYMPC_HIP_NO_MFMA") && !std::getenv("TINYMPC_HIP_NO_QUAD"))
         if (const KernelEntry *m = find_mfma_kernel(nx, nu, N)) k = m;
     if (!k && (nx > GEN_MAX_NX || nu > GEN_MAX_NU)) {
         set_error("problem shape exceeds the generic kernel limits (nx <= 64, nu <= 32)");
@@ -373,7 +378,7 @@ int Solver::select_kernel(bool rollout) {
     const ConeEntry *cn = std::getenv("TINYMPC_HIP_NO_MFMAR") ? nullptr : find_cone_kernel(nx, nu, N);
     if (cn && cn->supports && !cn->supports(*this)) cn = nullptr;
     const bool plain_ok = std::getenv("TINYMPC_HIP_MFMAC_ALL") != nullptr || (cn != nullptr && cn->plain);
-    if ((s2 || (k && plain_ok)) && !warm_start && chunk_iters == 0 && !rollout && precision == 0 && !hetero &&
+    if ((s2 || (k && plain_ok)) && !warm_start && chunk_iters == 0 && !rollout && !strict_fp32 && !hetero &&
         !st.adaptive_rho && (has_fdyn || cones_active() || lin_active() || plain_ok) && xref_kind < 2 && uref_kind < 2 &&
         !(refs_device_owned && ref_mode == REF_PER_INSTANCE) && !std::getenv("TINYMPC_HIP_NO_MFMAC") && !genv &&
         !std::getenv("TINYMPC_HIP_NO_MFMA")) {
@@ -400,7 +405,7 @@ int Solver::select_kernel(bool rollout) {
     if (ct && ct->supports && !ct->supports(*this)) ct = nullptr;
     // (per-instance references: a second set of LDS cells per tile; the per-step reference shift of the closed loop is for
     // shared references)
-    if (ct && (precision != 0 || hetero || lin_active() || st.adaptive_rho || (refs_per_instance() && ref_seq_steps > 0) || st.max_iter < 1 ||
+    if (ct && (strict_fp32 || hetero || lin_active() || st.adaptive_rho || (refs_per_instance() && ref_seq_steps > 0) || st.max_iter < 1 ||
                !(has_fdyn || cones_active() || ct->plain || std::getenv("TINYMPC_HIP_MFMAT_ALL")) ||
                ct->lds_bytes(*this) > 160 * 1024 - 1024 || (double)batch * ex() >= 2.0e9))
         ct = nullptr;
