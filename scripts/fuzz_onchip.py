@@ -1,16 +1,26 @@
 """Randomised parity sweep of the on-chip matrix-core kernels (mfmar / mfmac) against the fp64 oracle: random stable (6,3)
 families, horizons with and without a compiled instantiation, cones on either / both sides at random rows (state cone inside
 rows 0..3 -> mfmar, else mfmac), per-knot or constant bounds, zero or shared references, with / without the affine term,
-fixed-iteration and tolerance-terminated settings.  Every instance is compared by solution (tests/util.parity_every_instance)."""
+fixed-iteration and tolerance-terminated settings.  Every instance is compared by solution (tests/util.parity_every_instance).
+WIDE=1: what the LDS kernel takes since round 3 (opt-in, TINYMPC_HIP_MFMAC_WIDE): two cones on a side (state side of (6,3), both
+sides of (6,4)), linear-inequality rows on either / both sides, alone and with cones."""
 import numpy as np, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tinympc_julia_amd as t
 from oracle import cpu_oracle
 from tests.util import parity_every_instance
 
+WIDE = bool(os.environ.get("WIDE"))
+if WIDE:
+    os.environ["TINYMPC_HIP_MFMAC_WIDE"] = "1"
+    os.environ["TINYMPC_HIP_NO_MFMAT"] = "1"
+
+
 def one(seed):
     rng = np.random.default_rng(seed)
     nx, nu = 6, 3
+    if WIDE and rng.random() < 0.4:
+        nu = 4
     N = int(rng.choice([10, 20, 30, 50, 7, 13, 26, 41]))
     B = int(rng.integers(5, 60))
     A = np.eye(nx) + 0.2 * rng.standard_normal((nx, nx)) / np.sqrt(nx)
@@ -39,6 +49,21 @@ def one(seed):
         cx = ([a0], [q], [float(rng.uniform(0.3, 1.5))])
     else:
         cx = ([], [], [])
+    lin = None
+    if WIDE:
+        mode = int(rng.integers(0, 4))                      # 0: two cones, 1: linear rows, 2: both, 3: two cones on both sides (nu = 4)
+        if mode in (0, 2, 3):
+            split = int(rng.integers(2, 5))                 # state rows [0, split) and [split, 6), each >= 2 rows
+            cx = ([0, split], [split, nx - split], [float(rng.uniform(0.3, 1.5)), float(rng.uniform(0.3, 1.5))])
+            if rng.random() < 0.3:                          # a gap: the second cone one row shorter
+                cx = ([0, split + 1], [split, nx - split - 1], cx[2]) if nx - split - 1 >= 2 else cx
+            if nu == 4 and mode == 3:
+                cu = ([0, 2], [2, 2], [float(rng.uniform(0.3, 1.2)), float(rng.uniform(0.3, 1.2))])
+        if mode in (1, 2):
+            mx, mu = int(rng.integers(0, 4)), int(rng.integers(0, 3))
+            if mx + mu == 0:
+                mx = 1
+            lin = (rng.standard_normal((mx, nx)), list(rng.uniform(0.1, 0.6, mx)), rng.standard_normal((mu, nu)), list(rng.uniform(0.05, 0.3, mu)))
     cones = (cu[0], cu[1], cu[2], cx[0], cx[1], cx[2]) if (cu[0] or cx[0]) else None
     if cones is None and fdyn is None:
         fdyn = 0.02 * rng.standard_normal(nx)
@@ -52,6 +77,7 @@ def one(seed):
         o.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
         if fdyn is not None: o.set_fdyn(fdyn)
         if cones is not None: o.set_cone_constraints(*cones)
+        if lin is not None: o.set_linear_constraints(*lin)
         if xr is not None: o.set_x_ref(xr); o.set_u_ref(ur)
         return o
     X, U = np.zeros((nx, N, B)), np.zeros((nu, N - 1, B))
@@ -66,6 +92,7 @@ def one(seed):
     bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
     if fdyn is not None: bs.set_fdyn(fdyn)
     if cones is not None: bs.set_cone_constraints(*cones)
+    if lin is not None: bs.set_linear_constraints(*lin)
     bs.set_warm_start(False)
     if xr is not None: bs.set_x_ref(xr); bs.set_u_ref(ur)
     bs.set_x0(x0); bs.solve()
@@ -75,7 +102,7 @@ def one(seed):
         ok = True
     except AssertionError as e:
         ok = False
-        print("FAIL", seed, name, N, B, cones, kw, str(e)[:200], flush=True)
+        print("FAIL", seed, name, N, B, cones, None if lin is None else (len(lin[1]), len(lin[3])), kw, str(e)[:200], flush=True)
     bs.close()
     return name, ok
 
