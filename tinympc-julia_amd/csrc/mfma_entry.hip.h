@@ -156,6 +156,19 @@ hipError_t launch_mfma(const AdmmParams &P, int /*precision*/, bool state_bounds
                                : launch_mfma_xb<NX, NU, N, false, false>(P, stream);
 }
 
+// The twelve adaptive-rho kernels of a shape (reference mode x state bounds x workspace), as explicit instantiation
+// definitions (EXT empty) or declarations (EXT = extern): they are compiled in a translation unit of their own
+// (minst_*_adp.hip) — with them the N = 30 unit took six minutes.
+#define TMPC_MFMA_ADP_KERNELS_R(EXT, NX, NU, NN, REFS)                                                              \
+    EXT template __global__ void admm_mfma_kernel<NX, NU, NN, REFS, false, false, false, true>(const AdmmParams);  \
+    EXT template __global__ void admm_mfma_kernel<NX, NU, NN, REFS, false, true, false, true>(const AdmmParams);   \
+    EXT template __global__ void admm_mfma_kernel<NX, NU, NN, REFS, true, false, false, true>(const AdmmParams);   \
+    EXT template __global__ void admm_mfma_kernel<NX, NU, NN, REFS, true, true, false, true>(const AdmmParams);
+#define TMPC_MFMA_ADP_KERNELS(EXT, NX, NU, NN)                    \
+    TMPC_MFMA_ADP_KERNELS_R(EXT, NX, NU, NN, REF_ZERO)            \
+    TMPC_MFMA_ADP_KERNELS_R(EXT, NX, NU, NN, REF_SHARED)          \
+    TMPC_MFMA_ADP_KERNELS_R(EXT, NX, NU, NN, REF_PER_INSTANCE)
+
 #define TMPC_DEFINE_MFMA_ENTRY(NX, NU, NN)                                                                 \
     const KernelEntry *mfma_entry_##NX##_##NU##_##NN() {                                                   \
         static const KernelEntry e = {NX, NU, NN, 16, "mfma<" #NX "," #NU "," #NN ">", &build_mfma_coef<NX, NU, NN>, \

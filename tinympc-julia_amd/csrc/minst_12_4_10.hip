@@ -1,6 +1,6 @@
-// matrix-core kernel instantiation for nx=12 nu=4 N=10 (quadrotor horizons other than the examples' 20 / BASELINE's 30: the
-// shape has no lanes-per-instance kernel at these horizons, the matrix-core kernel takes its fp64 box-constrained solves)
+// matrix-core kernel instantiation for nx=12 nu=4 N=10 (the adaptive-rho variants: minst_12_4_10_adp.hip)
 #include "mfma_entry.hip.h"
 namespace tmpc {
+TMPC_MFMA_ADP_KERNELS(extern, 12, 4, 10)
 TMPC_DEFINE_MFMA_ENTRY(12, 4, 10)
 }

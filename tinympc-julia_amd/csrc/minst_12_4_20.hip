@@ -1,5 +1,6 @@
-// matrix-core kernel instantiation for nx=12 nu=4 N=20
+// matrix-core kernel instantiation for nx=12 nu=4 N=20 (the adaptive-rho variants: minst_12_4_20_adp.hip)
 #include "mfma_entry.hip.h"
 namespace tmpc {
+TMPC_MFMA_ADP_KERNELS(extern, 12, 4, 20)
 TMPC_DEFINE_MFMA_ENTRY(12, 4, 20)
 }
