@@ -1,4 +1,5 @@
-"""adaptive-rho solve of 65 536 cartpoles: kernel, time, and agreement of the stream kernel's ADP variant with the generic kernel"""
+"""adaptive-rho solve of 65 536 cartpoles (PROB=quadrotor N=30: the shape the reference's adaptive rho is built for): kernel, time, and
+agreement of the fast ADP variants (quad / matrix-core by default, then the stream kernel's) with the generic kernel"""
 import numpy as np, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tinympc_julia_amd as t
@@ -9,8 +10,8 @@ tol = float(os.environ.get("TOL", 1e-3))
 prob = t.problems.cartpole(NH, u_bound=0.5) if which == "cartpole" else t.problems.quadrotor(NH, u_bound=0.5)
 x0 = t.problems.cartpole_x0(B, seed=3) if which == "cartpole" else t.problems.quadrotor_x0(B, seed=3)
 outs = []
-for env in ((), ("TINYMPC_HIP_NO_QUAD_ADP",), ("TINYMPC_HIP_NO_QUAD_ADP", "TINYMPC_HIP_NO_STREAM_ADP")):
-    for v in ("TINYMPC_HIP_NO_QUAD_ADP", "TINYMPC_HIP_NO_STREAM_ADP"):
+for env in ((), ("TINYMPC_HIP_NO_QUAD_ADP", "TINYMPC_HIP_NO_MFMA_ADP"), ("TINYMPC_HIP_NO_QUAD_ADP", "TINYMPC_HIP_NO_MFMA_ADP", "TINYMPC_HIP_NO_STREAM_ADP")):
+    for v in ("TINYMPC_HIP_NO_QUAD_ADP", "TINYMPC_HIP_NO_STREAM_ADP", "TINYMPC_HIP_NO_MFMA_ADP"):
         os.environ.pop(v, None)
     for v in env:
         os.environ[v] = "1"
