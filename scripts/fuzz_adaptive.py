@@ -47,6 +47,9 @@ for seed in range(s0, s0 + n):
     if rng.random() < 0.3:
         prob.x_min[:], prob.x_max[:] = -1e17, 1e17
     refs = (0.2 * rng.standard_normal((nx, N)), 0.1 * rng.standard_normal((nu, N - 1))) if rng.random() < 0.5 else None
+    if refs is not None and rng.random() < 0.4:   # every instance its own references
+        refs = (np.asfortranarray(refs[0][:, :, None] + 0.1 * rng.standard_normal((nx, N, B))),
+                np.asfortranarray(refs[1][:, :, None] + 0.05 * rng.standard_normal((nu, N - 1, B))))
     kw = [dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=int(rng.integers(12, 60)), check_termination=int(rng.choice([1, 4]))),
           dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=int(rng.integers(20, 80)), check_termination=int(rng.choice([1, 5])))][int(rng.integers(0, 2))]
     clip = bool(rng.integers(0, 2))

@@ -617,3 +617,51 @@ def test_mfmat_per_instance_references(hip_lib, oracle_built, N):
     for o in orcs:
         o.close()
     bs.close()
+
+
+def test_mfmat_per_instance_references_chunked_and_closed_loop(hip_lib):
+    """per-instance references through the other calling patterns: a chunked solve with compaction (the launch's slots are
+    an index list into the batch: the tile stages the references of the instances it was handed) agrees with the
+    single-launch solve, and the fused closed loop (references constant over the steps) equals the host-stepped one"""
+    N, B = 10, 53
+    rng = np.random.default_rng(5)
+    prob = t.problems.rocket(N)
+    xr, ur = t.problems.rocket_refs(N)
+    xr3 = np.asfortranarray(xr[:, :, None] * (1.0 + 0.15 * rng.standard_normal((1, 1, B))))
+    ur3 = np.asfortranarray(ur[:, :, None] + 0.5 * rng.standard_normal((3, N - 1, B)))
+    x0 = t.problems.rocket_x0(B, seed=6)
+    kw = dict(abs_pri_tol=2e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=5)
+    outs = []
+    for chunk in (0, 10):
+        bs = _solver(prob, B, kw, xr3, ur3, prob.fdyn, ROCKET_CONES, True)
+        if chunk:
+            bs.set_compaction(chunk)
+        bs.set_x0(x0)
+        bs.solve()
+        assert bs.kernel_name == f"mfmat<6,3,{N}>"
+        outs.append((bs.get_solution(), bs.get_status()))
+        bs.close()
+    # (as for shared references: a chunk boundary takes the feed-forward term through the workspace's fp32 d = Quu_inv t and
+    # back, so the solutions agree to the last digits, not bit for bit)
+    same = outs[0][1]["iter"] == outs[1][1]["iter"]
+    assert same.mean() >= 0.98
+    assert nrel_batch(outs[0][0]["controls"], outs[1][0]["controls"])[same].max() <= 2e-6
+    assert nrel_batch(outs[0][0]["states"], outs[1][0]["states"])[same].max() <= 2e-6
+    assert len(np.unique(outs[0][1]["iter"])) > 1                      # (instances do leave at different checks: the compaction had work)
+    # closed loop: fused against host-stepped
+    steps = 6
+    kw = dict(abs_pri_tol=2e-3, abs_dua_tol=1e-3, max_iter=40, check_termination=1)
+    bs = _solver(prob, B, kw, xr3, ur3, prob.fdyn, ROCKET_CONES, True)
+    bs.set_x0(x0)
+    log = bs.mpc_rollout(steps)
+    assert bs.kernel_name == f"mfmat<6,3,{N}>"
+    bs.close()
+    bs = _solver(prob, B, kw, xr3, ur3, prob.fdyn, ROCKET_CONES, True)
+    xs = x0.copy()
+    for k in range(steps):
+        bs.set_x0(xs)
+        bs.solve()
+        u0 = bs.get_solution()["controls"][:, 0, :]
+        assert nrel(log["u"][:, k, :], u0) <= FP32_TOL, (k, nrel(log["u"][:, k, :], u0))
+        xs = np.asfortranarray(prob.A @ xs + prob.B @ u0 + prob.fdyn[:, None])
+    bs.close()
