@@ -1677,3 +1677,38 @@ def test_matrix_core_workspace_variant_vs_oracle(hip_lib, oracle_built, case):
     else:
         assert gmax <= 1e-5                               # g + x - (x + g): the dual empties once nothing clamps
     bs.close()
+
+
+def test_adaptive_rho_matrix_core_variant_needs_the_state_in_closed_form(hip_lib):
+    """the matrix-core kernel's adaptive variant rebuilds an instance's Kinf / Pinf from its rho alone (family + (rho - rho_family)
+    x tables) — true of a state that only adaptive solves with the CURRENT tables have touched.  New tables under a live state
+    break that: such solves go to the stream kernel (whose rows are the state itself) until the state is reset."""
+    prob = t.problems.quadrotor(20)
+    B = 64
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+    bs.update_settings(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=20, check_termination=1)
+    bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    rng = np.random.default_rng(3)
+    dK0, dP0 = 0.02 * rng.standard_normal((prob.nu, prob.nx)), 0.05 * rng.standard_normal((prob.nx, prob.nx))
+    bs.set_sensitivity(dK0, dP0)                                      # (before any adaptation: the state is the family's cache)
+    bs.set_adaptive_rho(True, 0.1, 10.0, True)
+    bs.set_x0(t.problems.quadrotor_x0(B, seed=2))
+    bs.solve()
+    assert bs.kernel_name == "mfma<12,4,20>"
+    ad = bs.get_adaptive_state()
+    assert np.abs(ad["rho"] - prob.rho).max() > 0                     # the solve did adapt
+    # the state is what the update rule leaves: family + (rho - rho_family) x tables (written once, when an instance finishes)
+    cache = bs.get_cache_terms()
+    for b in (0, B // 2, B - 1):
+        dr = ad["rho"][b] - prob.rho
+        assert nrel(ad["Kinf"][:, :, b], cache["Kinf"] + dr * dK0) <= 1e-12
+        assert nrel(ad["Pinf"][:, :, b], cache["Pinf"] + dr * dP0) <= 1e-12
+    dK = 0.01 * np.ones((prob.nu, prob.nx))
+    dP = 0.01 * np.eye(prob.nx)
+    bs.set_sensitivity(dK, dP)                                        # new tables, live state
+    bs.solve()
+    assert bs.kernel_name == "stream4<12,4>"
+    bs.reset()                                                        # every instance back to the family's cache
+    bs.solve()
+    assert bs.kernel_name == "mfma<12,4,20>"
+    bs.close()

@@ -58,7 +58,9 @@ struct MfmaShape {
                          O_SP = 4 * VX + 3;             // SP: (dPinf/drho)^T (adaptive rho: the terminal knot's Pinf_b x)
     // behind the lane fields: the family's Kinf, row-major [NU][NX] (adaptive rho: an instance's own Kinf enters as a
     // correction to the products formed with this one)
-    static constexpr int O_K0 = NF * 64, COEF_DOUBLES = O_K0 + NU * NX;
+    // ... and its Pinf, row-major [NX][NX] (what an instance's adaptive state is rebuilt from when it finishes)
+    // ... and its rho as a double (AdmmParams::rho is a float)
+    static constexpr int O_K0 = NF * 64, O_P0 = O_K0 + NU * NX, O_RHO0 = O_P0 + NX * NX, COEF_DOUBLES = O_RHO0 + 1;
     // bounds pack (fp32): xmin[N][NX] xmax[N][NX] umin[N-1][NU] umax[N-1][NU] Qd[NX] Rd[NU]
     static constexpr int B_XMIN = 0, B_XMAX = N * NX, B_UMIN = 2 * N * NX, B_UMAX = 2 * N * NX + (N - 1) * NU,
                          B_QD = 2 * N * NX + 2 * (N - 1) * NU, B_RD = B_QD + NX, BOUNDS_LEN = B_RD + NU;
@@ -155,8 +157,11 @@ constexpr int mfma_blocks_per_cu() {
 //               same products with d' — x+ = (A - B Kinf_0) x - B d' = A x + B u, u = -Kinf_0 x - d' = -Kinf_b x - d.  The
 //               product with d' now closes the chain instead of opening it.
 //     backward: -dK' r is added to the accumulator's start on the VALU (r gathered over the instance's lanes; off the chain).
-// Pinf_b is only needed at the terminal knot (its norm rows on adapting iterations, the reference term when there are
-// references) and stays in HBM; the reference term Pinf_b' xref is kept per lane and updated with delta * (dPinf' xref).
+// The updates are first-order in rho with constant tables, so an instance's matrices are the family's plus
+// (rho_b - rho_family) x table (the solver keeps the adaptive state in that form: Solver::adapt_pure): dK comes from rho_b
+// alone, Pinf_b — only needed at the terminal knot: its norm rows on adapting iterations, the reference term when there are
+// references — is two products (Pinf_0', dPinf') per use, and the adaptive state in HBM is read for rho_b at entry and
+// written (rho, Kinf, Pinf) once, when the instance finishes.
 // The norms of rho_benchmark.cpp are gathered as in the quad kernel's ADP variant (admm_quad.hip.h: rows of knot k - 1 at
 // knot k, the terminal knot's own), A'g / B'g by three more products with [A'; B'].
 template <int NX, int NU, int N, int REFS, bool XB, bool WS = false, bool RF = false, bool ADP = false>
@@ -252,20 +257,16 @@ __global__ __launch_bounds__(256, (ADP ? 1 : mfma_blocks_per_cu<NX, NU, N, REFS,
     const long AB = ADP ? P.adapt_stride : 0;
     double *const ad = ADP ? P.adapt + b : nullptr;
     if constexpr (ADP) {
-        const double *K0 = gc + S::O_K0;
+        if (active) rho_d = ad[0], rho = (float)rho_d;
 #pragma unroll
         for (int v = 0; v < VX; ++v) {
             accP[v] = spx[v] = 0.0;
 #pragma unroll
             for (int a = 0; a < 4; ++a)
-                dk[a][v] = (active && xok[v] && a < NU) ? ad[(long)(1 + a + (4 * v + g) * NU) * AB] - K0[a * NX + 4 * v + g] : 0.0;
+                dk[a][v] = (active && xok[v] && a < NU) ? (rho_d - gc[S::O_RHO0]) * P.sens[a + (4 * v + g) * NU] : 0.0;
         }
-        if (active) rho_d = ad[0], rho = (float)rho_d;
     }
-    // The solver's Kinf / Pinf of the instance are first-order in rho with constant tables, so the whole solve's change is
-    // (rho_now - rho_entry) x table: the lane's dK is kept current in registers, HBM gets Kinf and Pinf once, when the
-    // instance finishes (store_adapt) — not a read-modify-write of 192 doubles per instance at every adaptation.
-    const double rho_entry = rho_d;
+    const double rho_fam = ADP ? gc[S::O_RHO0] : 0.0, rho_entry = rho_d;
 
     auto ref_x = [&](auto kk, int v) -> float {
         constexpr int K = decltype(kk)::value;
@@ -281,8 +282,10 @@ __global__ __launch_bounds__(256, (ADP ? 1 : mfma_blocks_per_cu<NX, NU, N, REFS,
     };
     constexpr float kInf = __builtin_inff();
     if constexpr (ADP && REFS != REF_ZERO) {
-        // the terminal reference term Pinf_b' xref_{N-1} of this lane's rows, and what a unit step of rho adds to it
-        const double *sP = P.sens + NU * NX;
+        // the terminal reference term Pinf_b' xref_{N-1} of this lane's rows, and what a unit step of rho adds to it (on
+        // the VALU from the pack's row-major Pinf_0 and the table: once per launch; more products here have crashed the
+        // compiler's AGPR-copy rewrite on some horizons)
+        const double *sP = P.sens + NU * NX, *P0 = gc + S::O_P0;
 #pragma unroll
         for (int v = 0; v < VX; ++v)
             if (active && xok[v]) {
@@ -290,10 +293,10 @@ __global__ __launch_bounds__(256, (ADP ? 1 : mfma_blocks_per_cu<NX, NU, N, REFS,
                 double a0 = 0.0, a1 = 0.0;
                 for (int jj = 0; jj < NX; ++jj) {
                     const double xrj = REFS == REF_SHARED ? (double)s_ref[(N - 1) * NX + jj] : (double)P.xref[b * EX + (N - 1) * NX + jj];
-                    a0 = fma(ad[(long)(1 + NU * NX + jj + r * NX) * AB], xrj, a0);
+                    a0 = fma(P0[jj * NX + r], xrj, a0);
                     a1 = fma(sP[jj + r * NX], xrj, a1);
                 }
-                accP[v] = a0, spx[v] = a1;
+                spx[v] = a1, accP[v] = a0 + (rho_d - rho_fam) * a1;
             }
     }
 
@@ -348,22 +351,16 @@ __global__ __launch_bounds__(256, (ADP ? 1 : mfma_blocks_per_cu<NX, NU, N, REFS,
     // ADP: the instance's adaptive state as the reference leaves it (rho, Kinf, Pinf: admm.cpp:160-172 accumulated)
     auto store_adapt = [&]() {
         if constexpr (ADP) {
-            const double dr = rho_d - rho_entry;
-            if (dr != 0.0) {
-                const double *sK = P.sens, *sP = P.sens + NU * NX;
+            if (rho_d != rho_entry) {
+                const double dr = rho_d - rho_fam;
+                const double *sK = P.sens, *sP = P.sens + NU * NX, *K0 = gc + S::O_K0, *P0 = gc + S::O_P0;
 #pragma unroll
                 for (int v = 0; v < VX; ++v)
                     if (xok[v]) {
                         const int r = 4 * v + g;
 #pragma unroll
-                        for (int a = 0; a < NU; ++a) {
-                            const long e = (long)(1 + a + r * NU) * AB;
-                            ad[e] = ad[e] + dr * sK[a + r * NU];
-                        }
-                        for (int jj = 0; jj < NX; ++jj) {
-                            const long e = (long)(1 + NU * NX + jj + r * NX) * AB;
-                            ad[e] = ad[e] + dr * sP[jj + r * NX];
-                        }
+                        for (int a = 0; a < NU; ++a) ad[(long)(1 + a + r * NU) * AB] = K0[a * NX + r] + dr * sK[a + r * NU];
+                        for (int jj = 0; jj < NX; ++jj) ad[(long)(1 + NU * NX + jj + r * NX) * AB] = P0[jj * NX + r] + dr * sP[jj + r * NX];
                     }
                 if (g == 0) ad[0] = rho_d;
             }
@@ -502,28 +499,16 @@ __global__ __launch_bounds__(256, (ADP ? 1 : mfma_blocks_per_cu<NX, NU, N, REFS,
                         upmax(a_pq, px);
                         upmax(a_atym, aty);
                     }
-                    if constexpr (k == N - 1) {   // Pinf_b x + Q~ x - g of the terminal knot: Pinf_b from the solver's adaptive state
-                        float xs[VX][4];
-#pragma unroll
-                        for (int v = 0; v < VX; ++v) mf_all_gather4(a_xf[v], xs[v]);
-                        // Pinf_b = Pinf_entry + (rho_now - rho_entry) dPinf: the entry state from HBM, the table's part as a product
-                        mf_d4 spx4 = {0.0, 0.0, 0.0, 0.0};
+                    if constexpr (k == N - 1) {   // Pinf_b x + Q~ x - g of the terminal knot: Pinf_b = Pinf_0 + (rho_b - rho_family) dPinf
+                        mf_d4 p0x = {0.0, 0.0, 0.0, 0.0}, spx4 = {0.0, 0.0, 0.0, 0.0};
                         mf_for<0, VX>([&](auto ss) {
                             constexpr int s2 = decltype(ss)::value;
+                            p0x = mf_mma(cf[S::O_PT + s2], (double)a_xf[s2], p0x);
                             spx4 = mf_mma(cf[S::O_SP + s2], (double)a_xf[s2], spx4);
                         });
 #pragma unroll
                         for (int v = 0; v < VX; ++v) {
-                            double px = (rho_d - rho_entry) * spx4[v];
-                            if (active && xok[v]) {
-                                const int r = 4 * v + g;
-#pragma unroll
-                                for (int v2 = 0; v2 < VX; ++v2)
-#pragma unroll
-                                    for (int a2 = 0; a2 < 4; ++a2)
-                                        if (4 * v2 + a2 < NX)
-                                            px = fma(ad[(long)(1 + NU * NX + (4 * v2 + a2) + r * NX) * AB], (double)xs[v2][a2], px);
-                            }
+                            const double px = p0x[v] + (rho_d - rho_fam) * spx4[v];
                             const double qv = (double)qd[v] * (double)a_xf[v], aty = -(double)a_gn[v];
                             upmax(a_dres, px + qv + aty);
                             upmax(a_pxm, px);

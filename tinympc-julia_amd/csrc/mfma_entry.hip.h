@@ -50,6 +50,9 @@ void build_mfma_coef(const Solver &sv, std::vector<unsigned char> &out) {
     }
     for (int a = 0; a < NU; ++a)
         for (int r = 0; r < NX; ++r) o[S::O_K0 + a * NX + r] = c.Kinf(a, r);
+    for (int jj = 0; jj < NX; ++jj)
+        for (int r = 0; r < NX; ++r) o[S::O_P0 + jj * NX + r] = c.Pinf(jj, r);
+    o[S::O_RHO0] = c.rho;
 }
 
 template <int NX, int NU, int N>

@@ -107,6 +107,10 @@ struct Solver {
     // device; generic kernel only
     std::vector<double> sens;
     bool sens_set = false, sens_dirty = true, adapt_dirty = true;
+    // the adaptive state on the device is `family + (rho_b - rho_family) x tables` with the CURRENT tables (what every
+    // adaptive kernel leaves; false once the tables change under a live state): the matrix-core variant rebuilds an instance's
+    // Kinf / Pinf from rho_b alone
+    bool adapt_pure = true;
     double *d_sens = nullptr, *d_adapt = nullptr;
     unsigned char *d_adp_cols = nullptr;  // stream kernel, adaptive rho: per-lane coefficient columns (scratch)
     size_t adp_cols_bytes = 0;

@@ -336,6 +336,7 @@ int Solver::select_kernel(bool rollout) {
         // the matrix-core kernel's ADP variant (round 3; the quadrotor shapes — what the reference's adaptive rho is built
         // for): an instance's own Kinf as a correction to the shared products.  TINYMPC_HIP_NO_MFMA_ADP: tuning / test aid
         if (!k && !strict_fp32 && !has_fdyn && !cones_active() && !lin_active() && chunk_iters == 0 && !rollout && !cache_overridden &&
+            (adapt_pure || adapt_dirty) &&
             !genv && !std::getenv("TINYMPC_HIP_NO_MFMA") && !std::getenv("TINYMPC_HIP_NO_MFMA_ADP") && !std::getenv("TINYMPC_HIP_NO_QUAD"))
             if (const KernelEntry *m = find_mfma_kernel(nx, nu, N))
                 if (m->adp) k = m;
@@ -501,6 +502,7 @@ int Solver::set_sensitivity(const double *dK, const double *dP) {
     sens.assign((size_t)nu * nx + (size_t)nx * nx, 0.0);
     std::copy(dK, dK + (size_t)nu * nx, sens.begin());
     std::copy(dP, dP + (size_t)nx * nx, sens.begin() + (size_t)nu * nx);
+    if (d_adapt && !adapt_dirty && sens_set) adapt_pure = false;   // new tables under a live adaptive state
     sens_set = true;
     sens_dirty = true;
     packs_dirty = true;   // (the matrix-core kernel's adaptive variant carries dPinf' as an operand)
@@ -803,6 +805,7 @@ int Solver::ensure_extension_buffers() {
             HIP_TRY(hipDeviceSynchronize());
             dev_free(d_fam);
             adapt_dirty = false;
+            adapt_pure = true;
         }
         if (se) {  // stream kernel: the per-lane columns of the rows built from Kinf / Pinf (kernel-local scratch)
             const size_t G = (size_t)se->lanes, rx = (nx + G - 1) / G, ru = (nu + G - 1) / G;
