@@ -1712,3 +1712,45 @@ def test_adaptive_rho_matrix_core_variant_needs_the_state_in_closed_form(hip_lib
     bs.solve()
     assert bs.kernel_name == "mfma<12,4,20>"
     bs.close()
+
+
+@pytest.mark.parametrize("setting", ["fixed", "tol"])
+def test_adaptive_rho_one_lane_per_instance_variant(hip_lib, monkeypatch, setting):
+    """large batches of the cartpole shapes run adaptive solves on the ONE-lane-per-instance kernel (round 3): the instance's Kinf
+    as a correction dK = (rho_b - rho_family) dKinf/drho next to the family's wave-uniform coefficients, Pinf_b likewise at the
+    terminal knot.  Against the four-lanes-per-instance variant (which the compiled reference's G9c / G9d outputs pin) on the
+    same 20 517 instances, two consecutive solves (the workspace warm-starts, the adapted state persists): same iteration
+    counts, rho, the adapted Kinf / Pinf and the solutions within the fp32 tolerance."""
+    prob = t.problems.cartpole(20, u_bound=0.5)
+    B = 20517
+    kw = dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=60, check_termination=1) if setting == "fixed" else \
+        dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1)
+    x0 = t.problems.cartpole_x0(B, seed=9)
+    outs = {}
+    for which in ("g1", "g4"):
+        if which == "g4":
+            monkeypatch.setenv("TINYMPC_HIP_NO_QUAD_ADP1", "1")
+        bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+        bs.update_settings(**kw)
+        bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        bs.set_adaptive_rho(True, 0.1, 10.0, True)
+        res = []
+        xs = x0
+        for solve in range(2):
+            bs.set_x0(xs)
+            bs.solve()
+            assert bs.kernel_name == ("quad<4,1,20,g1>" if which == "g1" else "quad<4,1,20,g4>")
+            res.append((bs.get_solution(), bs.get_status(), bs.get_adaptive_state()))
+            xs = np.asfortranarray(prob.A @ xs + prob.B @ res[-1][0]["controls"][:, 0, :])
+        outs[which] = res
+        bs.close()
+    for k in range(2):
+        (sa, ta, aa), (sb, tb, ab) = outs["g1"][k], outs["g4"][k]
+        same = ta["iter"] == tb["iter"]
+        assert same.mean() >= 0.999, same.mean()
+        assert np.array_equal(ta["solved"][same], tb["solved"][same])
+        assert (np.abs(aa["rho"] - ab["rho"]) / ab["rho"])[same].max() <= 1e-5
+        assert nrel_batch(sa["controls"], sb["controls"])[same].max() <= FP32_TOL
+        assert nrel_batch(sa["states"], sb["states"])[same].max() <= FP32_TOL
+        assert nrel_batch(aa["Kinf"], ab["Kinf"])[same].max() <= FP32_TOL and nrel_batch(aa["Pinf"], ab["Pinf"])[same].max() <= FP32_TOL
+        assert np.abs(aa["rho"] - prob.rho).max() > 0.05

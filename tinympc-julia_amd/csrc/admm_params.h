@@ -75,6 +75,7 @@ struct AdmmParams {
     // ---- stream / generic kernels: adaptive rho (admm.cpp:147-174, rho_benchmark.cpp) ----
     int adaptive_rho;                    // every 5th iteration each instance re-predicts its rho and Taylor-updates Kinf, Pinf
     int rho_clip;
+    double rho_family;                   // the family's rho as a double (the adaptive state's reset value; `rho` above is a float)
     float rho_min, rho_max;
     const double *sens;                  // dKinf/drho [nu*nx] then dPinf/drho [nx*nx], column-major
     double *adapt;                       // [1 + nu*nx + nx*nx][batch]: rho, Kinf, Pinf of each instance; solver state, it

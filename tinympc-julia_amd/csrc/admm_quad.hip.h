@@ -105,7 +105,12 @@ struct QuadShape {
     static constexpr int INST_PER_BLOCK = THREADS / G;
     // adaptive rho (ADP kernels): built where a lane's coefficient rows live in its own registers — 4 lanes per instance
     // and a pack small enough for VGPRs (the cartpole shapes): the adapted Kinf / Pinf rows are then just those registers
-    static constexpr bool ADP_OK = G == 4 && CP_LIVE * 2 <= 72;
+    // ... or, with ONE lane per instance (wave-uniform coefficients), as a correction: the instance's Kinf enters as
+    // dK = Kinf_b - Kinf_family = (rho_b - rho_family) dKinf/drho (nu nx values per lane) next to the family's products, its
+    // Pinf — only needed at the terminal knot of adapting iterations — as Pinf_family + (rho_b - rho_family) dPinf/drho.
+    // Built for problems without an active state bound and with zero references (the headline workload): the state dual is
+    // then identically zero and the norm rows need neither A'g nor B'g nor a reference term.
+    static constexpr bool ADP_OK = (G == 4 && CP_LIVE * 2 <= 72) || G == 1;
     // ---- storage policy ----
     // ---- storage policy -------------------------------------------------------------------
     // Coefficient rows: VGPRs when small, LDS when their (live) register footprint would exceed
@@ -335,6 +340,8 @@ template <class S, int REFS, class RT, bool XB, bool OS, bool UNI, bool ADP = fa
 __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
     static_assert(!UNI || OS, "the uniform variant is only built for one-shot solves");
     static_assert(!ADP || (S::ADP_OK && !UNI), "adaptive rho: per-lane coefficient registers, per-lane guard");
+    static_assert(!(ADP && S::G == 1) || (!XB && REFS == REF_ZERO && sizeof(RT) == 8),
+                  "adaptive rho, one lane per instance: no active state bound, zero references, fp64 recurrences");
     constexpr int NX = S::NX, NU = S::NU, N = S::N, G = S::G;
     constexpr int RX = S::RX, RU = S::RU, NXP = S::NXP, NUP = S::NUP;
     constexpr int NXL = S::NXL, NUL = S::NUL;
@@ -426,8 +433,26 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
 #pragma unroll
     for (int m = 0; m < RX; ++m) accP[m] = (RT)0;
     // the family's Kinf^T rows: A' g = AmBKt g + Kinf0' (B' g) — the pack has no A^T block, and AmBKt stays the family's
-    RT kt0[ADP ? RX * NUP : 1];
-    if constexpr (ADP) {
+    RT kt0[(ADP && G != 1) ? RX * NUP : 1];
+    constexpr bool ADP1 = ADP && G == 1;
+    RT dK1[ADP1 ? NU : 1][ADP1 ? NX : 1];   // ADP, one lane per instance: Kinf_b - Kinf_family
+    double rho_entry = 0.0;
+    if constexpr (ADP1) {
+#pragma unroll
+        for (int a = 0; a < NU; ++a)
+#pragma unroll
+            for (int j = 0; j < NX; ++j) dK1[a][j] = (RT)0;
+        if (active) {
+            rho_d = P.adapt[b];
+            rho = (float)rho_d;
+#pragma unroll
+            for (int a = 0; a < NU; ++a)
+#pragma unroll
+                for (int j = 0; j < NX; ++j) dK1[a][j] = (RT)((rho_d - P.rho_family) * P.sens[a + j * NU]);
+        }
+        rho_entry = rho_d;
+    }
+    if constexpr (ADP && G != 1) {
 #pragma unroll
         for (int i = 0; i < RX * NUP; ++i) kt0[i] = rcoef[S::O_KT + i];
         if (active) {   // this instance's rows from the solver's adaptive state [1 + nu nx + nx nx][batch] (rho | Kinf | Pinf)
@@ -656,13 +681,15 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
                         for (int m = 0; m < RU; ++m) btg[m] = (RT)0;
 #pragma unroll
                         for (int m = 0; m < RX; ++m) atx[m] = (RT)0;
-                        quad_matvec<G, RU, NXL, RX, NXP>(btg, cBT, a_gn);          // B' g_k
-                        quad_matvec<G, RX, NXL, RX, NXP>(atx, cAT, a_gn);          // AmBKt g_k
-                        if constexpr (UREP) {
+                        if constexpr (G != 1) {   // (one lane per instance: no active state bound, g is identically zero)
+                            quad_matvec<G, RU, NXL, RX, NXP>(btg, cBT, a_gn);          // B' g_k
+                            quad_matvec<G, RX, NXL, RX, NXP>(atx, cAT, a_gn);          // AmBKt g_k
+                            if constexpr (UREP) {
 #pragma unroll
-                            for (int m = 0; m < RX; ++m) atx[m] = tfma(kt0[m * NUP], btg[0], atx[m]);   // + Kinf0' B' g_k = A' g_k
-                        } else {
-                            quad_matvec<G, RX, NUL, RU, NUP>(atx, (const RT *)kt0, btg);
+                                for (int m = 0; m < RX; ++m) atx[m] = tfma(kt0[m * NUP], btg[0], atx[m]);   // + Kinf0' B' g_k = A' g_k
+                            } else {
+                                quad_matvec<G, RX, NUL, RU, NUP>(atx, (const RT *)kt0, btg);
+                            }
                         }
 #pragma unroll
                         for (int m = 0; m < RX; ++m) {
@@ -688,7 +715,20 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
                         RT px[RX];
 #pragma unroll
                         for (int m = 0; m < RX; ++m) px[m] = (RT)0;
-                        quad_matvec<G, RX, NXL, RX, NXP>(px, cPT, a_xf);
+                        if constexpr (G == 1) {   // Pinf_b = Pinf_family + (rho_b - rho_family) dPinf/drho
+                            const SBlock<RT, S::PT_LEN / 8> pt(gcoef + S::O_PT);
+                            quad_matvec<G, RX, NXL, RX, NXP>(px, pt.at(0), a_xf);
+                            const double dr = rho_d - P.rho_family, *sP = P.sens + NU * NX;
+#pragma unroll
+                            for (int m = 0; m < RX; ++m) {
+                                RT t2 = (RT)0;
+#pragma unroll
+                                for (int j = 0; j < NX; ++j) t2 = tfma((RT)sP[j + m * NX], a_xf[j], t2);
+                                px[m] = tfma((RT)dr, t2, px[m]);
+                            }
+                        } else {
+                            quad_matvec<G, RX, NXL, RX, NXP>(px, cPT, a_xf);
+                        }
 #pragma unroll
                         for (int m = 0; m < RX; ++m) {
                             const RT qv = (RT)cQD[m] * a_xf[m], aty = (k >= 1) ? -a_gn[m] : (RT)0;
@@ -713,6 +753,10 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
 #pragma unroll
                 for (int m = 0; m < RU; ++m) {
                     if constexpr (!FOLD) u[m] = -u[m] - (RT)d_get(k, m);        // u = -Kinf x - d
+                    if constexpr (ADP1) {                                       // ... with the instance's own Kinf
+#pragma unroll
+                        for (int j = 0; j < NX; ++j) u[m] = tfma(-dK1[m][j], x[j], u[m]);
+                    }
                     const float uf = (float)u[m];
                     const float yk = y_get(k, m);
                     float zn = uf + yk;                                         // znew = u + y
@@ -824,6 +868,12 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
                         for (int m = 0; m < RX; ++m) ap[m] = qk[m];
                         quad_matvec<G, RX, NUL, RU, NUP, true>(ap, cKT, r);
                     }
+                    if constexpr (ADP1) {                                       // - dK' r: the instance's own Kinf in - Kinf' r
+#pragma unroll
+                        for (int m = 0; m < RX; ++m)
+#pragma unroll
+                            for (int a = 0; a < NU; ++a) ap[m] = tfma(-dK1[a][m], r[a], ap[m]);
+                    }
                     quad_matvec<G, RX, NXL, RX, NXP>(ap, cAT, p);
 #pragma unroll
                     for (int m = 0; m < RX; ++m) p[m] = ap[m];
@@ -917,9 +967,16 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
                     RT nrho = (RT)rho_d * (RT)sqrt((double)ratio);
                     if (P.rho_clip) nrho = nrho < (RT)P.rho_min ? (RT)P.rho_min : (nrho > (RT)P.rho_max ? (RT)P.rho_max : nrho);
                     const double delta = (double)nrho - rho_d;
+                    if constexpr (G == 1) {   // the correction moves; the solver's state is written once, in the epilogue
+#pragma unroll
+                        for (int a = 0; a < NU; ++a)
+#pragma unroll
+                            for (int j = 0; j < NX; ++j) dK1[a][j] += (RT)(delta * P.sens[a + j * NU]);
+                    }
                     const long AB = P.adapt_stride;
                     double *ad = P.adapt + b;
                     const double *sK = P.sens, *sP = P.sens + NU * NX;
+                    if constexpr (G != 1) {
 #pragma unroll
                     for (int m = 0; m < RU; ++m) {
                         const int a = UREP ? m : q * RU + m;
@@ -948,6 +1005,8 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
                         }
                     }
                     if (q == 0) ad[0] = (double)nrho;
+                    }   // G != 1
+                    (void)AB, (void)ad, (void)sK, (void)sP;
                     rho_d = (double)nrho;
                     rho = (float)nrho;
                 }
@@ -1048,6 +1107,20 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
             for (int m = 0; m < RX; ++m) {
                 const int row = q * RX + m;
                 if (row < NX) P.x0_out[b * NX + row] = (float)x0[m];
+            }
+        }
+        if constexpr (ADP1) {
+            // the adaptive state as the reference leaves it (admm.cpp:160-172 accumulated): family + (rho_b - rho_family) x tables
+            if (rho_d != rho_entry) {
+                const double dr = rho_d - P.rho_family, *sK = P.sens, *sP = P.sens + NU * NX;
+                const long AB = P.adapt_stride;
+                double *ad = P.adapt + b;
+                for (int a = 0; a < NU; ++a)
+                    for (int j = 0; j < NX; ++j) ad[(long)(1 + a + j * NU) * AB] = (double)gcoef[S::O_K + a * NXP + j] + dr * sK[a + j * NU];
+                for (int r = 0; r < NX; ++r)
+                    for (int j = 0; j < NX; ++j)
+                        ad[(long)(1 + NU * NX + j + r * NX) * AB] = (double)gcoef[S::O_PT + r * NXP + j] + dr * sP[j + r * NX];
+                ad[0] = rho_d;
             }
         }
         if (q == 0) {

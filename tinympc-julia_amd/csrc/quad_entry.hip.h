@@ -141,7 +141,22 @@ hipError_t launch_quad_adp(const AdmmParams &P, hipStream_t stream) {
 template <class S, class RT, bool XB>
 hipError_t launch_quad_rt(const AdmmParams &P, hipStream_t stream) {
     if (P.adaptive_rho) {
-        if constexpr (S::ADP_OK) {
+        if constexpr (S::G == 1) {
+            // one lane per instance: the correction form — no active state bound, zero references, fp64 recurrences (the
+            // solver selects the entry only then)
+            if constexpr (!XB && sizeof(RT) == 8) {
+                if (P.ref_mode != REF_ZERO) return hipErrorInvalidValue;
+                const int grid = (P.batch + S::INST_PER_BLOCK - 1) / S::INST_PER_BLOCK;
+                const bool oneshot = P.cold_start && !P.save_state && P.mpc_steps == 0;
+                if (oneshot)
+                    hipLaunchKernelGGL((admm_quad_kernel<S, REF_ZERO, RT, false, true, false, true>), dim3(grid), dim3(S::THREADS), 0, stream, P);
+                else
+                    hipLaunchKernelGGL((admm_quad_kernel<S, REF_ZERO, RT, false, false, false, true>), dim3(grid), dim3(S::THREADS), 0, stream, P);
+                return hipGetLastError();
+            } else {
+                return hipErrorInvalidValue;
+            }
+        } else if constexpr (S::ADP_OK) {
             const bool oneshot = P.cold_start && !P.save_state && P.mpc_steps == 0;
             return oneshot ? launch_quad_adp<S, RT, XB, true>(P, stream) : launch_quad_adp<S, RT, XB, false>(P, stream);
         } else {
