@@ -1714,18 +1714,23 @@ def test_adaptive_rho_matrix_core_variant_needs_the_state_in_closed_form(hip_lib
     bs.close()
 
 
-@pytest.mark.parametrize("setting", ["fixed", "tol"])
+@pytest.mark.parametrize("setting", ["fixed", "tol", "fixed_refs_xbounds", "tol_refs_xbounds"])
 def test_adaptive_rho_one_lane_per_instance_variant(hip_lib, monkeypatch, setting):
     """large batches of the cartpole shapes run adaptive solves on the ONE-lane-per-instance kernel (round 3): the instance's Kinf
     as a correction dK = (rho_b - rho_family) dKinf/drho next to the family's wave-uniform coefficients, Pinf_b likewise at the
-    terminal knot.  Against the four-lanes-per-instance variant (which the compiled reference's G9c / G9d outputs pin) on the
+    terminal knot and in the terminal reference term; zero or shared references, with or without finite state bounds.  Against the four-lanes-per-instance variant (which the compiled reference's G9c / G9d outputs pin) on the
     same 20 517 instances, two consecutive solves (the workspace warm-starts, the adapted state persists): same iteration
     counts, rho, the adapted Kinf / Pinf and the solutions within the fp32 tolerance."""
     prob = t.problems.cartpole(20, u_bound=0.5)
     B = 20517
-    kw = dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=60, check_termination=1) if setting == "fixed" else \
+    kw = dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=60, check_termination=1) if setting.startswith("fixed") else \
         dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1)
     x0 = t.problems.cartpole_x0(B, seed=9)
+    wide = setting.endswith("refs_xbounds")                # shared references + finite state bounds (A'g, B'g in the norm rows)
+    if wide:
+        rng = np.random.default_rng(2)
+        prob.x_min, prob.x_max = -np.array([[1.5], [3.0], [0.4], [2.5]]) * np.ones((1, prob.N)), np.array([[1.5], [3.0], [0.4], [2.5]]) * np.ones((1, prob.N))
+        xr, ur = 0.1 * rng.standard_normal((4, prob.N)), 0.05 * rng.standard_normal((1, prob.N - 1))
     outs = {}
     for which in ("g1", "g4"):
         if which == "g4":
@@ -1734,6 +1739,9 @@ def test_adaptive_rho_one_lane_per_instance_variant(hip_lib, monkeypatch, settin
         bs.update_settings(**kw)
         bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
         bs.set_adaptive_rho(True, 0.1, 10.0, True)
+        if wide:
+            bs.set_x_ref(xr)
+            bs.set_u_ref(ur)
         res = []
         xs = x0
         for solve in range(2):

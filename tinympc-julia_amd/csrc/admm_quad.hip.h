@@ -108,8 +108,9 @@ struct QuadShape {
     // ... or, with ONE lane per instance (wave-uniform coefficients), as a correction: the instance's Kinf enters as
     // dK = Kinf_b - Kinf_family = (rho_b - rho_family) dKinf/drho (nu nx values per lane) next to the family's products, its
     // Pinf — only needed at the terminal knot of adapting iterations — as Pinf_family + (rho_b - rho_family) dPinf/drho.
-    // Built for problems without an active state bound and with zero references (the headline workload): the state dual is
-    // then identically zero and the norm rows need neither A'g nor B'g nor a reference term.
+    // Zero or shared references (the terminal reference term is then (Pinf_family' + (rho_b - rho_family) dPinf') xref: two
+    // wave-uniform vectors, formed once); the norm rows' A'g, B'g read the forward block's A and B transposed — with
+    // wave-uniform coefficients any element is as near as any other.
     static constexpr bool ADP_OK = (G == 4 && CP_LIVE * 2 <= 72) || G == 1;
     // ---- storage policy ----
     // ---- storage policy -------------------------------------------------------------------
@@ -139,13 +140,13 @@ struct QuadShape {
         if (nog && a == A_G) return 0;                     // the state dual is identically zero
         return (a == A_V || a == A_W || a == A_G) ? RX * N : RU * (N - 1);
     }
-    template <class RT, int REFS, bool OS, bool NOG = false>
+    template <class RT, int REFS, bool OS, bool NOG = false, int EXTRA = 0>   // EXTRA: registers beyond the model's working set
     static constexpr Placement place() {
         Placement p{};
         const int fixed = ((coef_in_lds<RT, REFS>() || G == 1) ? 0 : coef_regs<RT, REFS>()) +  // G = 1: SGPRs
                          
                           (G == 1 ? 150 : (sizeof(RT) == 8 ? 60 : 45)) +  // working registers of a knot
-                          (REFS == REF_PER_INSTANCE ? RX * N + RU * (N - 1) : 0);
+                          (REFS == REF_PER_INSTANCE ? RX * N + RU * (N - 1) : 0) + EXTRA;
         const int total = (OS ? 2 : 3) * RX * N + (OS ? 3 : 4) * RU * (N - 1) - (NOG ? RX * N : 0);
         // (register budget, LDS floats per lane) for 2 waves/SIMD, then 1 wave/SIMD
         const int budget[2] = {250 - fixed, (sizeof(RT) == 8 ? BUD64_ : BUD32_) - fixed};
@@ -340,8 +341,8 @@ template <class S, int REFS, class RT, bool XB, bool OS, bool UNI, bool ADP = fa
 __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
     static_assert(!UNI || OS, "the uniform variant is only built for one-shot solves");
     static_assert(!ADP || (S::ADP_OK && !UNI), "adaptive rho: per-lane coefficient registers, per-lane guard");
-    static_assert(!(ADP && S::G == 1) || (!XB && REFS == REF_ZERO && sizeof(RT) == 8),
-                  "adaptive rho, one lane per instance: no active state bound, zero references, fp64 recurrences");
+    static_assert(!(ADP && S::G == 1) || (REFS != REF_PER_INSTANCE && sizeof(RT) == 8),
+                  "adaptive rho, one lane per instance: zero or shared references, fp64 recurrences");
     constexpr int NX = S::NX, NU = S::NU, N = S::N, G = S::G;
     constexpr int RX = S::RX, RU = S::RU, NXP = S::NXP, NUP = S::NUP;
     constexpr int NXL = S::NXL, NUL = S::NUL;
@@ -451,6 +452,22 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
                 for (int j = 0; j < NX; ++j) dK1[a][j] = (RT)((rho_d - P.rho_family) * P.sens[a + j * NU]);
         }
         rho_entry = rho_d;
+    }
+    // ADP, one lane per instance, shared references: Pinf_family' xref_{N-1} and dPinf' xref_{N-1} (wave-uniform)
+    RT accA0[(ADP1 && REFS == REF_SHARED) ? NX : 1], accA1[(ADP1 && REFS == REF_SHARED) ? NX : 1];
+    if constexpr (ADP1 && REFS == REF_SHARED) {
+        const double *sP = P.sens + NU * NX;
+#pragma unroll
+        for (int m = 0; m < NX; ++m) {
+            RT a0 = (RT)0, a1 = (RT)0;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                const RT xrj = (RT)lr[(N - 1) * G * S::RW + j];
+                a0 = tfma((RT)gcoef[S::O_PT + m * NXP + j], xrj, a0);
+                a1 = tfma((RT)sP[j + m * NX], xrj, a1);
+            }
+            accA0[m] = a0, accA1[m] = a1;
+        }
     }
     if constexpr (ADP && G != 1) {
 #pragma unroll
@@ -681,7 +698,16 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
                         for (int m = 0; m < RU; ++m) btg[m] = (RT)0;
 #pragma unroll
                         for (int m = 0; m < RX; ++m) atx[m] = (RT)0;
-                        if constexpr (G != 1) {   // (one lane per instance: no active state bound, g is identically zero)
+                        if constexpr (G == 1 && XB) {   // one lane per instance: A, B of the forward block, read transposed
+#pragma unroll
+                            for (int j = 0; j < NX; ++j) {
+#pragma unroll
+                                for (int m = 0; m < RX; ++m) atx[m] = tfma((RT)cA[j * NXP + m], a_gn[j], atx[m]);
+#pragma unroll
+                                for (int a = 0; a < RU; ++a) btg[a] = tfma((RT)cB[j * NUP + a], a_gn[j], btg[a]);
+                            }
+                        }
+                        if constexpr (G != 1) {   // (one lane per instance without an active state bound: g is identically zero)
                             quad_matvec<G, RU, NXL, RX, NXP>(btg, cBT, a_gn);          // B' g_k
                             quad_matvec<G, RX, NXL, RX, NXP>(atx, cAT, a_gn);          // AmBKt g_k
                             if constexpr (UREP) {
@@ -935,7 +961,12 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
             if constexpr (ADP) {
                 adapt_now = i > 0 && i % 5 == 0;                                // admm.cpp:147 (loop index, before it is bumped)
                 a_pri = a_axm = a_zm = a_dres = a_pxm = a_atym = a_qm = (RT)0;
-                if constexpr (REFS != REF_ZERO) {                               // the terminal cost with the Pinf of this iteration's linear cost
+                if constexpr (ADP1 && REFS == REF_SHARED) {
+                    const RT dr = (RT)(rho_d - P.rho_family);
+#pragma unroll
+                    for (int m = 0; m < RX; ++m) accP[m] = tfma(dr, accA1[m], accA0[m]);
+                }
+                if constexpr (REFS != REF_ZERO && G != 1) {                     // the terminal cost with the Pinf of this iteration's linear cost
                     RT xrl[RX];
 #pragma unroll
                     for (int m = 0; m < RX; ++m) {

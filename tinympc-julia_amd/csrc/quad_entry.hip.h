@@ -142,16 +142,20 @@ template <class S, class RT, bool XB>
 hipError_t launch_quad_rt(const AdmmParams &P, hipStream_t stream) {
     if (P.adaptive_rho) {
         if constexpr (S::G == 1) {
-            // one lane per instance: the correction form — no active state bound, zero references, fp64 recurrences (the
-            // solver selects the entry only then)
-            if constexpr (!XB && sizeof(RT) == 8) {
-                if (P.ref_mode != REF_ZERO) return hipErrorInvalidValue;
+            // one lane per instance: the correction form — zero or shared references, fp64 recurrences (the solver selects
+            // the entry only then)
+            if constexpr (sizeof(RT) == 8) {
+                if (P.ref_mode == REF_PER_INSTANCE) return hipErrorInvalidValue;
                 const int grid = (P.batch + S::INST_PER_BLOCK - 1) / S::INST_PER_BLOCK;
                 const bool oneshot = P.cold_start && !P.save_state && P.mpc_steps == 0;
-                if (oneshot)
-                    hipLaunchKernelGGL((admm_quad_kernel<S, REF_ZERO, RT, false, true, false, true>), dim3(grid), dim3(S::THREADS), 0, stream, P);
-                else
-                    hipLaunchKernelGGL((admm_quad_kernel<S, REF_ZERO, RT, false, false, false, true>), dim3(grid), dim3(S::THREADS), 0, stream, P);
+#define TMPC_QUAD_ADP1(REFS_, OS_) \
+    hipLaunchKernelGGL((admm_quad_kernel<S, REFS_, RT, XB, OS_, false, true>), dim3(grid), dim3(S::THREADS), 0, stream, P)
+                if (P.ref_mode == REF_ZERO) {
+                    if (oneshot) TMPC_QUAD_ADP1(REF_ZERO, true); else TMPC_QUAD_ADP1(REF_ZERO, false);
+                } else {
+                    if (oneshot) TMPC_QUAD_ADP1(REF_SHARED, true); else TMPC_QUAD_ADP1(REF_SHARED, false);
+                }
+#undef TMPC_QUAD_ADP1
                 return hipGetLastError();
             } else {
                 return hipErrorInvalidValue;

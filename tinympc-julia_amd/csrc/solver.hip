@@ -334,16 +334,12 @@ int Solver::select_kernel(bool rollout) {
                                  !rollout && !cache_overridden;
         k = quad_adp_ok ? ka : nullptr;
         // ... with ONE lane per instance — the benched variant of large batches — in the correction form (admm_quad.hip.h:
-        // dK = (rho_b - rho_family) dKinf/drho next to the family's wave-uniform coefficients): problems without a finite
-        // state bound and with zero references, fp64 recurrences, the adaptive state in closed form.
-        // TINYMPC_HIP_NO_QUAD_ADP1: tuning / test aid
-        if (quad_adp_ok && batch >= 20480 && precision == 0 && !genv && !refs_device_owned && xref_kind == 0 && uref_kind == 0 &&
+        // dK = (rho_b - rho_family) dKinf/drho next to the family's wave-uniform coefficients): zero or shared references,
+        // fp64 recurrences, the adaptive state in closed form.  TINYMPC_HIP_NO_QUAD_ADP1: tuning / test aid
+        if (quad_adp_ok && batch >= 20480 && precision == 0 && !genv && !refs_device_owned && xref_kind <= 1 && uref_kind <= 1 &&
             (adapt_pure || adapt_dirty) && !std::getenv("TINYMPC_HIP_NO_QUAD_ADP1")) {
-            bool xb = false;
-            if (st.en_state_bound)
-                for (size_t i = 0; i < x_min.size() && !xb; ++i) xb = x_min[i] > -1e17 || x_max[i] < 1e17;
             const KernelEntry *k1 = find_quad_kernel(nx, nu, N, 1);
-            if (!xb && !g_maybe_nonzero && k1 && k1->adp) k = k1;
+            if (k1 && k1->adp) k = k1;
         }
         // the matrix-core kernel's ADP variant (round 3; the quadrotor shapes — what the reference's adaptive rho is built
         // for): an instance's own Kinf as a correction to the shared products.  TINYMPC_HIP_NO_MFMA_ADP: tuning / test aid
