@@ -24,6 +24,8 @@
 #ifndef TINYMPC_HIP_H
 #define TINYMPC_HIP_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -61,6 +63,10 @@ void cleanup_solver(void);
 int set_x0_f32(float *x0_data, int x0_rows, int x0_cols, int verbose);
 int get_states_f32(float *states_buffer, int *rows, int *cols);
 int get_controls_f32(float *controls_buffer, int *rows, int *cols);
+/* Page-lock / release a caller-owned host array that is reused with the fp32 forms above (direct DMA instead of a bounce
+ * through pageable memory).  The library never registers caller memory on its own; unpin before the array is freed. */
+int pin_host_buffer(void *ptr, size_t bytes);
+int unpin_host_buffer(void *ptr);
 /* replaces bindings.cpp:336-376.  en_*_soc / en_*_linear switch the sets given to set_cone_constraints /
  * set_linear_constraints on and off (parity unpinned).  adaptive_rho != 0 turns on the per-instance rho adaptation of
  * admm.cpp:147-174 (see tinympc_set_adaptive_rho; runs on the generic kernel).  check_termination <= 0 means "never check"
@@ -209,6 +215,16 @@ int tinympc_set_ref_mode(tinympc_solver *s, int ref_mode);
 int tinympc_solve_async(tinympc_solver *s, void *hip_stream);
 /* After the stream has been synchronised: 0 all converged / 1 otherwise (reads gstat). */
 int tinympc_solve_status(tinympc_solver *s);
+/* fp32 host buffers (plain copies to / from the fp32 device buffers, no conversion pass): x0 nx x 1 or nx x batch;
+ * states nx*N*batch, controls nu*(N-1)*batch floats, instance-major as the fp64 forms.  The library never page-locks
+ * memory it does not own: a caller that reuses its buffers and wants direct DMA into them registers them itself with
+ * tinympc_pin_host and removes the registration with tinympc_unpin_host BEFORE freeing the memory (whatever is still
+ * registered at tinympc_destroy is unregistered there). */
+int tinympc_set_x0_f32(tinympc_solver *s, const float *x0, int cols);
+int tinympc_get_states_f32(tinympc_solver *s, float *buf);
+int tinympc_get_controls_f32(tinympc_solver *s, float *buf);
+int tinympc_pin_host(tinympc_solver *s, void *ptr, size_t bytes);
+int tinympc_unpin_host(tinympc_solver *s, void *ptr);
 /* Fused closed loop (the caller pattern of examples/cartpole_example_mpc.jl:35-51):
  * `steps` repetitions of  solve -> u0 = controls[:,0] -> x0 = A x0 + B u0 -> set_x0  in ONE launch,
  * the warm-start workspace staying on chip between steps.  Needs warm-start mode and a specialised
@@ -217,19 +233,14 @@ int tinympc_solve_status(tinympc_solver *s);
  * describe the last solve.  Logs, instance-major: x [batch][steps][nx] (plant state after each
  * step), u [batch][steps][nu] (control applied), iter [batch][steps] (ADMM iterations of the step,
  * negated when the step hit max_iter).  Any log pointer may be NULL. */
-/* fp32 host buffers (plain copies to / from the fp32 device buffers, no conversion pass): x0 nx x 1 or nx x batch;
- * states nx*N*batch, controls nu*(N-1)*batch floats, instance-major as the fp64 forms. */
-int tinympc_set_x0_f32(tinympc_solver *s, const float *x0, int cols);
-int tinympc_get_states_f32(tinympc_solver *s, float *buf);
-int tinympc_get_controls_f32(tinympc_solver *s, float *buf);
 int tinympc_mpc_rollout(tinympc_solver *s, int steps, void *hip_stream);
 int tinympc_get_mpc_log(tinympc_solver *s, double *x, double *u, int *iter);
 /* Shared references of EVERY step of the next closed loops — the caller pattern of
  * examples/rocket_landing_constraints.jl:97-134, which shifts x_ref by one knot per step (:107-115) before each solve:
  * x_ref_seq is nx x (N*steps), u_ref_seq nu x ((N-1)*steps), column-major, step after step (what `steps` calls of
  * set_x_ref / set_u_ref would have passed).  The plant step of such a loop includes the affine term,
- * x0 = A x0 + B u0 + f (:123).  Step 0's references become the solver's own; a later set_x_ref / set_u_ref or
- * steps = 0 drops the sequence.  Needs the transposed-sets kernel (mfmat) for the shape. */
+ * x0 = A x0 + B u0 + f (:123).  Step 0's references become the solver's own shared references and stay installed when
+ * the sequence is dropped (by a later set_x_ref / set_u_ref, which replaces them, or by steps = 0, which does not).  Needs the transposed-sets kernel (mfmat) for the shape. */
 int tinympc_set_ref_sequence(tinympc_solver *s, const double *x_ref_seq, int x_rows, int x_cols, const double *u_ref_seq,
                              int u_rows, int u_cols, int steps);
 /* Tolerance-terminated solves of big batches: with chunk_iters > 0 (rounded up to a multiple of check_termination)
@@ -248,8 +259,13 @@ double tinympc_kernel_elapsed_mean_ms(tinympc_solver *s, int last_n);
 /* Arithmetic of the two serial recurrences (rollout, Riccati gradient): 0 = fp64 accumulation
  * with fp64 coefficients (default; ADMM state and elementwise steps stay fp32), 1 = all fp32. */
 int tinympc_set_precision(tinympc_solver *s, int precision);
-/* Name of the kernel path that the last solve used: "quad<nx,nu,N>" or "generic". */
+/* Name of the kernel family the solver's shape / options select: "quad<nx,nu,N,gG>", "mfma<...>", "mfmat<...>",
+ * "stream4<nx,nu>", "generic", ... */
 const char *tinympc_kernel_name(tinympc_solver *s);
+/* Name of the kernel the most recent launch actually ran: the family above, or the variant a launch of that family took
+ * for its calling pattern — "lean<nx,nu,N>" for one-shot solves (cold start, workspace not kept) of a one-lane-per-instance
+ * quad entry without an active state bound, zero references, fp64 recurrences (admm_lean.hip.h). */
+const char *tinympc_last_launch_name(tinympc_solver *s);
 /* Algorithmic HBM bytes and FLOPs of one solve of the whole batch (SURVEY.md 8d formulas);
  * flops assume `iters` ADMM iterations per instance. */
 double tinympc_algorithmic_bytes(tinympc_solver *s);

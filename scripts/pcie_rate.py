@@ -21,10 +21,11 @@ t0 = time.perf_counter(); n = 10
 for _ in range(n): once()
 dt = (time.perf_counter() - t0) / n
 print(f"PCIe-inclusive (fp64 host buffers in/out through the C-ABI): {dt*1e3:.2f} ms per 65536-solve batch = {B/dt:.3e} solves/s")
-# the same round trip through the fp32 entry points (Float32 host arrays: plain copies, buffers page-locked on first use)
+# the same round trip through the fp32 entry points (Float32 host arrays: plain copies into buffers the caller page-locked with pin_host)
 x0f = np.asfortranarray(x0.astype(np.float32))
 xsf, usf = np.zeros(4 * 20 * B, dtype=np.float32), np.zeros(19 * B, dtype=np.float32)
 fp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+for a in (x0f, xsf, usf): bs.pin_host(a)
 def once32():
     bs.lib.tinympc_set_x0_f32(bs.h, fp(x0f), B)
     bs.lib.tinympc_solve(bs.h)

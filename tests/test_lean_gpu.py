@@ -1,0 +1,187 @@
+"""The lean kernel (csrc/admm_lean.hip.h, "lean<4,1,N>") — what BASELINE config 2 (the headline) runs on since round 4:
+one-shot solves (cold start, workspace not kept) of the one-lane-per-instance cartpole entries without an active state
+bound, zero references, fp64 recurrences.
+ * every instance against the fp64 oracle, fixed-iteration and tolerance-terminated (per-instance exits, check intervals),
+   iteration counts / status / residuals included;
+ * against the quad kernel it replaces for this calling pattern (TINYMPC_HIP_NO_LEAN keeps a solver there);
+ * per-knot input bounds (the bounds then come from LDS knot by knot);
+ * every calling pattern outside its scope stays on the quad kernel: finite state bounds, references, warm starts /
+   kept workspace, fp32 recurrences, adaptive rho, a cache whose AmBKt is not (A - B Kinf)'.
+Reference arithmetic: src/codegen_src/tinympc/admm.cpp:13-107, solve() :109-207."""
+import os
+
+import numpy as np
+import pytest
+
+import tinympc_julia_amd as t
+from tests.util import FP32_TOL, nrel_batch, parity_every_instance
+
+pytestmark = pytest.mark.gpu
+
+B_G1 = 24576          # one lane per instance from 20 480 instances up (select_quad_kernel)
+
+
+def _oracle_make(oracle_built, prob, kw):
+    def make(b=None):
+        o = oracle_built.CpuSolver("orc64", prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N)
+        o.update_settings(**kw)
+        o.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        return o
+    return make
+
+
+def _solver(prob, B, kw, warm=False):
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+    bs.update_settings(**kw)
+    bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    bs.set_warm_start(warm)
+    return bs
+
+
+@pytest.mark.parametrize("kw", [
+    dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=100, check_termination=1),      # the benchmark's setting
+    dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=47, check_termination=10),      # last check at 40, seven more iterations
+    dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=1, check_termination=1),
+    dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=30, check_termination=0),     # never check (the reference divides by it)
+    dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1),    # per-instance exits
+    dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=95, check_termination=10),
+    dict(abs_pri_tol=1e-4, abs_dua_tol=1e-4, max_iter=100, check_termination=3),
+], ids=["fixed100", "fixed47_ct10", "one_iter", "nocheck", "tol_ct1", "tol_ct10", "tol1e-4_ct3"])
+def test_lean_vs_oracle_every_instance(hip_lib, oracle_built, kw):
+    prob, x0 = t.problems.cartpole(20, u_bound=0.5), t.problems.cartpole_x0(B_G1, seed=11)
+    ref = oracle_built.solve_batch("orc64", prob, x0, nthreads=len(os.sched_getaffinity(0)), **kw)
+    bs = _solver(prob, B_G1, kw)
+    bs.set_x0(x0)
+    status = bs.solve()
+    assert bs.kernel_name == "quad<4,1,20,g1>" and bs.last_launch_name == "lean<4,1,20>"
+    sol, st = bs.get_solution(), bs.get_status()
+    assert status == int(np.any(st["solved"] == 0))
+    same = parity_every_instance(sol, st, ref, _oracle_make(oracle_built, prob, kw), x0, kw, prob.rho, min_same=0.97, tag="lean")
+    eq = st["iter"] == ref["iter"]
+    # residuals as the reference reports them (types.hpp:128-131): the last check's values
+    assert np.allclose(st["residuals"][eq], ref["res"][eq], rtol=2e-3, atol=2e-6)
+    if kw["abs_pri_tol"] > 0 and kw["check_termination"] > 0:
+        assert len(np.unique(st["iter"])) > 3 and same >= 0.97
+    else:
+        assert np.all(st["iter"] == kw["max_iter"]) and not st["solved"].any()
+    bs.close()
+
+
+def test_lean_against_the_quad_kernel(hip_lib, monkeypatch):
+    """the kernel this calling pattern ran on until round 3: same iterates to fp32 rounding of the stored state, same
+    iteration counts wherever the residuals are not within rounding of the tolerance"""
+    prob, x0 = t.problems.cartpole(20, u_bound=0.5), t.problems.cartpole_x0(B_G1, seed=12)
+    out = {}
+    for which in ("lean", "quad"):
+        if which == "quad":
+            monkeypatch.setenv("TINYMPC_HIP_NO_LEAN", "1")
+        for tag, kw in (("fixed", dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=100, check_termination=1)),
+                        ("tol", dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1))):
+            bs = _solver(prob, B_G1, kw)
+            bs.set_x0(x0)
+            bs.solve()
+            assert bs.last_launch_name == ("lean<4,1,20>" if which == "lean" else "quad<4,1,20,g1>")
+            out[which, tag] = (bs.get_solution(), bs.get_status())
+            bs.close()
+    monkeypatch.delenv("TINYMPC_HIP_NO_LEAN")
+    for tag in ("fixed", "tol"):
+        (sl, tl), (sq, tq) = out["lean", tag], out["quad", tag]
+        eq = tl["iter"] == tq["iter"]
+        assert eq.mean() >= (1.0 if tag == "fixed" else 0.995)
+        ex = nrel_batch(sl["states"][:, :, eq], sq["states"][:, :, eq])
+        eu = nrel_batch(sl["controls"][:, :, eq], sq["controls"][:, :, eq])
+        assert ex.max() <= 4e-6 and eu.max() <= 4e-6, (tag, ex.max(), eu.max())
+        assert np.array_equal(tl["solved"][eq], tq["solved"][eq])
+
+
+def test_lean_per_knot_input_bounds(hip_lib, oracle_built):
+    """u_min / u_max differ from knot to knot (set_bound_constraints takes nu x (N-1) matrices, bindings.cpp:378-411)"""
+    prob, x0 = t.problems.cartpole(20, u_bound=0.5), t.problems.cartpole_x0(B_G1, seed=13)
+    rng = np.random.default_rng(5)
+    prob.u_max = np.asfortranarray(0.2 + 0.5 * rng.random((1, 19)))
+    prob.u_min = np.asfortranarray(-(0.2 + 0.5 * rng.random((1, 19))))
+    for kw in (dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=60, check_termination=1),
+               dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=2)):
+        ref = oracle_built.solve_batch("orc64", prob, x0, nthreads=len(os.sched_getaffinity(0)), **kw)
+        bs = _solver(prob, B_G1, kw)
+        bs.set_x0(x0)
+        bs.solve()
+        assert bs.last_launch_name == "lean<4,1,20>"
+        sol, st = bs.get_solution(), bs.get_status()
+        parity_every_instance(sol, st, ref, _oracle_make(oracle_built, prob, kw), x0, kw, prob.rho, min_same=0.97, tag="lean knot bounds")
+        assert (sol["controls"] <= prob.u_max[:, :, None] + 1e-6).all() and (sol["controls"] >= prob.u_min[:, :, None] - 1e-6).all()
+        bs.close()
+
+
+def test_lean_unbounded_inputs_and_ragged_batch(hip_lib, oracle_built):
+    """input bounds disabled (the clamp sees -inf / +inf); a batch that does not fill its last workgroup"""
+    B = 20480 + 77
+    prob, x0 = t.problems.cartpole(20), t.problems.cartpole_x0(B, seed=14)
+    kw = dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=25, check_termination=1)
+    ref = oracle_built.solve_batch("orc64", prob, x0, nthreads=len(os.sched_getaffinity(0)), **kw)
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+    bs.update_settings(**kw)
+    bs.set_warm_start(False)
+    bs.set_x0(x0)
+    bs.solve()
+    assert bs.last_launch_name == "lean<4,1,20>"
+    sol = bs.get_solution()
+    assert nrel_batch(sol["states"], ref["x"]).max() <= FP32_TOL and nrel_batch(sol["controls"], ref["u"]).max() <= FP32_TOL
+    bs.close()
+
+
+def test_lean_scope(hip_lib):
+    """what the lean kernel does not take stays on the quad kernel (and a solver goes back and forth between the two)"""
+    prob, x0 = t.problems.cartpole(20, u_bound=0.5), t.problems.cartpole_x0(B_G1, seed=15)
+    kw = dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=10, check_termination=1)
+    bs = _solver(prob, B_G1, kw)
+    bs.set_x0(x0)
+    bs.solve()
+    assert bs.last_launch_name == "lean<4,1,20>"
+    base = bs.get_solution()
+    # kept workspace (the reference's default calling pattern)
+    bs.set_warm_start(True)
+    bs.reset()
+    bs.solve()
+    assert bs.last_launch_name == "quad<4,1,20,g1>"
+    warm = bs.get_solution()
+    assert nrel_batch(warm["controls"], base["controls"]).max() <= 4e-6
+    bs.set_warm_start(False)
+    # shared references
+    xr = np.zeros((4, 20), order="F"); xr[0] = 0.1
+    bs.set_x_ref(xr)
+    bs.solve()
+    assert bs.last_launch_name == "quad<4,1,20,g1>"
+    bs.set_x_ref(np.zeros((4, 20), order="F"))
+    bs.solve()
+    assert bs.last_launch_name == "lean<4,1,20>"
+    # a finite state bound
+    xmax = prob.x_max.copy(); xmax[0, :] = 0.4
+    bs.set_bound_constraints(prob.x_min, xmax, prob.u_min, prob.u_max)
+    bs.solve()
+    assert bs.last_launch_name == "quad<4,1,20,g1>"
+    bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    # fp32 recurrences
+    bs.set_precision(1)
+    bs.solve()
+    assert bs.last_launch_name == "quad<4,1,20,g1>"
+    bs.set_precision(0)
+    bs.solve()
+    assert bs.last_launch_name == "lean<4,1,20>"
+    again = bs.get_solution()
+    assert np.array_equal(again["controls"], base["controls"]) and np.array_equal(again["states"], base["states"])
+    # a cache whose AmBKt is no longer (A - B Kinf)': the two sweeps cannot share one matrix
+    c = bs.get_cache_terms()
+    bs.set_cache_terms(c["Kinf"], c["Pinf"], c["Quu_inv"], c["AmBKt"] * (1.0 + 1e-6))
+    bs.solve()
+    assert bs.last_launch_name == "quad<4,1,20,g1>"
+    bs.set_cache_terms(c["Kinf"], c["Pinf"], c["Quu_inv"], c["AmBKt"])
+    bs.solve()
+    assert bs.last_launch_name == "lean<4,1,20>"
+    bs.close()
+    # small batches use four lanes per instance: no lean variant there
+    b4 = _solver(prob, 512, kw)
+    b4.set_x0(x0[:, :512])
+    b4.solve()
+    assert b4.last_launch_name == "quad<4,1,20,g4>"
+    b4.close()

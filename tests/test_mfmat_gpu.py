@@ -282,6 +282,42 @@ def test_mfmat_fused_rocket_loop_vs_oracle(hip_lib, oracle_built, shifted):
     bs.close(); bs2.close()
 
 
+def test_mfmat_fused_loop_shifted_refs_many_tiles(hip_lib, oracle_built):
+    """A persistent workgroup that takes a SECOND tile must solve that tile's step 0 against step 0's references, not the
+    ones the previous tile's last step left in LDS (round-3 advisor finding).  A batch far beyond what the launch has
+    workgroups for, identical x0 everywhere: every instance must be bit-equal to instance 0, and instance 0 must be the
+    oracle's loop (rocket_landing_constraints.jl:97-134)."""
+    N, B, steps = 10, 49152, 6            # 3 072 tiles; a launch holds at most 256 CUs x 8 workgroups
+    prob = t.problems.rocket(N)
+    x1 = t.problems.rocket_x0(1, seed=5)
+    x0 = np.repeat(x1, B, axis=1)
+    kw = dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=12, check_termination=1)
+    xs, us = _rocket_ref_sequence(N, steps)
+    bs = _solver(prob, B, kw, xs[:, :, 0], us[:, :, 0], prob.fdyn, ROCKET_CONES, True)
+    bs.set_ref_sequence(xs, us)
+    bs.set_x0(x0)
+    log = bs.mpc_rollout(steps)
+    assert bs.kernel_name == "mfmat<6,3,10>"
+    for key in ("u", "x"):
+        assert np.array_equal(log[key], np.repeat(log[key][:, :, :1], B, axis=2)), f"{key}: instances differ between tiles"
+    o = _configure(oracle_built.CpuSolver("orc64", prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N), prob, kw, xs[:, :, 0],
+                   us[:, :, 0], prob.fdyn, ROCKET_CONES)
+    x = x1[:, 0].copy()
+    ref_u, ref_x = np.zeros((3, steps)), np.zeros((6, steps))
+    for k in range(steps):
+        o.set_x0(x)
+        o.set_x_ref(xs[:, :, k])
+        o.set_u_ref(us[:, :, k])
+        o.solve()
+        u0 = o.get_solution()["u"][:, 0]
+        x = prob.A @ x + prob.B @ u0 + prob.fdyn
+        ref_u[:, k], ref_x[:, k] = u0, x
+    o.close()
+    assert np.abs(log["u"][:, :, 0] - ref_u).max() <= FP32_TOL * np.abs(ref_u).max()
+    assert np.abs(log["x"][:, :, -1] - ref_x).max() <= FP32_TOL * np.abs(ref_x).max()
+    bs.close()
+
+
 def test_mfmat_chunked_solve_with_compaction(hip_lib):
     """tolerance-terminated solve in chunks with the unconverged instances gathered between them (tinympc_set_compaction):
     the workspace carries every instance from chunk to chunk, so the result is the single launch's"""
@@ -436,7 +472,16 @@ def test_fp32_host_entry_points(hip_lib):
     one = bs.get_solution_f32()
     assert np.array_equal(one["controls"][:, :, 0], one["controls"][:, :, B - 1])
     assert np.array_equal(one["controls"][:, :, 0].astype(np.float64), ref["controls"][:, :, 5])
-    bs.close()
+    # caller-controlled page-locking (the library pins nothing by itself: round-3 advisor finding): pinned buffers carry the
+    # same bits, a second pin of the same range is a no-op, unpinning an unknown address is an error
+    keep_x, keep_u = np.zeros((4, 20, B), dtype=np.float32, order="F"), np.zeros((1, 19, B), dtype=np.float32, order="F")
+    bs.pin_host(keep_x); bs.pin_host(keep_u); bs.pin_host(keep_x)
+    again = bs.get_solution_f32(keep_x, keep_u)
+    assert again["states"] is keep_x and np.array_equal(keep_x, one["states"]) and np.array_equal(keep_u, one["controls"])
+    bs.unpin_host(keep_x)
+    with pytest.raises(t.TinyMPCError):
+        bs.unpin_host(keep_x)
+    bs.close()                                             # (keep_u is still registered: destroy releases it)
     # the process-global forms a Julia host binds
     lib = hip_lib
     s = t.TinyMPCSolver()
@@ -452,6 +497,11 @@ def test_fp32_host_entry_points(hip_lib):
     assert lib.get_controls_f32(fp(us), ctypes.byref(r), ctypes.byref(c)) == 0 and (r.value, c.value) == (1, 19 * B)
     assert np.array_equal(us.reshape((1, 19, B), order="F").astype(np.float64), ref["controls"])
     assert lib.set_x0_f32(fp(x32), 3, B, 0) == -1
+    assert lib.pin_host_buffer(xs.ctypes.data_as(ctypes.c_void_p), xs.nbytes) == 0
+    assert lib.get_states_f32(fp(xs), ctypes.byref(r), ctypes.byref(c)) == 0
+    assert np.array_equal(xs.reshape((4, 20, B), order="F").astype(np.float64), ref["states"])
+    assert lib.unpin_host_buffer(xs.ctypes.data_as(ctypes.c_void_p)) == 0
+    assert lib.unpin_host_buffer(xs.ctypes.data_as(ctypes.c_void_p)) == -1
     t.cleanup()
 
 

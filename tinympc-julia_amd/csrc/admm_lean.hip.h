@@ -1,0 +1,293 @@
+// Fused TinyMPC ADMM kernel for gfx950 — "lean" layout: the benchmark's calling pattern of the small shapes with as few
+// vector instructions per ADMM iteration as the arithmetic allows.
+//
+// What it computes: the reference's solve() loop (src/codegen_src/tinympc/admm.cpp:109-207; phases :13-107) for one-shot
+// solves — cold start (the zero workspace tiny_setup leaves, tiny_api.cpp:73-88), nothing of the workspace kept — of a
+// box-constrained family with NO active state bound, zero (or shared) references, fp64 recurrences.  One lane per
+// instance, like quad<..., g1> (admm_quad.hip.h), which stays the kernel of every other calling pattern of the shape.
+//
+// Why a separate kernel (round 3 review, item 1): quad<4,1,20,g1> executed 1 506 vector instructions per iteration, of
+// which 911 were the recurrences' fp64 FMAs; 268 were v_accvgpr moves (its state homed in AGPRs and copied through VGPRs
+// every iteration) and 228 fp32 <-> fp64 conversions.  A lone wavefront issues one vector instruction per 4 cycles
+// whatever its type (MI355X_MICROARCH.md, "vector-instruction ISSUE cost"), so the instruction count IS the time.  Here:
+//   * without an active state bound the state slack is the rollout itself (vnew = x + g clamps nothing, so g stays 0 and
+//     vnew = x: admm.cpp:46-58, :67-68) — the trajectory x is kept in fp64 registers and IS v: no x -> fp32 -> fp64 round
+//     trip between the forward and the backward sweep (8 conversions per knot), and v is MORE accurate than the fp32 copy;
+//   * the whole iterated state — x (fp64), y, znew, d (fp32): 2 nx N + 3 nu (N-1) registers = 217 for cartpole N = 20 —
+//     plus the working set of a knot fits the 256 architectural VGPRs: no AGPR homes, no moves, and the kernel may run two
+//     wavefronts per SIMD when the batch has them (__launch_bounds__(256, 2));
+//   * the backward recursion runs on p~ = -p / rho, r~ = -r / rho: with zero references q = -rho x, r = -rho (z - y)
+//     (admm.cpp:77-80), so p~_k = x_k + AmBKt p~_{k+1} - Kinf' r~_k starts from the x register itself and the products by
+//     rho disappear; d_k = (-rho Quu_inv) (B' p~_{k+1} + r~_k) (admm.cpp:17-18);
+//   * the rollout is regrouped as x+ = (A - B Kinf) x - B d, u = -Kinf x - d (admm.cpp:29-30; fp64, results move by
+//     ~1e-16): x+ does not wait for u, and (A - B Kinf) is the transpose of the AmBKt the backward sweep reads, so ONE set
+//     of 25 fp64 coefficients (50 SGPRs) serves both sweeps and stays resident for the whole solve — no per-sweep scalar
+//     reloads.  (The host only selects this kernel when cache.AmBKt equals (A - B Kinf)' — set_cache_terms may break that.)
+// Termination (admm.cpp:89-107) as in the quad kernel: residual maxima only on the iterations whose check can matter; with
+// positive tolerances (LIVE) an instance that converges stores its solution at that iteration and its lane idles on
+// (what the matrix-core kernels do), the wavefront leaves when all its instances are done.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "admm_params.h"
+#include "admm_quad.hip.h"   // SBlock, sfor
+
+#ifndef TMPC_LEAN_WAVES
+#define TMPC_LEAN_WAVES 2     // wavefronts per SIMD the register budget is held to (256 VGPRs, no AGPRs)
+#endif
+#ifndef TMPC_LEAN_KNOT_BARRIER
+#define TMPC_LEAN_KNOT_BARRIER 0   // 1: a scheduling barrier per knot (keeps the scheduler from hoisting a later knot's loads / conversions)
+#endif
+#ifndef TMPC_LEAN_D64
+#define TMPC_LEAN_D64 0       // 1: the feed-forward term d kept in fp64 (nu (N-1) more registers, two conversions per knot fewer)
+#endif
+#ifndef TMPC_LEAN_SPLITK
+#define TMPC_LEAN_SPLITK 0    // 1: Kinf x as two chains of two (+ an add): shorter dependent chain, one more instruction
+#endif
+
+namespace tmpc {
+
+template <int NX, int NU>
+struct LeanPack {
+    static constexpr LeanLayout LL = lean_layout(NX, NU);
+    static constexpr int O_M = LL.oM, O_K = LL.oK, O_B = LL.oB, O_C = LL.oC, LEN = LL.len;
+    static constexpr int NLOADS = LL.padded / 8;     // s_load_dwordx16 per 8 doubles
+};
+
+// clamp(t, lo, hi) as one v_med3_f32 (lo <= hi; +-inf for "no bound")
+__device__ __forceinline__ float clamp3(float t, float lo, float hi) { return __builtin_amdgcn_fmed3f(t, lo, hi); }
+
+template <int NX, int NU, int N, bool LIVE, bool UBK>
+__global__ __launch_bounds__(256, TMPC_LEAN_WAVES) void admm_lean_kernel(const AdmmParams P) {
+    using L = LeanPack<NX, NU>;
+    constexpr int EX = NX * N, EU = NU * (N - 1);
+    constexpr int BW = 2 * NX + 2 * NU;              // the quad kernel's bounds pack, one lane per instance: [N][xmin xmax umin umax]
+    static_assert(L::NLOADS <= 4, "coefficient block too large for SGPRs");
+
+    __shared__ float s_bnd[UBK ? 1 : 2 * NU * (N - 1)];
+    const int tid = threadIdx.x;
+    if constexpr (!UBK) {
+        for (int i = tid; i < 2 * NU * (N - 1); i += 256) {
+            const int k = i / (2 * NU), j = i % (2 * NU);
+            s_bnd[i] = P.bounds[k * BW + 2 * NX + j];
+        }
+        __syncthreads();
+    }
+    const long slot = (long)blockIdx.x * 256 + tid;
+    const bool active = slot < P.batch;
+    const long b = (active && P.idx) ? P.idx[slot] : slot;
+
+    const SBlock<double, L::NLOADS> blk(P.lean);
+    const auto cM = blk.at(L::O_M), cK = blk.at(L::O_K), cB = blk.at(L::O_B), cC = blk.at(L::O_C);
+
+    float lo[NU], hi[NU];
+#pragma unroll
+    for (int a = 0; a < NU; ++a) lo[a] = P.bounds[2 * NX + a], hi[a] = P.bounds[2 * NX + NU + a];
+
+    // ---- the iterated state: x (= v = vnew) in fp64, input dual / slack / feed-forward in fp32 ----
+    double X[N][NX];
+    float Y[N - 1][NU], Z[N - 1][NU];
+    using DT = std::conditional_t<TMPC_LEAN_D64 != 0, double, float>;
+    DT D[N - 1][NU];
+#pragma unroll
+    for (int m = 0; m < NX; ++m) X[0][m] = active ? (double)P.x0[b * NX + m] : 0.0;
+#pragma unroll
+    for (int k = 1; k < N; ++k)
+#pragma unroll
+        for (int m = 0; m < NX; ++m) X[k][m] = 0.0;
+#pragma unroll
+    for (int k = 0; k < N - 1; ++k)
+#pragma unroll
+        for (int a = 0; a < NU; ++a) Y[k][a] = 0.f, Z[k][a] = 0.f, D[k][a] = (DT)0;
+
+    int it = 0, conv = 0;
+    float res0 = 0.f, res1 = 0.f, res2 = 0.f, res3 = 0.f;
+    const int ct = P.check_termination;
+    const int last_check_it = ct > 0 ? (P.max_iter / ct) * ct : 0;
+    const float rho = P.rho;
+    double dua_x = 0.0;
+    float pri_u = 0.f, dua_u = 0.f;
+
+    // ================= fused forward sweep: forward_pass (admm.cpp:25-35) + update_slack (:43-59) + update_dual (:65-69)
+    // (+ RES: the residual maxima of termination_condition, :93-96) =================
+    auto forward = [&](auto res_tag) {
+        constexpr bool RES = decltype(res_tag)::value;
+        if constexpr (RES) dua_x = 0.0, pri_u = 0.f, dua_u = 0.f;
+        sfor<0, N - 1>([&](auto kk) {
+            constexpr int k = decltype(kk)::value;
+            double dk[NU], u[NU], xn[NX];
+#pragma unroll
+            for (int a = 0; a < NU; ++a) dk[a] = (double)D[k][a];
+            // x+ = (A - B Kinf) x - B d: NX independent chains, none waits for u
+#pragma unroll
+            for (int m = 0; m < NX; ++m) {
+                double acc = -(cB[m * NU] * dk[0]);
+#pragma unroll
+                for (int a = 1; a < NU; ++a) acc = fma(-cB[m * NU + a], dk[a], acc);
+                xn[m] = acc;
+            }
+#pragma unroll
+            for (int j = 0; j < NX; ++j)
+#pragma unroll
+                for (int m = 0; m < NX; ++m) xn[m] = fma(cM[m * NX + j], X[k][j], xn[m]);
+            // u = -Kinf x - d
+#pragma unroll
+            for (int a = 0; a < NU; ++a) {
+                if constexpr (TMPC_LEAN_SPLITK && NX >= 4) {
+                    double u0 = -dk[a], u1 = -(cK[a * NX + NX / 2] * X[k][NX / 2]);
+#pragma unroll
+                    for (int j = 0; j < NX / 2; ++j) u0 = fma(-cK[a * NX + j], X[k][j], u0);
+#pragma unroll
+                    for (int j = NX / 2 + 1; j < NX; ++j) u1 = fma(-cK[a * NX + j], X[k][j], u1);
+                    u[a] = u0 + u1;
+                } else {
+                    double acc = -dk[a];
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) acc = fma(-cK[a * NX + j], X[k][j], acc);
+                    u[a] = acc;
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < NU; ++a) {
+                const float uf = (float)u[a];
+                const float t = uf + Y[k][a];                                   // znew = u + y  (admm.cpp:45)
+                float l_ = lo[a], h_ = hi[a];
+                if constexpr (!UBK) l_ = s_bnd[k * 2 * NU + a], h_ = s_bnd[k * 2 * NU + NU + a];
+                const float zn = clamp3(t, l_, h_);                             //   clamped to [u_min, u_max]  (:50-52)
+                Y[k][a] = t - zn;                                               // y = y + u - znew  (:67)
+                if constexpr (RES) {
+                    pri_u = fmaxf(pri_u, fabsf(uf - zn));                       // (:95)
+                    dua_u = fmaxf(dua_u, fabsf(Z[k][a] - zn));                  // (:96), times rho at the check
+                }
+                Z[k][a] = zn;
+            }
+#pragma unroll
+            for (int m = 0; m < NX; ++m) {
+                if constexpr (RES) dua_x = fmax(dua_x, fabs(X[k + 1][m] - xn[m]));   // v - vnew with v = the previous x  (:94)
+                X[k + 1][m] = xn[m];
+            }
+            if constexpr (TMPC_LEAN_KNOT_BARRIER) __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+    // ================= fused backward sweep: update_linear_cost (admm.cpp:75-83) + backward_pass_grad (:13-20), scaled by
+    // -1 / rho; q, r, p never stored =================
+    auto backward = [&]() {
+        double p[NX];
+#pragma unroll
+        for (int m = 0; m < NX; ++m) p[m] = X[N - 1][m];                        // p~_{N-1} = vnew_{N-1}  (:81-82 with Xref = 0)
+        sfor<0, N - 1>([&](auto kk) {
+            constexpr int k = N - 2 - decltype(kk)::value;
+            double r[NU], t[NU];
+#pragma unroll
+            for (int a = 0; a < NU; ++a) {
+                r[a] = (double)(Z[k][a] - Y[k][a]);                             // r~ = znew - y  (:77-78)
+                t[a] = r[a];
+            }
+#pragma unroll
+            for (int j = 0; j < NX; ++j)
+#pragma unroll
+                for (int a = 0; a < NU; ++a) t[a] = fma(cB[j * NU + a], p[j], t[a]);   // B' p~_{k+1} + r~_k
+#pragma unroll
+            for (int a = 0; a < NU; ++a) {                                      // d_k = Quu_inv (B' p_{k+1} + r_k)  (:17)
+                double acc = cC[a * NU] * t[0];
+#pragma unroll
+                for (int c = 1; c < NU; ++c) acc = fma(cC[a * NU + c], t[c], acc);
+                D[k][a] = (DT)acc;
+            }
+            if constexpr (k > 0) {                                              // (p_0 is never read)
+                double ap[NX];
+#pragma unroll
+                for (int m = 0; m < NX; ++m) {                                  // q~_k - Kinf' r~_k
+                    double acc = X[k][m];
+#pragma unroll
+                    for (int a = 0; a < NU; ++a) acc = fma(-cK[a * NX + m], r[a], acc);
+                    ap[m] = acc;
+                }
+#pragma unroll
+                for (int j = 0; j < NX; ++j)
+#pragma unroll
+                    for (int m = 0; m < NX; ++m) ap[m] = fma(cM[j * NX + m], p[j], ap[m]);   // + AmBKt p~_{k+1}  (:18)
+#pragma unroll
+                for (int m = 0; m < NX; ++m) p[m] = ap[m];
+            }
+            if constexpr (TMPC_LEAN_KNOT_BARRIER) __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+    // solution = projected slack of the iteration (admm.cpp:187-188, :204-205); status of the instance
+    auto store = [&](bool solved_flag) {
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+#pragma unroll
+            for (int m = 0; m < NX; ++m) P.xout[b * EX + k * NX + m] = (float)X[k][m];
+#pragma unroll
+        for (int k = 0; k < N - 1; ++k)
+#pragma unroll
+            for (int a = 0; a < NU; ++a) P.uout[b * EU + k * NU + a] = Z[k][a];
+        P.iter[b] = P.iter_offset + it;
+        P.solved[b] = solved_flag ? 1 : 0;
+        P.res[b * 4 + 0] = res0;
+        P.res[b * 4 + 1] = res1;
+        P.res[b * 4 + 2] = res2;
+        P.res[b * 4 + 3] = res3;
+    };
+
+    // Iterations whose termination check can matter carry the residual arithmetic (every check when the tolerances are
+    // positive; otherwise nobody can converge and only the last check's values are ever reported); all others run in a
+    // tight loop of their own, so that the two forms of the forward sweep never meet at a join (a join costs a copy per
+    // loop-carried register and lets the compiler hoist their common parts above the branch, live across everything).
+    const bool can_converge = P.abs_pri_tol > 0.f && P.abs_dua_tol > 0.f;
+    const int max_iter = P.max_iter;
+    int i = 0;
+    while (i < max_iter) {
+        int next_res = max_iter;                                                // 0-based index of the next iteration with residuals
+        if (ct > 0) {
+            if (LIVE && can_converge) next_res = (i / ct) * ct + ct - 1;
+            else if (last_check_it - 1 >= i) next_res = last_check_it - 1;
+        }
+        const int n_plain = (next_res < max_iter ? next_res : max_iter) - i;
+        for (int j = 0; j < n_plain; ++j) {
+            forward(std::false_type{});
+            backward();
+        }
+        i += n_plain;
+        if (!LIVE || !conv) it += n_plain;                                      // admm.cpp:143
+        if (i >= max_iter) break;
+        forward(std::true_type{});
+        i += 1;
+        if (!LIVE || !conv) {                                                   // termination_condition (admm.cpp:89-107)
+            it += 1;
+            res0 = 0.f;                                                         // x - vnew = 0: nothing clamps the state
+            res1 = (float)dua_x * rho;
+            res2 = pri_u;
+            res3 = dua_u * rho;
+        }
+        if constexpr (LIVE) {
+            const bool now = active && !conv && res0 < P.abs_pri_tol && res2 < P.abs_pri_tol && res1 < P.abs_dua_tol &&
+                             res3 < P.abs_dua_tol;
+            if (now) {                                                          // returns before v = vnew and the backward pass (:181-193)
+                store(true);
+                conv = 1;
+            }
+            if (!__builtin_amdgcn_ballot_w64(active && !conv)) break;           // every instance of this wavefront finished
+        }
+        backward();
+    }
+    if (active && !conv) store(false);
+
+    {   // global status block: wavefront max of the residuals, count of unsolved instances
+        float m0 = active ? res0 : 0.f, m1 = active ? res1 : 0.f, m2 = active ? res2 : 0.f, m3 = active ? res3 : 0.f;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            m0 = fmaxf(m0, __shfl_xor(m0, off, 64));
+            m1 = fmaxf(m1, __shfl_xor(m1, off, 64));
+            m2 = fmaxf(m2, __shfl_xor(m2, off, 64));
+            m3 = fmaxf(m3, __shfl_xor(m3, off, 64));
+        }
+        const unsigned long long unsolved = __builtin_amdgcn_ballot_w64(active && !conv);
+        fold_status(P, m0, m1, m2, m3, __popcll(unsolved), tid);
+    }
+}
+
+}  // namespace tmpc

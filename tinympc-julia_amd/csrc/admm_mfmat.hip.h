@@ -292,6 +292,7 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
 
     float fm0 = 0.f, fm1 = 0.f, fm2 = 0.f, fm3 = 0.f;          // over this workgroup's tiles: residual maxima, unsolved instances
     int f_unsolved = 0;
+    bool refs_shifted = false;                                 // s_ref / s_pterm hold a later step's references than step 0's
     for (;;) {
     // Persistent workgroups: a workgroup takes 16-instance tiles off a global counter until none is left (the hardware
     // dispatcher's strict XCD rotation leaves slots empty, admm_mfmar.hip.h)
@@ -438,6 +439,11 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
         if (P.xref_seq && step > 0) {                          // shifted references of this step (rocket_landing_constraints.jl:107-115)
             __syncthreads();
             stage_refs(P.xref_seq + (size_t)step * EX, P.uref_seq + (size_t)step * EU);
+            refs_shifted = true;
+        } else if (refs_shifted) {                             // a persistent workgroup's next tile: step 0 solves against the
+            __syncthreads();                                   // solver's shared references again, not the previous tile's last step
+            stage_refs(P.xref, P.uref);
+            refs_shifted = false;
         }
     }
     __syncthreads();

@@ -89,7 +89,23 @@ struct AdmmParams {
     // ---- mfmat kernel, fused closed loop: shared references of every step, [steps][N][nx] / [steps][N-1][nu] (NULL: the
     // references stay as set) — the per-step shift of rocket_landing_constraints.jl:107-115 ----
     const float *xref_seq, *uref_seq;
+    // ---- lean kernel (admm_lean.hip.h): its fp64 coefficient pack (LeanPack), wave-uniform ----
+    const double *lean;
 };
+
+// Coefficient pack of the lean kernel (admm_lean.hip.h), fp64, all wave-uniform; filled by build_lean_pack (kernels.hip).
+struct LeanLayout {
+    int oM;      // A - B Kinf     [nx][nx] row-major (its transpose is the AmBKt the backward sweep reads)
+    int oK;      // Kinf           [nu][nx]
+    int oB;      // B              [nx][nu]
+    int oC;      // -rho Quu_inv   [nu][nu]
+    int len;
+    int padded;  // rounded up to whole 8-double scalar loads
+};
+constexpr LeanLayout lean_layout(int nx, int nu) {
+    return LeanLayout{0, nx * nx, nx * nx + nu * nx, nx * nx + 2 * nu * nx, nx * nx + 2 * nu * nx + nu * nu,
+                      (nx * nx + 2 * nu * nx + nu * nu + 7) / 8 * 8};
+}
 
 #ifdef __HIPCC__
 // Folds one wavefront's residual maxima / unsolved count into the launch's status block without a host-side clear:

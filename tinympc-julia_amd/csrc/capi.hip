@@ -362,7 +362,6 @@ int tinympc_set_x0_f32(tinympc_solver *s, const float *x0, int cols) {
         }
         if (!tmpc::hip_ok(hipSetDevice(v.device), "hipSetDevice") || v.wait_last_launch()) return -1;
         if (cols == v.batch) {
-            v.pin_host_range(const_cast<float *>(x0), (size_t)v.batch * v.nx * sizeof(float));
             return tmpc::hip_ok(hipMemcpy(v.d_x0, x0, (size_t)v.batch * v.nx * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy") ? 0 : -1;
         }
         std::vector<float> h((size_t)v.batch * v.nx);
@@ -374,7 +373,6 @@ static int get_traj_f32(tinympc_solver *s, bool states, float *buf) {
     tmpc::Solver &v = s->s;
     if (!tmpc::hip_ok(hipSetDevice(v.device), "hipSetDevice") || v.wait_last_launch()) return -1;
     const size_t n = (size_t)v.batch * (states ? v.ex() : v.eu());
-    v.pin_host_range(buf, n * sizeof(float));   // (a caller that reuses its buffers gets a direct DMA from the second call on)
     return tmpc::hip_ok(hipMemcpy(buf, states ? v.d_xout : v.d_uout, n * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy") ? 0 : -1;
 }
 int tinympc_get_states_f32(tinympc_solver *s, float *buf) {
@@ -384,6 +382,14 @@ int tinympc_get_states_f32(tinympc_solver *s, float *buf) {
 int tinympc_get_controls_f32(tinympc_solver *s, float *buf) {
     if (!s || !buf) return -1;
     return guarded("get_controls_f32", [&] { return get_traj_f32(s, false, buf); });
+}
+int tinympc_pin_host(tinympc_solver *s, void *ptr, size_t bytes) {
+    if (!s) return -1;
+    return guarded("pin_host", [&] { return s->s.pin_host_range(ptr, bytes); });
+}
+int tinympc_unpin_host(tinympc_solver *s, void *ptr) {
+    if (!s) return -1;
+    return guarded("unpin_host", [&] { return s->s.unpin_host_range(ptr); });
 }
 int tinympc_get_status(tinympc_solver *s, int *iter, int *solved, double *residuals4) {
     if (!s) return -1;
@@ -456,6 +462,10 @@ int tinympc_set_precision(tinympc_solver *s, int precision) {
 }
 
 const char *tinympc_kernel_name(tinympc_solver *s) { return s ? s->s.kernel_name.c_str() : ""; }
+const char *tinympc_last_launch_name(tinympc_solver *s) {
+    if (!s) return "";
+    return s->s.last_launch_name.empty() ? s->s.kernel_name.c_str() : s->s.last_launch_name.c_str();
+}
 
 /* compulsory fp32 device I/O per solve, state on chip. */
 double tinympc_algorithmic_bytes(tinympc_solver *s) {
@@ -662,6 +672,25 @@ int get_controls_f32(float *controls_buffer, int *rows, int *cols) {
     *rows = g_solver->s.nu;
     *cols = (g_solver->s.N - 1) * global_batch();
     return tinympc_get_controls_f32(g_solver.get(), controls_buffer);
+}
+
+// page-lock / release a host array the Julia caller owns and reuses with the fp32 forms (tinympc_pin_host); the caller
+// unpins before the array can be collected
+int pin_host_buffer(void *ptr, size_t bytes) {
+    if (need_global("pin_host_buffer")) return -1;
+    if (g_sharded) {
+        set_error("pin_host_buffer: not available on a sharded solver");
+        return -1;
+    }
+    return tinympc_pin_host(g_solver.get(), ptr, bytes);
+}
+int unpin_host_buffer(void *ptr) {
+    if (need_global("unpin_host_buffer")) return -1;
+    if (g_sharded) {
+        set_error("unpin_host_buffer: not available on a sharded solver");
+        return -1;
+    }
+    return tinympc_unpin_host(g_solver.get(), ptr);
 }
 
 void cleanup_solver(void) {

@@ -1,4 +1,6 @@
 // Kernel table, generic-kernel launcher and its host-side pack builders.
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <limits>
 
@@ -49,6 +51,43 @@ const KernelEntry *find_mfma_kernel(int nx, int nu, int N) {
     for (const KernelEntry *e : table)
         if (e->nx == nx && e->nu == nu && e->N == N) return e;
     return nullptr;
+}
+
+const LeanEntry *lean_entry_4_1_20();
+
+const LeanEntry *find_lean_kernel(int nx, int nu, int N) {
+    static const LeanEntry *const table[] = {lean_entry_4_1_20()};
+    for (const LeanEntry *e : table)
+        if (e->nx == nx && e->nu == nu && e->N == N) return e;
+    return nullptr;
+}
+
+bool build_lean_pack(const Solver &sv, std::vector<double> &out) {
+    const int nx = sv.nx, nu = sv.nu;
+    const LeanLayout L = lean_layout(nx, nu);
+    out.assign((size_t)L.padded, 0.0);
+    const Cache &c = sv.cache;
+    // the kernel reads ONE matrix as A - B Kinf (rollout) and, transposed, as AmBKt (gradient recursion): only valid while
+    // the cache's AmBKt is that transpose (tiny_api.cpp:170; set_cache_terms can install anything)
+    double scale = 0.0, diff = 0.0;
+    for (int i = 0; i < nx; ++i)
+        for (int j = 0; j < nx; ++j) {
+            double m = sv.A(i, j);
+            for (int a = 0; a < nu; ++a) m -= sv.B(i, a) * c.Kinf(a, j);
+            out[L.oM + i * nx + j] = m;
+            scale = std::max(scale, std::fabs(m));
+            diff = std::max(diff, std::fabs(m - c.AmBKt(j, i)));
+        }
+    if (!(diff <= 1e-12 * std::max(scale, 1.0))) return false;
+    for (int i = 0; i < nx; ++i)      // (bit for bit the cache's own values where the two agree to rounding)
+        for (int j = 0; j < nx; ++j) out[L.oM + i * nx + j] = c.AmBKt(j, i);
+    for (int a = 0; a < nu; ++a)
+        for (int j = 0; j < nx; ++j) out[L.oK + a * nx + j] = c.Kinf(a, j);
+    for (int i = 0; i < nx; ++i)
+        for (int a = 0; a < nu; ++a) out[L.oB + i * nu + a] = sv.B(i, a);
+    for (int a = 0; a < nu; ++a)
+        for (int b2 = 0; b2 < nu; ++b2) out[L.oC + a * nu + b2] = -c.rho * c.Quu_inv(a, b2);
+    return true;
 }
 
 // Lanes per instance for a batch size.  Fewer lanes per instance means fewer cross-lane moves and no redundant

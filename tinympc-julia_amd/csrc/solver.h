@@ -29,6 +29,16 @@ const KernelEntry *find_quad_kernel(int nx, int nu, int N, int group = -1);
 const KernelEntry *select_quad_kernel(int nx, int nu, int N, int batch);
 // the matrix-core kernel of the shape, for one-shot solves (nullptr: not instantiated)
 const KernelEntry *find_mfma_kernel(int nx, int nu, int N);
+// One instantiation of the lean kernel (admm_lean.hip.h): the one-lane-per-instance quad entry's one-shot solves without an
+// active state bound, zero references, fp64 recurrences (the benchmark's calling pattern) run there.
+struct LeanEntry {
+    int nx, nu, N;
+    const char *name;
+    hipError_t (*launch)(const AdmmParams &, bool live, bool knot_bounds, hipStream_t);
+};
+const LeanEntry *find_lean_kernel(int nx, int nu, int N);
+// the lean kernel's fp64 pack (lean_layout); false when the family does not qualify (cache.AmBKt is not (A - B Kinf)')
+bool build_lean_pack(const Solver &, std::vector<double> &);
 // One (nx, nu) instantiation of the run-time-horizon stream kernel (admm_streamg.hip.h).
 struct StreamEntry {
     int nx, nu;
@@ -138,6 +148,13 @@ struct Solver {
     const StreamEntry *se = nullptr;  // run-time-horizon stream kernel, or
     const ConeEntry *ce = nullptr;    // LDS-resident matrix-core kernel (one-shot solves), or (all null) the generic kernel
     std::string kernel_name;
+    // the lean kernel of the shape (admm_lean.hip.h): takes the one-lane-per-instance quad entry's one-shot solves without an
+    // active state bound (launch_pass decides per launch); its pack, and whether the family qualifies (build_lean_pack)
+    const LeanEntry *le = nullptr;
+    double *d_lean = nullptr;
+    bool lean_ok = false, lean_knot_bounds = false;
+    bool lean_enabled = true;             // TINYMPC_HIP_NO_LEAN, read once at creation
+    std::string last_launch_name;         // the kernel the most recent launch actually ran (family or its lean variant)
     // device buffers
     unsigned char *d_coef = nullptr;
     float *d_bounds = nullptr;
@@ -157,7 +174,8 @@ struct Solver {
     // fp32 host buffers of the *_f32 entry points: page-locked on first sight (at most 8 ranges, of at least 1 MB) so that
     // the copies of a caller who reuses its buffers are direct DMAs; unlocked when the solver is destroyed
     std::vector<std::pair<void *, size_t>> pinned_ranges;
-    void pin_host_range(void *p, size_t bytes);
+    int pin_host_range(void *p, size_t bytes);
+    int unpin_host_range(void *p);
     int h2d_float(float *d, const double *in, size_t n);
     float *d_scratch = nullptr;
     float *d_mpc_x = nullptr, *d_mpc_u = nullptr;  // fused closed-loop logs

@@ -142,6 +142,7 @@ Solver::~Solver() {
     dev_free(d_bounds);
     dev_free(d_gstat);
     dev_free(d_sens);
+    dev_free(d_lean);
     dev_free(d_plant);
     if (h_gstat) (void)hipHostFree(h_gstat);
     h_gstat = nullptr;
@@ -247,6 +248,7 @@ int Solver::init(const double *A_, const double *B_, const double *Q_, const dou
     if (device_ < 0) HIP_TRY(hipGetDevice(&device_));
     device = device_;
     HIP_TRY(hipSetDevice(device));
+    lean_enabled = std::getenv("TINYMPC_HIP_NO_LEAN") == nullptr;   // tuning / test aid: keep such solves on the quad kernel
     nx = nx_;
     nu = nu_;
     N = N_;
@@ -568,6 +570,22 @@ int Solver::upload_packs() {
     if (dev_alloc(d_coef, coef.size()) || dev_alloc(d_bounds, bnd.size())) return -1;
     HIP_TRY(hipMemcpy(d_coef, coef.data(), coef.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_bounds, bnd.data(), bnd.size() * sizeof(float), hipMemcpyHostToDevice));
+    // the lean kernel's own pack where the selected entry has one lane per instance and the shape a lean instantiation
+    le = (ke && ke->G == 1 && lean_enabled) ? find_lean_kernel(nx, nu, N) : nullptr;
+    lean_ok = false;
+    if (le) {
+        std::vector<double> lp;
+        if (build_lean_pack(*this, lp)) {
+            if (dev_alloc(d_lean, lp.size())) return -1;
+            HIP_TRY(hipMemcpy(d_lean, lp.data(), lp.size() * sizeof(double), hipMemcpyHostToDevice));
+            lean_ok = true;
+            lean_knot_bounds = false;
+            if (st.en_input_bound)
+                for (int k = 1; k < N - 1 && !lean_knot_bounds; ++k)
+                    for (int a = 0; a < nu; ++a)
+                        if (u_min[a + (size_t)k * nu] != u_min[a] || u_max[a + (size_t)k * nu] != u_max[a]) lean_knot_bounds = true;
+        }
+    }
     packs_dirty = false;
     return 0;
 }
@@ -1082,6 +1100,15 @@ int Solver::launch_pass(hipStream_t stream, int mpc_steps, const int *idx, int n
     // caller wrote one in): the matrix-core kernel (G == 16) carries g only then
     if (state_bounds_active && save) g_maybe_nonzero = true;
     const bool carry_g = state_bounds_active || (ke && ke->G == 16 && g_maybe_nonzero);
+    // one-shot solves (cold start, nothing of the workspace kept) of a one-lane-per-instance entry without an active state
+    // bound, zero references, fp64 recurrences: the lean kernel (same arithmetic, a third fewer instructions)
+    const bool lean = ke && le && lean_ok && precision == 0 && cold && !save && mpc_steps == 0 && !idx && !carry_g &&
+                      ref_mode == REF_ZERO && !st.adaptive_rho && max_iter_pass >= 1;
+    P.lean = d_lean;
+    last_launch_name = lean ? le->name : kernel_name;
+    if (lean) {
+        HIP_TRY(le->launch(P, st.abs_pri_tol > 0.0 && st.abs_dua_tol > 0.0, lean_knot_bounds, stream));
+    } else
     HIP_TRY(ke ? ke->launch(P, precision, carry_g, stream)
                : (ce ? ce->launch(P, cones_active(), ce->lds_bytes(*this), stream)
                      : (se ? se->launch(P, precision, lin_active() ? 2 : ((has_fdyn || cones_active()) ? 1 : 0), hetero, stream)
@@ -1268,13 +1295,37 @@ int Solver::d2h_double(const float *d, double *out, size_t n) {
     }
     return 0;
 }
-void Solver::pin_host_range(void *p, size_t bytes) {
-    if (!p || bytes < ((size_t)1 << 20)) return;
+// Page-lock a caller-owned host range so that the fp32 transfers DMA straight into it.  Only on request
+// (tinympc_pin_host): the library does not own these buffers and cannot know when they are freed, so it never registers
+// them on its own — the caller unpins (tinympc_unpin_host) before releasing the memory; whatever is still registered
+// when the solver is destroyed is unregistered there.
+int Solver::pin_host_range(void *p, size_t bytes) {
+    if (!p || bytes == 0) {
+        set_error("pin_host: null or empty range");
+        return -1;
+    }
     for (const auto &r : pinned_ranges)
-        if (r.first == p && r.second >= bytes) return;
-    if (pinned_ranges.size() >= 8) return;
-    if (hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess) pinned_ranges.emplace_back(p, bytes);
-    else (void)hipGetLastError();   // (not registrable — e.g. already pinned by its owner: the plain copy still works)
+        if (r.first == p) {
+            if (r.second >= bytes) return 0;
+            set_error("pin_host: this address is already pinned with a smaller size; unpin it first");
+            return -1;
+        }
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    pinned_ranges.emplace_back(p, bytes);
+    return 0;
+}
+int Solver::unpin_host_range(void *p) {
+    for (size_t i = 0; i < pinned_ranges.size(); ++i)
+        if (pinned_ranges[i].first == p) {
+            HIP_TRY(hipSetDevice(device));
+            if (wait_last_launch()) return -1;
+            pinned_ranges.erase(pinned_ranges.begin() + i);
+            HIP_TRY(hipHostUnregister(p));
+            return 0;
+        }
+    set_error("unpin_host: this address was not pinned through this solver");
+    return -1;
 }
 
 int Solver::h2d_float(float *d, const double *in, size_t n) {

@@ -19,7 +19,7 @@ module TinyMPC
 # mirror (tinympc-julia_amd/tinympc.py) in tests/.  INTEGRATION.md shows the two-line change that
 # makes the reference's own src/TinyMPC.jl use this library without adopting this module.
 
-export TinyMPCSolver, setup, solve, get_solution, get_solution!, get_status, set_x0, set_x_ref, set_u_ref, set_ref_sequence, mpc_rollout,
+export TinyMPCSolver, setup, solve, get_solution, get_solution!, pin_host!, unpin_host!, get_status, set_x0, set_x_ref, set_u_ref, set_ref_sequence, mpc_rollout,
        set_bound_constraints, set_linear_constraints, set_equality_constraints, set_cone_constraints, update_settings,
        set_cache_terms, set_batch_size, set_gpus, get_gpus, set_warm_start, kernel_name, reset_workspace, print_problem_data,
        compute_sensitivity_autograd, set_sensitivity, get_adaptive_rho
@@ -181,6 +181,18 @@ function get_solution!(states::Array{Float32,3}, controls::Array{Float32,3}, sol
     s2 = ccall((:get_controls_f32, _lib_path()), Int32, (Ptr{Float32}, Ref{Int32}, Ref{Int32}), controls, ur, uc)
     (s1 != 0 || s2 != 0) && error("Failed to get solution ($(_last_error()))")
     return (states=states, controls=controls)
+end
+
+# Page-lock an array that is reused with `get_solution!` / the Float32 `set_x0` (the copies then DMA straight into it).  The
+# library never pins caller memory by itself: call `unpin_host!` before the array can be garbage-collected, e.g.
+#   pin_host!(solver, states); try ... finally unpin_host!(solver, states) end
+function pin_host!(solver::TinyMPCSolver, a::Array{Float32})
+    _need(solver)
+    _ok(ccall((:pin_host_buffer, _lib_path()), Int32, (Ptr{Cvoid}, Csize_t), a, sizeof(a)), "Failed to pin host array")
+end
+function unpin_host!(solver::TinyMPCSolver, a::Array{Float32})
+    _need(solver)
+    _ok(ccall((:unpin_host_buffer, _lib_path()), Int32, (Ptr{Cvoid},), a), "Failed to unpin host array")
 end
 
 # Per-instance iteration count, solved flag and residuals (pri_state, dua_state, pri_input, dua_input)

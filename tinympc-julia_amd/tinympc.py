@@ -102,11 +102,15 @@ SIGNATURES = {
     "tinympc_set_x0_f32": (c_int, [c_vp, c_fp, c_int]),
     "tinympc_get_states_f32": (c_int, [c_vp, c_fp]),
     "tinympc_get_controls_f32": (c_int, [c_vp, c_fp]),
+    "tinympc_pin_host": (c_int, [c_vp, c_vp, ctypes.c_size_t]),
+    "tinympc_unpin_host": (c_int, [c_vp, c_vp]),
     "set_ref_sequence": (c_int, [c_dp, c_int, c_int, c_dp, c_int, c_int, c_int]),
     "mpc_rollout": (c_int, [c_int, c_dp, c_dp, c_ip]),
     "set_x0_f32": (c_int, [c_fp, c_int, c_int, c_int]),
     "get_states_f32": (c_int, [c_fp, c_ip, c_ip]),
     "get_controls_f32": (c_int, [c_fp, c_ip, c_ip]),
+    "pin_host_buffer": (c_int, [c_vp, ctypes.c_size_t]),
+    "unpin_host_buffer": (c_int, [c_vp]),
     "tinympc_set_ref_sequence": (c_int, [c_vp, c_dp, c_int, c_int, c_dp, c_int, c_int, c_int]),
     "tinympc_set_profiling": (c_int, [c_vp, c_int]),
     "tinympc_set_compaction": (c_int, [c_vp, c_int]),
@@ -118,6 +122,7 @@ SIGNATURES = {
     "tinympc_kernel_elapsed_mean_ms": (c_dbl, [c_vp, c_int]),
     "tinympc_set_precision": (c_int, [c_vp, c_int]),
     "tinympc_kernel_name": (ctypes.c_char_p, [c_vp]),
+    "tinympc_last_launch_name": (ctypes.c_char_p, [c_vp]),
     "tinympc_algorithmic_bytes": (c_dbl, [c_vp]),
     "tinympc_algorithmic_flops": (c_dbl, [c_vp, c_int]),
     "tinympc_last_error": (ctypes.c_char_p, []),
@@ -754,6 +759,14 @@ class BatchSolver:
         self._chk(self.lib.tinympc_get_controls_f32(self.h, controls.ctypes.data_as(c_fp)), "get_controls_f32")
         return dict(states=states, controls=controls)
 
+    def pin_host(self, arr):
+        """page-lock a numpy array the caller keeps alive and reuses (the fp32 transfers then DMA straight into it);
+        call unpin_host(arr) before dropping the array"""
+        self._chk(self.lib.tinympc_pin_host(self.h, arr.ctypes.data_as(c_vp), arr.nbytes), "pin_host")
+
+    def unpin_host(self, arr):
+        self._chk(self.lib.tinympc_unpin_host(self.h, arr.ctypes.data_as(c_vp)), "unpin_host")
+
     def set_ref_sequence(self, x_ref_seq, u_ref_seq):
         """shared references of every step of the next closed loops: x_ref_seq (nx, N, steps), u_ref_seq (nu, N-1, steps)
         (rocket_landing_constraints.jl:107-115 shifts them step by step); None, None drops the sequence"""
@@ -803,6 +816,11 @@ class BatchSolver:
     @property
     def kernel_name(self):
         return self.lib.tinympc_kernel_name(self.h).decode()
+
+    @property
+    def last_launch_name(self):
+        """the kernel the most recent launch actually ran (the family, or e.g. its lean<nx,nu,N> one-shot variant)"""
+        return self.lib.tinympc_last_launch_name(self.h).decode()
 
     def algorithmic_bytes(self):
         return float(self.lib.tinympc_algorithmic_bytes(self.h))
