@@ -35,13 +35,16 @@ for i, l in enumerate(lines):
             print("   ", dict(c), "total", sum(c.values()))
             # innermost loops (backward branches), largest first
             body = lines[start:i]
-            lab = {m.group(1): n for n, b in enumerate(body) if (m := re.match(r"^(\.LBB\d+_\d+):", b))}
-            loops = []
+            # loop headers as the compiler marks them (the comment sits on the label's line or the one after)
+            lab = {}
+            for n, b in enumerate(body):
+                m = re.match(r"^(\.LBB\d+_\d+):", b)
+                if m and ("Inner Loop Header" in b or (n + 1 < len(body) and "Inner Loop Header" in body[n + 1])): lab[m.group(1)] = n
+            inner = []
             for n, b in enumerate(body):
                 m = re.match(r"\s+s_c?branch\w*\s+(\.LBB\d+_\d+)", b)
-                if m and m.group(1) in lab and lab[m.group(1)] < n: loops.append((lab[m.group(1)], n))
-            inner = [lp for lp in loops if not any(o != lp and lp[0] <= o[0] and o[1] <= lp[1] for o in loops)]
-            for lo_, hi_ in sorted(inner, key=lambda lp: lp[0] - lp[1])[:2]:
+                if m and m.group(1) in lab and lab[m.group(1)] < n: inner.append((lab[m.group(1)], n))
+            for lo_, hi_ in sorted(inner, key=lambda lp: lp[0] - lp[1])[:6]:
                 c2 = collections.Counter()
                 for b in body[lo_:hi_ + 1]:
                     s2 = b.strip()
@@ -51,5 +54,6 @@ for i, l in enumerate(lines):
                         if re.match(pat, op): c2[k] += 1; break
                     else: c2["other"] += 1
                 valu = sum(v for k, v in c2.items() if k in ("fp64", "cvt", "accvgpr", "fp32", "vmov", "valu_other"))
-                print("    loop lines %d-%d:" % (lo_, hi_), dict(c2), "total", sum(c2.values()), "VALU", valu)
+                if c2.get("fp64", 0) > 100 or len(sys.argv) > 3:
+                    print("    loop lines %d-%d:" % (lo_, hi_), dict(c2), "total", sum(c2.values()), "VALU", valu)
         start = None

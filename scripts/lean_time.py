@@ -28,6 +28,26 @@ tag = os.path.basename(lib)
 if mode == "head":
     ms, name, sol = run(65536, fixed)
     print(f"{tag:34s} {name:18s} 65536 x 100 it: {ms:.4f} ms  ({65536 / ms * 1e3:.3e} solves/s)  chk {float(np.abs(sol['controls']).sum()):.6f}", flush=True)
+elif mode == "clock":   # a library built with -DTMPC_LEAN_CLOCK_PROBE: the residual slots carry (core clocks, 100 MHz ticks) of each lane's solve
+    for B in (20480, 65536, 131072):
+        x0 = t.problems.cartpole_x0(B, seed=0)
+        bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+        bs.update_settings(**fixed); bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        bs.set_warm_start(False); bs.set_x0(x0); bs.set_profiling(True)
+        for _ in range(20): bs.solve()
+        stt = bs.get_status(); r = stt["residuals"]; ms = bs.kernel_elapsed_ms(12); bs.close()
+        print(f"    first entry -> last: stores issued {(stt['iter'].max() - r[:, 2].min()) * 1e-5:.4f} ms, stores acknowledged {(stt['solved'].max() - r[:, 2].min()) * 1e-5:.4f} ms, "
+              f"status fold done {(r[:, 3].max() - r[:, 2].min()) * 1e-5:.4f} ms (kernel by events {ms:.4f} ms)")
+        clk = r[:, 0] / r[:, 1] * 0.1
+        e0, e1 = r[:, 2].min(), r[:, 3].max()
+        wv = r[::64]                         # one lane per wavefront
+        print(f"    timeline (100 MHz ticks = 10 ns): first entry -> last loop end {(e1 - e0) * 1e-5:.4f} ms; entry spread {(wv[:, 2].max() - e0) * 1e-5:.4f} ms; "
+              f"loop-end spread {(e1 - wv[:, 3].min()) * 1e-5:.4f} ms; per-wave loop time min / median / max {wv[:, 1].min() * 1e-5:.4f} / {np.median(wv[:, 1]) * 1e-5:.4f} / {wv[:, 1].max() * 1e-5:.4f} ms; "
+              f"per-wave cycles min / median / max {wv[:, 0].min():.0f} / {np.median(wv[:, 0]):.0f} / {wv[:, 0].max():.0f}")
+        h, _ = np.histogram((wv[:, 2] - e0) * 1e-2, bins=10)   # microseconds
+        print("    entry-time histogram (10 bins over the spread):", h.tolist(), "  loop-time histogram:", np.histogram(wv[:, 1] * 1e-2, bins=10)[0].tolist())
+        print(f"{tag:34s} batch {B:7d}: kernel {ms:.4f} ms; in-kernel core clock median {np.median(clk):.3f} GHz (min {clk.min():.3f}, max {clk.max():.3f}); "
+              f"cycles per solve median {np.median(r[:, 0]):.0f} = {np.median(r[:, 0]) / 100 / 1063:.2f} cycles per loop instruction", flush=True)
 elif mode == "sweep":
     for B in (20480, 32768, 65536, 98304, 131072, 196608, 262144, 524288, 1048576):
         ms, name, _ = run(B, fixed, reps=12)
@@ -41,7 +61,10 @@ elif mode == "patterns":
         ms, name, _ = run(65536, kw, xb=xb)
         print(f"{tag:34s} {name:18s} {label:32s}: {ms:.4f} ms", flush=True)
 '''
-libs = ["-"] + sys.argv[1:]
+clk = [a for a in sys.argv[1:] if "clk" in os.path.basename(a)]
+for lib in clk:
+    subprocess.run([sys.executable, "-c", code, lib, "clock"], cwd=ROOT, check=False)
+libs = ["-"] + [a for a in sys.argv[1:] if a not in clk]
 for rep in range(2):
     for lib in libs:
         subprocess.run([sys.executable, "-c", code, lib, "head"], cwd=ROOT, check=False)

@@ -59,7 +59,8 @@ def test_lean_vs_oracle_every_instance(hip_lib, oracle_built, kw):
     same = parity_every_instance(sol, st, ref, _oracle_make(oracle_built, prob, kw), x0, kw, prob.rho, min_same=0.97, tag="lean")
     eq = st["iter"] == ref["iter"]
     # residuals as the reference reports them (types.hpp:128-131): the last check's values
-    assert np.allclose(st["residuals"][eq], ref["res"][eq], rtol=2e-3, atol=2e-6)
+    dres = np.abs(st["residuals"][eq] - ref["res"][eq]).max(axis=0) / np.maximum(1.0, np.abs(ref["res"][eq]).max(axis=0))
+    assert dres.max() <= FP32_TOL, f"residuals (pri_x, dua_x, pri_u, dua_u) off by {dres}"
     if kw["abs_pri_tol"] > 0 and kw["check_termination"] > 0:
         assert len(np.unique(st["iter"])) > 3 and same >= 0.97
     else:

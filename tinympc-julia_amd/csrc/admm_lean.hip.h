@@ -32,14 +32,8 @@
 #include "admm_params.h"
 #include "admm_quad.hip.h"   // SBlock, sfor
 
-#ifndef TMPC_LEAN_WAVES
-#define TMPC_LEAN_WAVES 2     // wavefronts per SIMD the register budget is held to (256 VGPRs, no AGPRs)
-#endif
 #ifndef TMPC_LEAN_KNOT_BARRIER
 #define TMPC_LEAN_KNOT_BARRIER 0   // 1: a scheduling barrier per knot (keeps the scheduler from hoisting a later knot's loads / conversions)
-#endif
-#ifndef TMPC_LEAN_D64
-#define TMPC_LEAN_D64 0       // 1: the feed-forward term d kept in fp64 (nu (N-1) more registers, two conversions per knot fewer)
 #endif
 #ifndef TMPC_LEAN_SPLITK
 #define TMPC_LEAN_SPLITK 0    // 1: Kinf x as two chains of two (+ an add): shorter dependent chain, one more instruction
@@ -57,8 +51,15 @@ struct LeanPack {
 // clamp(t, lo, hi) as one v_med3_f32 (lo <= hi; +-inf for "no bound")
 __device__ __forceinline__ float clamp3(float t, float lo, float hi) { return __builtin_amdgcn_fmed3f(t, lo, hi); }
 
-template <int NX, int NU, int N, bool LIVE, bool UBK>
-__global__ __launch_bounds__(256, TMPC_LEAN_WAVES) void admm_lean_kernel(const AdmmParams P) {
+// ONE: the launch has at most one wavefront per SIMD (batch <= 256 x CUs), so the kernel may take the whole register file:
+// the feed-forward term d is then kept in fp64 too (nu (N-1) more registers, two conversions per knot fewer: 3.5 % of the
+// instructions).  Otherwise the kernel is held to 256 registers and two wavefronts share a SIMD (batches beyond one
+// wavefront per SIMD: 10 % faster than one 512-register wavefront after the other).
+template <int NX, int NU, int N, bool LIVE, bool UBK, bool ONE>
+__global__ __launch_bounds__(256, (ONE ? 1 : 2)) void admm_lean_kernel(const AdmmParams P) {
+#ifdef TMPC_LEAN_CLOCK_PROBE
+    const unsigned long long probe_entry = __builtin_amdgcn_s_memrealtime();
+#endif
     using L = LeanPack<NX, NU>;
     constexpr int EX = NX * N, EU = NU * (N - 1);
     constexpr int BW = 2 * NX + 2 * NU;              // the quad kernel's bounds pack, one lane per instance: [N][xmin xmax umin umax]
@@ -73,9 +74,14 @@ __global__ __launch_bounds__(256, TMPC_LEAN_WAVES) void admm_lean_kernel(const A
         }
         __syncthreads();
     }
-    const long slot = (long)blockIdx.x * 256 + tid;
-    const bool active = slot < P.batch;
-    const long b = (active && P.idx) ? P.idx[slot] : slot;
+    const long b = (long)blockIdx.x * 256 + tid;     // (no index list: the solver sends compacted / chunked solves to the quad kernel)
+    const bool active = b < P.batch;
+    const int lane = tid & 63;
+    // staging of a wavefront's solution for the final store (below): [64 instances][16 + 1 floats], or [64][nu (N-1)]
+    constexpr int STAGE = (64 * 17 > 64 * (EU | 1)) ? 64 * 17 : 64 * (EU | 1);
+    __shared__ float s_stage[4][STAGE];
+    __shared__ float s_fold[4][4];
+    __shared__ int s_unsolved[4];
 
     const SBlock<double, L::NLOADS> blk(P.lean);
     const auto cM = blk.at(L::O_M), cK = blk.at(L::O_K), cB = blk.at(L::O_B), cC = blk.at(L::O_C);
@@ -87,7 +93,7 @@ __global__ __launch_bounds__(256, TMPC_LEAN_WAVES) void admm_lean_kernel(const A
     // ---- the iterated state: x (= v = vnew) in fp64, input dual / slack / feed-forward in fp32 ----
     double X[N][NX];
     float Y[N - 1][NU], Z[N - 1][NU];
-    using DT = std::conditional_t<TMPC_LEAN_D64 != 0, double, float>;
+    using DT = std::conditional_t<ONE, double, float>;
     DT D[N - 1][NU];
 #pragma unroll
     for (int m = 0; m < NX; ++m) X[0][m] = active ? (double)P.x0[b * NX + m] : 0.0;
@@ -100,6 +106,9 @@ __global__ __launch_bounds__(256, TMPC_LEAN_WAVES) void admm_lean_kernel(const A
 #pragma unroll
         for (int a = 0; a < NU; ++a) Y[k][a] = 0.f, Z[k][a] = 0.f, D[k][a] = (DT)0;
 
+#ifdef TMPC_LEAN_CLOCK_PROBE
+    const unsigned long long probe_t0 = __builtin_amdgcn_s_memtime(), probe_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     int it = 0, conv = 0;
     float res0 = 0.f, res1 = 0.f, res2 = 0.f, res3 = 0.f;
     const int ct = P.check_termination;
@@ -110,11 +119,18 @@ __global__ __launch_bounds__(256, TMPC_LEAN_WAVES) void admm_lean_kernel(const A
 
     // ================= fused forward sweep: forward_pass (admm.cpp:25-35) + update_slack (:43-59) + update_dual (:65-69)
     // (+ RES: the residual maxima of termination_condition, :93-96) =================
-    auto forward = [&](auto res_tag) {
+    auto forward = [&](auto res_tag, bool first_iter) {
         constexpr bool RES = decltype(res_tag)::value;
-        if constexpr (RES) dua_x = 0.0, pri_u = 0.f, dua_u = 0.f;
+        if constexpr (RES) {
+            dua_x = 0.0, pri_u = 0.f, dua_u = 0.f;
+            if (first_iter) {   // cold start: the previous state slack is the zero workspace at knot 0 too, where vnew is x0 (admm.cpp:94)
+#pragma unroll
+                for (int m = 0; m < NX; ++m) dua_x = fmax(dua_x, fabs(X[0][m]));
+            }
+        }
         sfor<0, N - 1>([&](auto kk) {
             constexpr int k = decltype(kk)::value;
+            if constexpr (!UBK) asm volatile("" ::: "memory");   // per-knot bounds are re-read from LDS at their knot, not hoisted out of the solve
             double dk[NU], u[NU], xn[NX];
 #pragma unroll
             for (int a = 0; a < NU; ++a) dk[a] = (double)D[k][a];
@@ -166,6 +182,9 @@ __global__ __launch_bounds__(256, TMPC_LEAN_WAVES) void admm_lean_kernel(const A
                 if constexpr (RES) dua_x = fmax(dua_x, fabs(X[k + 1][m] - xn[m]));   // v - vnew with v = the previous x  (:94)
                 X[k + 1][m] = xn[m];
             }
+            // (the residual maxima are only read under `!conv`: left alone, the compiler sinks the whole chain into that
+            // branch, behind the sweep, and keeps every knot's u, znew and previous x alive for it — 190 spilled registers)
+            if constexpr (RES) asm volatile("" : "+v"(pri_u), "+v"(dua_u), "+v"(dua_x));
             if constexpr (TMPC_LEAN_KNOT_BARRIER) __builtin_amdgcn_sched_barrier(0);
         });
     };
@@ -215,22 +234,30 @@ __global__ __launch_bounds__(256, TMPC_LEAN_WAVES) void admm_lean_kernel(const A
         });
     };
 
-    // solution = projected slack of the iteration (admm.cpp:187-188, :204-205); status of the instance
+    // solution = projected slack of the iteration (admm.cpp:187-188, :204-205); status of the instance.  This direct form
+    // (every lane its own instance: scattered 16-byte pieces) serves the instances that converge inside the loop, a few at
+    // a time; the final store below goes through LDS
     auto store = [&](bool solved_flag) {
+        // one opaque base address per array, constant offsets behind it: left to itself the compiler forms the 99 store
+        // addresses once, outside the iteration loop (the LIVE variant stores inside it), and spills 200 registers for them
+        float *xo = P.xout + b * EX, *uo = P.uout + b * EU, *ro = P.res + b * 4;
+        asm volatile("" : "+v"(xo), "+v"(uo), "+v"(ro));
 #pragma unroll
-        for (int k = 0; k < N; ++k)
+        for (int k = 0; k < N; ++k) {
 #pragma unroll
-            for (int m = 0; m < NX; ++m) P.xout[b * EX + k * NX + m] = (float)X[k][m];
+            for (int m = 0; m < NX; ++m) xo[k * NX + m] = (float)X[k][m];
+            __builtin_amdgcn_sched_barrier(0);   // (a knot's conversions next to its stores, not eighty temporaries up front)
+        }
 #pragma unroll
         for (int k = 0; k < N - 1; ++k)
 #pragma unroll
-            for (int a = 0; a < NU; ++a) P.uout[b * EU + k * NU + a] = Z[k][a];
+            for (int a = 0; a < NU; ++a) uo[k * NU + a] = Z[k][a];
         P.iter[b] = P.iter_offset + it;
         P.solved[b] = solved_flag ? 1 : 0;
-        P.res[b * 4 + 0] = res0;
-        P.res[b * 4 + 1] = res1;
-        P.res[b * 4 + 2] = res2;
-        P.res[b * 4 + 3] = res3;
+        ro[0] = res0;
+        ro[1] = res1;
+        ro[2] = res2;
+        ro[3] = res3;
     };
 
     // Iterations whose termination check can matter carry the residual arithmetic (every check when the tolerances are
@@ -248,13 +275,13 @@ __global__ __launch_bounds__(256, TMPC_LEAN_WAVES) void admm_lean_kernel(const A
         }
         const int n_plain = (next_res < max_iter ? next_res : max_iter) - i;
         for (int j = 0; j < n_plain; ++j) {
-            forward(std::false_type{});
+            forward(std::false_type{}, false);
             backward();
         }
         i += n_plain;
         if (!LIVE || !conv) it += n_plain;                                      // admm.cpp:143
         if (i >= max_iter) break;
-        forward(std::true_type{});
+        forward(std::true_type{}, i == 0);
         i += 1;
         if (!LIVE || !conv) {                                                   // termination_condition (admm.cpp:89-107)
             it += 1;
@@ -274,19 +301,119 @@ __global__ __launch_bounds__(256, TMPC_LEAN_WAVES) void admm_lean_kernel(const A
         }
         backward();
     }
-    if (active && !conv) store(false);
+    // ---- final store of every instance that has not stored at its convergence: through LDS, so that a store instruction
+    // writes whole 64-byte pieces (X: 16 consecutive floats of 4 instances) or one contiguous 256 bytes (U) instead of 64
+    // scattered 16-byte / 4-byte ones — with every wavefront finishing at once the scattered form took 50 us of a 300 us
+    // launch (26 MB at 0.5 TB/s) ----
+    {
+        const bool mine = active && !conv;
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(mine);
+        if (mask) {
+            float *so = s_stage[tid >> 6];
+            const long w0 = (long)blockIdx.x * 256 + (tid & ~63);          // the wavefront's first instance
+            float *__restrict__ xo = P.xout + w0 * EX, *__restrict__ uo = P.uout + w0 * EU;
+            const int sub = lane >> 4, off = lane & 15;
+            constexpr int NCH = (EX + 15) / 16;
+            // every instance of the wavefront stores (the usual case): no predicates; else bit `inst` of the mask decides
+            auto put_all = [&](auto full_tag) {
+                constexpr bool FULL = decltype(full_tag)::value;
+                sfor<0, NCH>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j)
+                        if (c * 16 + j < EX) so[lane * 17 + j] = (float)X[(c * 16 + j) / NX][(c * 16 + j) % NX];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    float v[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) v[j] = so[(4 * j + sub) * 17 + off];   // piece j: instances 4 j .. 4 j + 3, 16 floats each
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int inst = 4 * j + sub;
+                        const bool ok = (EX % 16 == 0 || c * 16 + off < EX) && (FULL || ((mask >> inst) & 1ull));
+                        if (ok) xo[inst * EX + c * 16 + off] = v[j];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                });
+#pragma unroll
+                for (int e = 0; e < EU; ++e) so[lane * (EU | 1) + e] = Z[e / NU][e % NU];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                float w[EU];
+#pragma unroll
+                for (int j = 0; j < EU; ++j) {                             // flat element f of the wavefront's 64 x EU controls
+                    const int f = j * 64 + lane;
+                    w[j] = so[(f / EU) * (EU | 1) + f % EU];
+                }
+#pragma unroll
+                for (int j = 0; j < EU; ++j) {
+                    const int f = j * 64 + lane;
+                    if (FULL || ((mask >> (f / EU)) & 1ull)) uo[f] = w[j];
+                }
+            };
+            if (mask == ~0ull) put_all(std::true_type{});
+            else put_all(std::false_type{});
+            if (mine) {
+                float *ro = P.res + b * 4;
+                P.iter[b] = P.iter_offset + it;
+                P.solved[b] = 0;
+                ro[0] = res0, ro[1] = res1, ro[2] = res2, ro[3] = res3;
+#ifdef TMPC_LEAN_CLOCK_PROBE
+                ro[0] = (float)(__builtin_amdgcn_s_memtime() - probe_t0);          // core clocks of the iteration loop (+ store issue)
+                ro[1] = (float)(__builtin_amdgcn_s_memrealtime() - probe_r0);      // ... in 100 MHz ticks
+                ro[2] = (float)(probe_entry & 0xFFFFFFull);                        // kernel entry on the chip-wide 100 MHz counter
+#endif
+            }
+        }
+    }
 
-    {   // global status block: wavefront max of the residuals, count of unsolved instances
+    {   // global status block: workgroup max of the residuals and count of unsolved instances, then ONE set of atomics per
+        // workgroup (fold_status's per-wavefront set: 1 024 wavefronts finishing together queue on five words)
         float m0 = active ? res0 : 0.f, m1 = active ? res1 : 0.f, m2 = active ? res2 : 0.f, m3 = active ? res3 : 0.f;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            m0 = fmaxf(m0, __shfl_xor(m0, off, 64));
-            m1 = fmaxf(m1, __shfl_xor(m1, off, 64));
-            m2 = fmaxf(m2, __shfl_xor(m2, off, 64));
-            m3 = fmaxf(m3, __shfl_xor(m3, off, 64));
+        for (int o = 1; o < 64; o <<= 1) {
+            m0 = fmaxf(m0, __shfl_xor(m0, o, 64));
+            m1 = fmaxf(m1, __shfl_xor(m1, o, 64));
+            m2 = fmaxf(m2, __shfl_xor(m2, o, 64));
+            m3 = fmaxf(m3, __shfl_xor(m3, o, 64));
         }
         const unsigned long long unsolved = __builtin_amdgcn_ballot_w64(active && !conv);
-        fold_status(P, m0, m1, m2, m3, __popcll(unsolved), tid);
+        if (lane == 0) {
+            s_fold[tid >> 6][0] = m0, s_fold[tid >> 6][1] = m1, s_fold[tid >> 6][2] = m2, s_fold[tid >> 6][3] = m3;
+            s_unsolved[tid >> 6] = __popcll(unsolved);
+        }
+#ifdef TMPC_LEAN_CLOCK_PROBE
+        if (active) P.iter[b] = (int)(__builtin_amdgcn_s_memrealtime() & 0xFFFFFFull);     // stores issued
+        __builtin_amdgcn_s_waitcnt(0);
+        if (active) P.solved[b] = (int)(__builtin_amdgcn_s_memrealtime() & 0xFFFFFFull);   // ... and acknowledged
+#endif
+        __syncthreads();
+        if (tid == 0) {
+            float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f;
+            int un = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                f0 = fmaxf(f0, s_fold[w][0]), f1 = fmaxf(f1, s_fold[w][1]), f2 = fmaxf(f2, s_fold[w][2]), f3 = fmaxf(f3, s_fold[w][3]);
+                un += s_unsolved[w];
+            }
+            atomicMax(&P.gacc[0], __float_as_uint(f0));
+            atomicMax(&P.gacc[1], __float_as_uint(f1));
+            atomicMax(&P.gacc[2], __float_as_uint(f2));
+            atomicMax(&P.gacc[3], __float_as_uint(f3));
+            if (un) atomicAdd(&P.gacc[4], (uint32_t)un);
+            __threadfence();  // this workgroup's contributions before its ticket
+            if (atomicAdd(&P.gacc[7], 1u) == gridDim.x - 1) {   // last workgroup: publish, hand the accumulator back zeroed (fold_status)
+                __threadfence();
+#pragma unroll
+                for (int i = 0; i < 5; ++i) P.gstat[i] = atomicExch(&P.gacc[i], 0u);
+                atomicExch(&P.gacc[6], 0u);
+                atomicExch(&P.gacc[7], 0u);
+            }
+        }
+#ifdef TMPC_LEAN_CLOCK_PROBE
+        if (active) P.res[b * 4 + 3] = (float)(__builtin_amdgcn_s_memrealtime() & 0xFFFFFFull);   // after the status fold
+#endif
     }
 }
 

@@ -8,13 +8,17 @@ namespace tmpc {
 template <int NX, int NU, int N>
 hipError_t launch_lean(const AdmmParams &P, bool live, bool knot_bounds, hipStream_t stream) {
     const int grid = (P.batch + 255) / 256;
-#define TMPC_LEAN_LAUNCH(LIVE_, UBK_) \
-    hipLaunchKernelGGL((admm_lean_kernel<NX, NU, N, LIVE_, UBK_>), dim3(grid), dim3(256), 0, stream, P)
+    const bool one = grid <= device_cu_count();   // at most one workgroup per CU = one wavefront per SIMD
+#define TMPC_LEAN_LAUNCH(LIVE_, UBK_, ONE_) \
+    hipLaunchKernelGGL((admm_lean_kernel<NX, NU, N, LIVE_, UBK_, ONE_>), dim3(grid), dim3(256), 0, stream, P)
+#define TMPC_LEAN_LAUNCH2(LIVE_, UBK_) \
+    do { if (one) TMPC_LEAN_LAUNCH(LIVE_, UBK_, true); else TMPC_LEAN_LAUNCH(LIVE_, UBK_, false); } while (0)
     if (live) {
-        if (knot_bounds) TMPC_LEAN_LAUNCH(true, false); else TMPC_LEAN_LAUNCH(true, true);
+        if (knot_bounds) TMPC_LEAN_LAUNCH2(true, false); else TMPC_LEAN_LAUNCH2(true, true);
     } else {
-        if (knot_bounds) TMPC_LEAN_LAUNCH(false, false); else TMPC_LEAN_LAUNCH(false, true);
+        if (knot_bounds) TMPC_LEAN_LAUNCH2(false, false); else TMPC_LEAN_LAUNCH2(false, true);
     }
+#undef TMPC_LEAN_LAUNCH2
 #undef TMPC_LEAN_LAUNCH
     return hipGetLastError();
 }
