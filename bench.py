@@ -94,6 +94,12 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the `configs` block (configs 3, 4, 5-shard)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--sharded-capi", action="store_true",
+                    help="ONE process drives all --gpus devices through the in-process multi-GPU handle of the C-ABI "
+                         "(tinympc_create_sharded: what a Julia host uses) instead of one process per GPU")
+    ap.add_argument("--devices", default=None,
+                    help="--sharded-capi: comma-separated device of every shard (default 0..gpus-1); repeating a device, "
+                         "e.g. 0,0, rehearses the multi-shard path on a one-GPU box (host status fold)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo only with --dry")
     ap.add_argument("--dry", action="store_true", help="no GPU, no solver: rehearse launch, sharding and status fold")
     return ap.parse_args(argv)
@@ -147,6 +153,7 @@ def make_workload(t, name, batch, seed, lo=0, hi=None):
 def build_solver(t, name, prob, x0, refs, device, iters, tol, check, precision, compaction=0):
     bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=x0.shape[1], device=device)
     bs.update_settings(abs_pri_tol=tol, abs_dua_tol=tol, max_iter=iters, check_termination=check)
+    bs._bench_check, bs._bench_tol = check, tol
     bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
     bs.set_precision(precision)
     if name == "rocket_soc":
@@ -197,6 +204,14 @@ def committed_counters(family, precision, batch, kernel):
     return out
 
 
+def bs_check_interval(bs):
+    return int(getattr(bs, "_bench_check", 1))
+
+
+def bs_can_converge(bs):
+    return bool(getattr(bs, "_bench_tol", 0.0) > 0.0)
+
+
 def roofline_of(bs, family, precision, batch, iters_done, k_ms):
     """roofline + valu objects of one configuration from its kernel time.  Bytes and FLOPs are SURVEY 8(d)'s
     algorithmic figures (state on chip) x the instances x iterations of one launch."""
@@ -204,7 +219,8 @@ def roofline_of(bs, family, precision, batch, iters_done, k_ms):
     alg_flops = bs.algorithmic_flops(1) * iters_done
     sec = k_ms * 1e-3
     ach_gbs, ach_tf = alg_bytes / sec / 1e9, alg_flops / sec / 1e12
-    cc = committed_counters(family, precision, batch, bs.kernel_name)
+    launched = bs.last_launch_name            # the family's kernel or the variant this calling pattern took (e.g. lean<4,1,20>)
+    cc = committed_counters(family, precision, batch, launched)
     hbm = {"achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS}
     # What bounds the path is instruction issue (~430-950 FLOP/B against a machine balance of ~20), so the
     # dominant kernel is priced in FLOP/s.  `frac` keeps SURVEY 8(d)'s definition for every round — algorithmic FLOPs (all of
@@ -226,21 +242,49 @@ def roofline_of(bs, family, precision, batch, iters_done, k_ms):
             "necessary_fma_flops_per_launch": matvec_flops,
             "algorithmic_flops_per_launch": alg_flops,
             "issue_utilisation": cc["valu_issue"], "counters_source": cc.get("sq_source")}
+    # FLOPs of the phases the kernel that ran actually executes (SURVEY 8a's rows, the same counting as algorithmic_flops):
+    # a variant may elide work that cannot change the result — the lean kernel has no state clamp / state dual (no active
+    # state bound: 3 + 2 per state element less), forms the linear cost without the products by rho, and both kernels skip the
+    # residual maxima (6 per element) on iterations whose check cannot matter
+    E = nx * N + nu * (N - 1)
+    per_iter = {"a2_forward_pass": 2.0 * (N - 1) * (nx * nx + 2 * nx * nu),
+                "a7_backward_pass_grad": 2.0 * (N - 1) * (nx * nx + 2 * nx * nu + nu * nu) + (N - 1) * (nu + 2 * nx),
+                "a3_update_slack": 3.0 * E, "a4_update_dual": 2.0 * E, "a5_update_linear_cost": 4.0 * E + 2.0 * nx * nx + 3 * nx,
+                "a6_termination_condition": 6.0 * E}
+    executed = dict(per_iter)
+    check_every = bs_check_interval(bs)
+    can_converge = bs_can_converge(bs)
+    res_share = (1.0 / check_every if can_converge else 1.0 / max(1.0, iters_done)) if check_every > 0 else 0.0
+    executed["a6_termination_condition"] *= res_share
+    if launched.startswith("lean"):
+        executed["a3_update_slack"] = 3.0 * nu * (N - 1)                 # input clamp only: vnew = x
+        executed["a4_update_dual"] = 2.0 * nu * (N - 1)                  # y only: g stays 0
+        executed["a5_update_linear_cost"] = 1.0 * nu * (N - 1)           # r~ = znew - y; q~ = x itself
+        executed["a6_termination_condition"] = (2.0 * nx * (N - 1) + 4.0 * nu * (N - 1)) * res_share
+        executed["a7_backward_pass_grad"] = 2.0 * (N - 1) * (nx * nx + 2 * nx * nu + nu * nu) - 2.0 * nx * (nx + nu)   # p_0 is never formed
+    ex_flops = sum(executed.values()) * batch * iters_done
+    roof["executed_frac"] = ex_flops / sec / 1e12 / roof["peak"]
+    roof["executed_flops_per_launch"] = ex_flops
+    roof["executed_note"] = ("FLOPs of the phases this kernel variant executes (elided: " +
+                             ("state clamp / state dual / products by rho (no active state bound), " if launched.startswith("lean") else "") +
+                             f"residual maxima on {100.0 * (1.0 - res_share):.0f} % of the iterations) over the same peak as `frac`")
     if cc["valu_insts"]:
         # upper bound of what the VALU executed: every wave64 VALU instruction counted as one FMA on 64 lanes
         valu["executed_flops_upper_bound"] = cc["valu_insts"] * 128.0
         valu["executed_frac_of_fp64_vector_peak"] = cc["valu_insts"] * 128.0 / sec / 1e12 / FP64_PEAK_TFLOPS
-    if bs.kernel_name.startswith("mfma"):
+    if launched.startswith("mfma"):
         roof.update({"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": ach_tf / FP64_PEAK_TFLOPS, "frac_of_fp32_vector_peak": ach_tf / FP32_PEAK_TFLOPS,
                      "issue_utilisation": cc["mfma_issue"],
                      "counters_source": cc.get("sq_source"),
                      "note": "algorithmic FLOPs (SURVEY 8d) over the dense fp64 matrix-core peak; tiles are padded, so the "
                              "issued MFMA FLOPs are higher (DESIGN.md, mfma kernel)"})
-    if bs.kernel_name.startswith("stream"):
+    if launched.startswith("stream"):
         roof.update({"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS})
         roof["note"] = ("run-time-horizon kernel: the per-instance trajectories stream through HBM once per ADMM iteration "
                         "(traffic >> algorithmic bytes, by design of that kernel; DESIGN.md 3.2)")
+    roof["executed_frac"] = roof["executed_flops_per_launch"] / sec / 1e12 / (roof["peak"] if roof["unit"] == "TFLOP/s" else FP32_PEAK_TFLOPS)
+    roof["kernel"] = launched
     return roof, valu
 
 
@@ -310,9 +354,14 @@ def cpu_baseline(prob, x0, refs, iters, seconds):
 # extra configurations (one GPU): configs 3, 4 and one shard of config 5
 # ----------------------------------------------------------------------------------------------------------------------
 def time_config(t, torch, dev, stream, name, batch, seed, iters=100, tol=0.0, check=1, steps=5, warmup=2, compaction=0,
-                adaptive=False, keep_workspace=False):
+                adaptive=False, keep_workspace=False, state_bound=None):
     import numpy as np
     prob, x0, refs, label = make_workload(t, name, batch, seed)
+    if state_bound is not None:       # a finite bound on state row 0: the state clamp and the state dual are live (a3 / a4 at full cost)
+        prob.x_max = prob.x_max.copy()
+        prob.x_min = prob.x_min.copy()
+        prob.x_max[0, :], prob.x_min[0, :] = state_bound, -state_bound
+        label += f", |x_0| <= {state_bound:g} at every knot"
     bs = build_solver(t, name, prob, x0, refs, dev.index, iters, tol, check, 0, compaction)
     if adaptive:
         bs.set_adaptive_rho(True)
@@ -339,7 +388,7 @@ def time_config(t, torch, dev, stream, name, batch, seed, iters=100, tol=0.0, ch
         if compaction > 0 and tol > 0.0:
             k_ms, launches_per_step = ms, None      # several launches + compaction kernels per solve: wall time is the figure
         roof, valu = roofline_of(bs, name, 0, batch, it_mean, k_ms if k_ms > 0 else ms)
-        if adaptive or keep_workspace or tol != 0.0:
+        if adaptive or keep_workspace or tol != 0.0 or state_bound is not None:
             # the committed counter passes are of the plain cold fixed-iteration launch of the family: another kernel variant /
             # calling pattern moves other bytes and issues other instructions
             roof["traffic"], roof["traffic_source"] = None, "not profiled in this calling pattern"
@@ -350,7 +399,7 @@ def time_config(t, torch, dev, stream, name, batch, seed, iters=100, tol=0.0, ch
         out = {"workload": f"{label}, batch={batch}, " + (f"tol={tol:g} check every {check}, max_iter={iters}" if tol > 0
                                                          else f"fixed {iters} ADMM iters") +
                            (", workspace kept between solves (warm start)" if keep_workspace else ", cold start"),
-               "ms_per_step": ms, "solves_per_sec": batch / (ms * 1e-3), "kernel": bs.kernel_name, "kernel_ms": k_ms,
+               "ms_per_step": ms, "solves_per_sec": batch / (ms * 1e-3), "kernel": bs.last_launch_name, "kernel_family": bs.kernel_name, "kernel_ms": k_ms,
                "mean_iters": it_mean, "unsolved": int((st["solved"] == 0).sum()) if tol > 0 else None,
                "roofline": roof, "valu": valu, "steps": steps}
         if launches_per_step is None:
@@ -387,11 +436,94 @@ def run_mpc_mode(args, bs, prob, x0, dev, torch):
     return res
 
 
+def run_sharded_capi(args):
+    """`--sharded-capi`: the batch over `--gpus` devices of one node from ONE host process, through tinympc_create_sharded
+    (include/tinympc_hip.h section 3) — per-shard solvers and streams, inputs scattered / outputs gathered by offset, the
+    status block all-reduced over RCCL (host fold when shards share a device).  A step = one tinympc_sharded_solve: enqueue
+    on every shard, wait for all, fold the status.  Same JSON line as the one-process-per-GPU path, plus the per-shard
+    kernel times and the fold backend."""
+    import numpy as np
+    import tinympc_julia_amd as t
+    devices = [int(d) for d in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    if len(devices) != args.gpus:
+        raise SystemExit(f"bench.py: --devices names {len(devices)} shards but --gpus is {args.gpus}")
+    name = args.config or ("quadrotor" if args.scaling == "strong" else "cartpole")
+    tol = float(args.tol)
+    check = args.check_termination or (10 if tol > 0 else 1)
+    n = len(devices)
+    total = (args.batch or STRONG_TOTAL) if args.scaling == "strong" else (args.batch or default_batch(name)) * n
+    seed = 3 if args.scaling == "strong" else {"cartpole": 0, "quadrotor": 1}.get(name, 2)
+    prob, x0, refs, label = make_workload(t, name, total, seed)
+    sh = t.ShardedBatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=total, devices=devices)
+    sh.update_settings(abs_pri_tol=tol, abs_dua_tol=tol, max_iter=args.iters, check_termination=check)
+    sh.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    sh.set_precision(args.precision)
+    sh.set_warm_start(False)
+    if args.compaction > 0:
+        sh.set_compaction(args.compaction)
+    sh.set_x0(x0)
+    if refs is not None:
+        sh.set_x_ref(refs[0])
+        sh.set_u_ref(refs[1])
+    handles = [sh.shard(i)[3] for i in range(n)]
+    for h in handles:
+        sh.lib.tinympc_set_profiling(h, 1)
+    t_warm = time.perf_counter()
+    while time.perf_counter() - t_warm < 0.15:      # clock pre-warm (set-up, not a step)
+        sh.solve()
+    for _ in range(args.warmup):
+        sh.solve()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        status = sh.solve()                          # synchronous: every shard done, status folded
+    elapsed = time.perf_counter() - t0
+    k_ms = [float(sh.lib.tinympc_kernel_elapsed_mean_ms(h, args.steps)) for h in handles]
+    st = sh.get_status()
+    if tol <= 0.0:
+        assert int(st["iter"].min()) == args.iters == int(st["iter"].max()), "work skipped"
+    res, unsolved = sh.global_status()
+    it_mean = float(np.mean(st["iter"]))
+    ms = 1e3 * elapsed / args.steps
+    how = (f"tol={tol:g}, check every {check}, max_iter={args.iters}" if tol > 0 else f"fixed {args.iters} ADMM iters")
+    kmax = max(k_ms)
+    per_shard = [sh.shard(i)[2] - sh.shard(i)[1] for i in range(n)]
+    one = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=1, device=devices[0])   # (the formulas' carrier)
+    alg_bytes = one.algorithmic_bytes() * max(per_shard)
+    alg_flops = one.algorithmic_flops(1) * it_mean * max(per_shard)
+    one.close()
+    peak = FP64_PEAK_TFLOPS if sh.kernel_names()[0].startswith("mfma") else FP32_PEAK_TFLOPS
+    out = {"metric": "qp_solves_per_sec", "value": total * args.steps / elapsed, "unit": "solves/s", "n_gpus": n,
+           "library_sha256": LIB_HASH, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+           "scaling": args.scaling, "vs_baseline": None, "dtype": "f32" if args.precision == 1 else "f32 (f64 recurrences)",
+           "data": "synthetic", "mode": "sharded_capi",
+           "config": {"workload": f"{label}, batch={total} in {n} contiguous shards of {per_shard[0]}, {how}, cold start",
+                      "family": name, "batch_per_gpu": per_shard[0], "batch_total": total, "admm_iters_per_solve": args.iters,
+                      "kernel": sh.kernel_names()[0], "devices": devices,
+                      "sharding": f"ONE process, tinympc_create_sharded over {n} shard(s); status fold by {sh.fold_backend} after every solve"},
+           "fold_backend": sh.fold_backend, "shard_kernel_ms": {"min": min(k_ms), "max": kmax, "all": k_ms},
+           "host_overhead_ms_per_step": ms - kmax if len(set(devices)) == n else None,
+           "admm_iters_per_sec": float(np.sum(st["iter"], dtype=np.float64)) * args.steps / elapsed,
+           "solve_status": status, "mean_iters": it_mean, "global_residual_maxima": [float(v) for v in res],
+           "roofline": {"bound": "mfma" if peak == FP64_PEAK_TFLOPS else "valu_fp64", "achieved": alg_flops / (kmax * 1e-3) / 1e12,
+                        "peak": peak, "unit": "TFLOP/s", "frac": alg_flops / (kmax * 1e-3) / 1e12 / peak, "kernel_ms": kmax,
+                        "hbm": {"achieved": alg_bytes / (kmax * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": alg_bytes / (kmax * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                        "traffic": None, "note": "per device: the slowest shard's kernel (HIP events on the shard's stream) against one GPU's peak"}}
+    if len(set(devices)) != n:
+        out["note"] = "shards share a device (rehearsal of the multi-shard path on fewer GPUs): they run one after the other"
+    sh.close()
+    print(json.dumps(out), flush=True)
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.sharded_capi:
+        if args.dry:
+            raise SystemExit("--sharded-capi has no dry mode: rehearse it on one GPU with --gpus 2 --devices 0,0")
+        return run_sharded_capi(args)
     if args.backend == "gloo" and not args.dry:
         raise SystemExit("--backend gloo is the CPU rehearsal: use it with --dry (the solver has no CPU path)")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -555,11 +687,14 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": avg_step_ms,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             # (precision 1 asks for fp32 recurrences; shapes with a matrix-core kernel run fp64 recurrences all the same — faster there)
-            "dtype": ("f32" if args.precision == 1 and not (not args.dry and bs.kernel_name.startswith("mfma")) else "f32 (f64 recurrences)"),
+            "dtype": ("f32" if args.precision == 1 and not (not args.dry and bs.kernel_name.startswith("mfma")) else
+                      ("f64 recurrences and state trajectory, f32 input slack / dual" if (not args.dry and bs.last_launch_name.startswith("lean"))
+                       else "f32 (f64 recurrences)")),
             "data": "synthetic",
             "config": {"workload": f"{label}, {shard}, {how}, cold start", "family": name,
                        "batch_per_gpu": n_local, "batch_total": total, "admm_iters_per_solve": args.iters,
-                       "kernel": None if args.dry else bs.kernel_name,
+                       "kernel": None if args.dry else bs.last_launch_name,
+                       "kernel_family": None if args.dry else bs.kernel_name,
                        "sharding": f"batch-sharded x{world}, no data-path collective; status all-reduce "
                                    + ("every step" if every_step else "once") + (" (RCCL)" if not args.dry else " (gloo, dry)")},
             "admm_iters_per_sec": iters_total * args.steps / elapsed,
@@ -585,6 +720,11 @@ def main():
             and args.scaling == "weak" and tol <= 0 and args.mode == "solve":
         # BASELINE configs[2], [3] and one rank's shard of configs[4]; a few hundred ms in total
         ex = {}
+        # the headline workload with the work its benched variant elides switched on: the termination check live at every
+        # iteration (tolerances of 1e-30: nobody converges, every residual is formed every iteration), and a finite state bound
+        # (state clamp + state dual live; runs on the quad kernel)
+        ex["cartpole_65536_check_every_iteration"] = time_config(t, torch, dev, stream, "cartpole", 65536, 0, tol=1e-30)
+        ex["cartpole_65536_state_bound"] = time_config(t, torch, dev, stream, "cartpole", 65536, 0, state_bound=0.45)
         ex["quadrotor_65536"] = time_config(t, torch, dev, stream, "quadrotor", 65536, 1)
         ex["rocket_soc_32768"] = time_config(t, torch, dev, stream, "rocket_soc", 32768, 2)
         ex["rocket_soc_32768_workspace_kept"] = time_config(t, torch, dev, stream, "rocket_soc", 32768, 2, keep_workspace=True)

@@ -257,8 +257,23 @@ int tinympc_set_profiling(tinympc_solver *s, int enable);
 double tinympc_kernel_elapsed_ms(tinympc_solver *s);
 double tinympc_kernel_elapsed_mean_ms(tinympc_solver *s, int last_n);
 /* Arithmetic of the two serial recurrences (rollout, Riccati gradient): 0 = fp64 accumulation
- * with fp64 coefficients (default; ADMM state and elementwise steps stay fp32), 1 = all fp32. */
+ * with fp64 coefficients (default; ADMM state and elementwise steps stay fp32), 1 = all fp32,
+ * 2 = all fp64 — the reference's own arithmetic end to end (types.hpp:15): recurrences, slacks, duals, residual
+ * comparisons and the workspace kept between solves in fp64, on the generic kernel (any shape and option set of the
+ * single-family solvers; no fused closed loop); x0 / references / bounds go in and the solution comes out as the fp32
+ * device arrays.  It is the mode for callers who need the reference's digits rather than the 1e-5 of the fp32-state
+ * kernels (families whose duals lose digits to fp32 rounding miss 1e-5 there); it is the slowest path of the library.
+ * Switching to or from precision 2 restarts the workspace cold.
+ * precision = 1 is a request to save time and does NOT meet the 1e-5 parity target on every instance (3 of the 65 536
+ * benchmark cartpole instances miss it, worst 1.6e-5).  Where a shape has a matrix-core kernel that kernel is faster than the
+ * fp32 one, so such solves run there — with fp64 recurrences — unless tinympc_set_strict_precision(s, 1) insists on fp32.
+ * tinympc_effective_precision returns the recurrence precision (0 / 1) the solver's current options run with. */
 int tinympc_set_precision(tinympc_solver *s, int precision);
+int tinympc_set_strict_precision(tinympc_solver *s, int strict);
+/* Tuning / test aid.  The TINYMPC_HIP_* environment switches are read ONCE, when a solver is created —
+ * nothing on the solve path calls getenv; this re-reads them for a live solver. */
+int tinympc_reload_switches(tinympc_solver *s);
+int tinympc_effective_precision(tinympc_solver *s);
 /* Name of the kernel family the solver's shape / options select: "quad<nx,nu,N,gG>", "mfma<...>", "mfmat<...>",
  * "stream4<nx,nu>", "generic", ... */
 const char *tinympc_kernel_name(tinympc_solver *s);
@@ -271,6 +286,14 @@ const char *tinympc_last_launch_name(tinympc_solver *s);
 double tinympc_algorithmic_bytes(tinympc_solver *s);
 double tinympc_algorithmic_flops(tinympc_solver *s, int iters);
 const char *tinympc_last_error(void);
+/* Specialisation at setup.  The reference takes any (nx, nu, N) at run time (tiny_api.cpp:21-71); the on-chip kernels here are
+ * compiled per shape.  For a shape the library was not built with, tinympc_create / setup_solver compile the one instantiation
+ * that suits it (hipcc as a child process, from the library's own csrc/ headers), cache it under $TINYMPC_HIP_CACHE or
+ * ~/.cache/tinympc_hip/<source hash>/ and load it; the time of the one-off compile is printed on stderr.  Without a
+ * compiler or the sources, when the shape's state does not fit the chip, or with TINYMPC_HIP_NO_JIT=1, such a solver runs
+ * on the run-time-shape kernels (stream / generic) as before.  This entry point does the same ahead of time (no GPU needed):
+ * returns 1 if an on-chip kernel exists for the shape afterwards, 0 if not. */
+int tinympc_specialise(int nx, int nu, int N, int verbose);
 /* Host-only fp64 part of setup() — the infinite-horizon Riccati precompute of
  * tiny_precompute_and_set_cache (tiny_api.cpp:124-190, incl. the rho-twice quirk of
  * tiny_setup :90-91,113).  Needs no GPU.  Outputs column-major: Kinf nu x nx, Pinf nx x nx,

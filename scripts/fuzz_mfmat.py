@@ -3,7 +3,9 @@ compiled horizons, the compiled cone layout on either / both / neither side, per
 shared references, with / without the affine term, fixed-iteration and tolerance-terminated settings, and — per case — one of
 three calling patterns: cold one-shot; TWO consecutive solves with the workspace kept (second x0 = the plant's next state),
 each compared with a persistent oracle including the workspace; a fused closed loop of a few steps against the oracle loop.
-Usage: python scripts/fuzz_mfmat.py [first_seed] [n_cases]"""
+Usage: python scripts/fuzz_mfmat.py [first_seed] [n_cases]
+PRECISION=2 in the environment runs every case with tinympc_set_precision(s, 2) (fp64 end to end, generic kernel) at the plain
+1e-5 of the suite — the closed-loop pattern then stepped from the host (precision 2 has no fused loop)."""
 import numpy as np, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tinympc_julia_amd as t
@@ -11,7 +13,9 @@ from oracle import cpu_oracle
 from tests.util import parity_every_instance, nrel, FP32_TOL
 
 
-def one(seed):
+def one(seed, precision=0, tol=None):
+    tol = tol if tol is not None else (1e-5 if precision == 2 else 2e-5)      # solution
+    tol_ws, tol_step = (tol, tol) if precision == 2 else (4e-5, 3e-5)            # workspace arrays / closed-loop steps
     rng = np.random.default_rng(seed)
     nx, nu = 6, 3
     N = int(rng.choice([10, 20, 30, 50]))
@@ -57,6 +61,7 @@ def one(seed):
     if cones is not None: bs.set_cone_constraints(*cones)
     if xr is not None: bs.set_x_ref(xr); bs.set_u_ref(ur)
     bs.set_warm_start(pattern != "one_shot")
+    bs.set_precision(precision)
     tag = f"seed {seed} N={N} B={B} {pattern} cones={cones is not None} fdyn={fdyn is not None} refs={refs} {kw}"
     ok, name = True, None
     try:
@@ -69,7 +74,7 @@ def one(seed):
                 o.close()
             bs.set_x0(x0); bs.solve(); name = bs.kernel_name
             parity_every_instance(bs.get_solution(), bs.get_status(), dict(x=X, u=U, iter=it, solved=so, res=res), mk, x0, kw, prob.rho,
-                                  tol=2e-5, min_same=0.0, tag=tag)
+                                  tol=tol, min_same=0.0, tag=tag)
         elif pattern == "workspace":
             orcs = [mk() for _ in range(B)]
             x = x0.copy()
@@ -89,17 +94,27 @@ def one(seed):
                         o.solve(); o.set_forced_exit(0); r = o.get_solution()
                     sv = o.get_state()
                     ex_, eu_ = nrel(sol["states"][:, :, b], r["x"]), nrel(sol["controls"][:, :, b], r["u"])
-                    assert ex_ <= 2e-5 and eu_ <= 2e-5, f"{tag} solve {k} instance {b}: x {ex_:.3e} u {eu_:.3e}"
+                    assert ex_ <= tol and eu_ <= tol, f"{tag} solve {k} instance {b}: x {ex_:.3e} u {eu_:.3e}"
                     for key in ("d", "y", "g", "v", "z"):
                         e_ = np.abs(ws[key][:, :, b] - sv[key]).max() / max(np.abs(sv[key]).max(), 1e-2)
-                        assert e_ <= 4e-5, f"{tag} solve {k} instance {b} workspace {key}: {e_:.3e}"
+                        assert e_ <= tol_ws, f"{tag} solve {k} instance {b} workspace {key}: {e_:.3e}"
                     xn[:, b] = prob.A @ x[:, b] + prob.B @ r["u"][:, 0] + f
                 x = xn
             for o in orcs: o.close()
         else:
             steps = 4
             log = None
-            bs.set_x0(x0); log = bs.mpc_rollout(steps); name = bs.kernel_name
+            if precision == 2:      # no fused loop: the same loop stepped from the host (x+ = A x + B u0 + f in fp64 here)
+                log = dict(u=np.zeros((nu, steps, B)), x=np.zeros((nx, steps, B)), iter=np.zeros((steps, B), dtype=int), solved=np.zeros((steps, B), dtype=int))
+                xh = x0.copy()
+                for k in range(steps):
+                    bs.set_x0(xh); bs.solve(); name = bs.kernel_name
+                    u0 = bs.get_solution()["controls"][:, 0, :]
+                    sth = bs.get_status()
+                    xh = prob.A @ xh + prob.B @ u0 + f[:, None]
+                    log["u"][:, k, :], log["x"][:, k, :], log["iter"][k], log["solved"][k] = u0, xh, sth["iter"], sth["solved"]
+            else:
+                bs.set_x0(x0); log = bs.mpc_rollout(steps); name = bs.kernel_name
             for b in range(B):
                 o = mk(); x = x0[:, b].copy()
                 for k in range(steps):
@@ -108,7 +123,7 @@ def one(seed):
                     x = prob.A @ x + prob.B @ r["u"][:, 0] + f
                     eu_ = np.abs(log["u"][:, k, b] - r["u"][:, 0]).max() / max(np.abs(r["u"]).max(), 1e-3)
                     ex_ = np.abs(log["x"][:, k, b] - x).max() / max(np.abs(x).max(), 1e-3)
-                    assert eu_ <= 3e-5 and ex_ <= 3e-5, f"{tag} step {k} instance {b}: u0 {eu_:.3e} x+ {ex_:.3e}"
+                    assert eu_ <= tol_step and ex_ <= tol_step, f"{tag} step {k} instance {b}: u0 {eu_:.3e} x+ {ex_:.3e}"
                 o.close()
     except AssertionError as e:
         ok = False
@@ -123,7 +138,7 @@ if __name__ == "__main__":
     cpu_oracle.build(port=True, ref=False) if not os.path.isfile(cpu_oracle.PORT_LIB) else None
     tally = {}
     for seed in range(first, first + n):
-        name, pattern, ok = one(seed)
+        name, pattern, ok = one(seed, precision=int(os.environ.get("PRECISION", "0")))
         key = (name, pattern)
         tally.setdefault(key, [0, 0])
         tally[key][0 if ok else 1] += 1

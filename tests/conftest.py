@@ -8,6 +8,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# Shapes the library was not built with are specialised at setup (csrc/jit.cpp: a one-off hipcc run per shape).  The suite pins
+# which kernel takes which shape, and uses dozens of odd shapes to reach the run-time-shape kernels: off here, on in the tests
+# of the specialisation itself (tests/test_jit.py).
+os.environ.setdefault("TINYMPC_HIP_NO_JIT", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -56,6 +56,40 @@ def test_gpus_2_on_two_real_devices():
     assert d["value"] > 1.0e8 and not d.get("dry")            # two GPUs' worth of the one-GPU rate (1.8e8 each)
 
 
+@pytest.mark.gpu
+def test_sharded_capi_mode_rehearsed_on_one_device():
+    """`bench.py --sharded-capi`: ONE process drives every device through tinympc_create_sharded (the path a Julia host
+    uses).  Rehearsed on the one GPU of this box with two shards placed on device 0 (host fold): the same JSON contract,
+    plus the per-shard kernel times and the fold backend; tolerance-terminated config 5 style and the fixed headline."""
+    p, lines = _run("--sharded-capi", "--gpus", "2", "--devices", "0,0", "--steps", "3", "--warmup", "1", "--batch", "24576")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["mode"] == "sharded_capi" and d["fold_backend"] == "host" and d["scaling"] == "weak"
+    assert d["config"]["batch_total"] == 49152 and d["config"]["batch_per_gpu"] == 24576 and d["config"]["devices"] == [0, 0]
+    assert d["value"] > 0 and len(d["shard_kernel_ms"]["all"]) == 2 and d["shard_kernel_ms"]["min"] > 0
+    assert d["solve_status"] == 1 and d["mean_iters"] == 100
+    p, lines = _run("--sharded-capi", "--gpus", "2", "--devices", "0,0", "--scaling", "strong", "--batch", "8192", "--tol", "1e-3",
+                    "--steps", "2", "--warmup", "1")
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads(lines[-1])
+    assert d["config"]["family"] == "quadrotor" and d["config"]["batch_total"] == 8192 and d["config"]["batch_per_gpu"] == 4096
+    assert 10 <= d["mean_iters"] < 100 and d["config"]["kernel"] == "mfma<12,4,30>"
+    # a real multi-device run of this mode (RCCL fold) needs >= 2 GPUs: first multi-GPU lease
+    import torch
+    if torch.cuda.device_count() >= 2:
+        p, lines = _run("--sharded-capi", "--gpus", "2", "--steps", "3", "--warmup", "1")
+        assert p.returncode == 0, p.stderr[-2000:]
+        assert json.loads(lines[-1])["fold_backend"] == "rccl"
+
+
+def test_sharded_capi_refuses_dry_and_bad_device_lists():
+    p, _ = _run("--sharded-capi", "--gpus", "2", "--dry")
+    assert p.returncode != 0 and "no dry mode" in (p.stderr + p.stdout)
+    p, _ = _run("--sharded-capi", "--gpus", "2", "--devices", "0,0,0")
+    assert p.returncode != 0
+
+
 def test_world_size_mismatch_is_refused():
     # a launcher that started a different number of ranks than --gpus says
     p, _ = _run("--gpus", "2", "--dry", "--backend", "gloo", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})

@@ -1181,11 +1181,14 @@ def test_config4_persistent_tiles_tolerance_terminated(hip_lib, oracle_built):
 
 
 def test_config5_shard_tolerance_terminated(hip_lib, oracle_built):
-    """BASELINE config 5 as one rank sees it: a 2^17-instance shard of the 2^20 quadrotor batch (seed 3),
+    """BASELINE config 5 as one rank sees it: rank 5's 2^17-instance shard of the 2^20 quadrotor batch (seed 3; columns
+    [5 x 2^17, 6 x 2^17) of the big batch),
     tolerance-terminated with check_termination = 10 — every instance against the fp64 oracle, iteration
     counts multiples of the check interval, per-instance early exit."""
     B = 2 ** 17
-    prob, x0 = t.problems.quadrotor(30), t.problems.quadrotor_x0(B, seed=3)
+    lo, hi = t.shard_range(2 ** 20, 8, 5)                    # rank 5's contiguous shard of the 2^20 batch
+    prob, x0 = t.problems.quadrotor(30), np.asfortranarray(t.problems.quadrotor_x0(2 ** 20, seed=3)[:, lo:hi])
+    assert x0.shape[1] == B
     kw = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=10)
     ref = _oracle_batch(oracle_built, prob, x0, nthreads=len(os.sched_getaffinity(0)), **kw)
     bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
@@ -1390,6 +1393,7 @@ def test_kernel_selection_by_batch(hip_lib, monkeypatch):
     bs.solve()
     assert bs.kernel_name == "mfma<12,4,30>"
     monkeypatch.setenv("TINYMPC_HIP_STRICT_FP32", "1")    # all-fp32 recurrences: not what the fp64 matrix cores run
+    bs.reload_switches()                                  # (the environment is read once, at creation)
     bs.solve()
     assert bs.kernel_name == "quad<12,4,30,g4>"
     bs.close()

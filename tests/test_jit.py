@@ -1,0 +1,117 @@
+"""Specialisation at setup (csrc/jit.cpp): the on-chip kernel of a shape the library was not built with is compiled once
+(hipcc, a child process, from the library's own csrc/ headers), cached and loaded — the reference accepts any (nx, nu, N)
+at run time (tiny_api.cpp:21-71) and should not fall to the HBM-streaming kernel for it.
+CPU part: the unit compiles, links against the library, loads, and exports an entry (no GPU needed: hipcc cross-compiles).
+GPU part: quadrotor N = 12 (matrix-core kernel) and an (8, 2, 25) family (four lanes per instance) against the fp64 oracle,
+with the calling patterns their built-in neighbours are tested with."""
+import os
+
+import numpy as np
+import pytest
+
+import tinympc_julia_amd as t
+from tests.util import FP32_TOL, nrel_batch, parity_every_instance
+
+
+@pytest.fixture
+def jit_on(monkeypatch, tmp_path_factory):
+    monkeypatch.delenv("TINYMPC_HIP_NO_JIT", raising=False)
+    # one cache for the whole test session (a unit is compiled once), outside the home directory
+    cache = os.environ.get("TINYMPC_TEST_JIT_CACHE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "jit_cache")
+    os.makedirs(cache, exist_ok=True)
+    monkeypatch.setenv("TINYMPC_HIP_CACHE", os.path.abspath(cache))
+    return os.path.abspath(cache)
+
+
+def test_specialise_compiles_links_and_loads_a_unit(hip_lib, jit_on):
+    """(3, 1, 6): no built-in kernel -> quad<3,1,6,g4> is compiled (tens of seconds, once), loaded, and found again"""
+    import glob
+    assert t.specialise(4, 1, 20) is True                      # built in: nothing to do
+    assert t.specialise(3, 1, 6, verbose=True) is True
+    units = glob.glob(os.path.join(jit_on, "*", "quad_3_1_6_g4.so"))
+    assert len(units) == 1 and os.path.getsize(units[0]) > 10000
+    assert t.specialise(3, 1, 6) is True                       # from the process's table now
+    assert t.specialise(20, 6, 10) is False                    # beyond what a lane group / tile holds: run-time-shape kernels
+
+
+def test_no_jit_switch_and_missing_compiler(hip_lib, monkeypatch, tmp_path):
+    monkeypatch.setenv("TINYMPC_HIP_CACHE", str(tmp_path))
+    monkeypatch.setenv("TINYMPC_HIP_NO_JIT", "1")
+    assert t.specialise(5, 2, 7) is False
+    monkeypatch.delenv("TINYMPC_HIP_NO_JIT")
+    monkeypatch.setenv("TINYMPC_HIP_HIPCC", "/nonexistent/hipcc")
+    assert t.specialise(5, 2, 7) is False                      # no compiler: fall back, no error
+
+
+def _random_family(nx, nu, N, seed):
+    rng = np.random.default_rng(seed)
+    A = np.eye(nx) + 0.2 * rng.standard_normal((nx, nx)) / np.sqrt(nx)
+    A *= 0.97 / np.abs(np.linalg.eigvals(A)).max()
+    prob = t.problems.Problem("rand", A, 0.5 * rng.standard_normal((nx, nu)), np.diag(rng.uniform(0.5, 5.0, nx)),
+                              np.diag(rng.uniform(0.5, 3.0, nu)), float(rng.uniform(0.5, 2.0)), N)
+    prob.x_min, prob.x_max = np.full((nx, N), -1e17), np.full((nx, N), 1e17)
+    prob.u_min, prob.u_max = np.full((nu, N - 1), -0.4), np.full((nu, N - 1), 0.4)
+    return prob, rng
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["quadrotor_N12", "family_8_2_25"])
+def test_specialised_kernels_vs_oracle(hip_lib, oracle_built, jit_on, shape):
+    B = 300
+    if shape == "quadrotor_N12":
+        prob, x0, want = t.problems.quadrotor(12), t.problems.quadrotor_x0(B, seed=6), "mfma<12,4,12>"
+        xr = ur = None
+    else:
+        prob, rng = _random_family(8, 2, 25, 11)
+        x0, want = np.asfortranarray(rng.uniform(-0.5, 0.5, (8, B))), "quad<8,2,25,g4>"
+        xr, ur = 0.1 * rng.standard_normal((8, 25)), 0.05 * rng.standard_normal((2, 24))
+
+    def oracle(kw, xb=None):
+        def make(b=None):
+            o = oracle_built.CpuSolver("orc64", prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N)
+            o.update_settings(**kw)
+            o.set_bound_constraints(prob.x_min, xb if xb is not None else prob.x_max, prob.u_min, prob.u_max)
+            if xr is not None:
+                o.set_x_ref(xr)
+                o.set_u_ref(ur)
+            return o
+        return make
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+    assert bs.kernel_name == want, "the shape was not specialised at setup"
+    if xr is not None:
+        bs.set_x_ref(xr)
+        bs.set_u_ref(ur)
+    for kw, warm in ((dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=60, check_termination=1), False),
+                     (dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1), False),
+                     (dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=5), True)):
+        bs.update_settings(**kw)
+        bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        bs.set_warm_start(warm)
+        bs.reset()
+        bs.set_x0(x0)
+        bs.solve()
+        assert bs.kernel_name == want
+        sol, st = bs.get_solution(), bs.get_status()
+        mk = oracle(kw)
+        ref = dict(x=np.zeros_like(sol["states"]), u=np.zeros_like(sol["controls"]), iter=np.zeros(B, dtype=int), solved=np.zeros(B, dtype=int), res=np.zeros((B, 4)))
+        for b in range(B):
+            o = mk()
+            o.set_x0(x0[:, b])
+            o.solve()
+            r = o.get_solution()
+            ref["x"][:, :, b], ref["u"][:, :, b], ref["iter"][b], ref["solved"][b], ref["res"][b] = r["x"], r["u"], r["iter"], r["solved"], r["res"]
+            o.close()
+        parity_every_instance(sol, st, ref, mk, x0, kw, prob.rho, min_same=0.95, tag=f"{shape} {kw}")
+    # what a specialised unit does not carry goes elsewhere: adaptive rho, fp32 recurrences (4 lanes per instance)
+    bs.set_adaptive_rho(True)
+    bs.solve()
+    assert bs.kernel_name != want
+    bs.set_adaptive_rho(False)
+    if shape == "family_8_2_25":
+        bs.set_precision(1)
+        bs.solve()
+        assert bs.kernel_name == "stream4<8,2>"
+        bs.set_precision(0)
+    bs.solve()
+    assert bs.kernel_name == want
+    bs.close()

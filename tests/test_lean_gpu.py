@@ -186,3 +186,41 @@ def test_lean_scope(hip_lib):
     b4.solve()
     assert b4.last_launch_name == "quad<4,1,20,g4>"
     b4.close()
+
+
+@pytest.mark.parametrize("N", [5, 10, 15])
+def test_lean_other_horizons(hip_lib, oracle_built, N):
+    """the other cartpole horizons with a one-lane-per-instance entry (tests/test_codegen.jl:15 uses N = 5, test_basic.jl N = 10)"""
+    prob, x0 = t.problems.cartpole(N, u_bound=0.5), t.problems.cartpole_x0(B_G1, seed=20 + N)
+    for kw in (dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=100, check_termination=1),
+               dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1)):
+        ref = oracle_built.solve_batch("orc64", prob, x0, nthreads=len(os.sched_getaffinity(0)), **kw)
+        bs = _solver(prob, B_G1, kw)
+        bs.set_x0(x0)
+        bs.solve()
+        assert bs.kernel_name == f"quad<4,1,{N},g1>" and bs.last_launch_name == f"lean<4,1,{N}>"
+        sol, st = bs.get_solution(), bs.get_status()
+        parity_every_instance(sol, st, ref, _oracle_make(oracle_built, prob, kw), x0, kw, prob.rho, min_same=0.97, tag=f"lean N={N}")
+        bs.close()
+
+
+def test_routing_is_cached_between_solves(hip_lib):
+    """the kernel selection is re-evaluated only when something it reads has changed (no getenv, no table walk per solve):
+    a changed option re-routes at the next solve, an unchanged one keeps the cached decision"""
+    prob, x0 = t.problems.cartpole(20, u_bound=0.5), t.problems.cartpole_x0(B_G1, seed=16)
+    bs = _solver(prob, B_G1, dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=5, check_termination=1))
+    bs.set_x0(x0)
+    for _ in range(3):
+        bs.solve()
+        assert bs.kernel_name == "quad<4,1,20,g1>"
+    bs.set_adaptive_rho(True)
+    bs.solve()
+    assert bs.kernel_name == "quad<4,1,20,g1>" and bs.last_launch_name == "quad<4,1,20,g1>"     # its adaptive variant
+    bs.set_adaptive_rho(False)
+    bs.set_fdyn(np.array([0.0, 0.01, 0.0, 0.0]))
+    bs.solve()
+    assert bs.kernel_name == "stream4<4,1>"
+    bs.set_fdyn(np.zeros(4))
+    bs.solve()
+    assert bs.last_launch_name == "lean<4,1,20>"
+    bs.close()

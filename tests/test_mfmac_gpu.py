@@ -293,7 +293,7 @@ def test_mfmac_is_not_used_where_it_does_not_apply(hip_lib, monkeypatch):
     bs.solve()
     assert bs.kernel_name == "stream4<6,3>"
     monkeypatch.setenv("TINYMPC_HIP_MFMAC_WIDE", "1")
-    bs.set_warm_start(True), bs.set_warm_start(False)       # (a setter re-runs the selection)
+    bs.reload_switches()                                    # (the environment is read once, at creation)
     bs.solve()
     assert bs.kernel_name == "mfmac<6,3>"                   # (round 3: linear rows on the LDS kernel; not on the compiled-horizon ones)
     bs.set_warm_start(True)
@@ -309,7 +309,7 @@ def test_mfmac_is_not_used_where_it_does_not_apply(hip_lib, monkeypatch):
     bs.solve()
     assert bs.kernel_name == "stream4<6,3>"
     monkeypatch.setenv("TINYMPC_HIP_MFMAC_WIDE", "1")
-    bs.set_cone_constraints([0], [3], [0.25], [0, 3], [3, 3], [0.5, 1.5])
+    bs.reload_switches()
     bs.solve()
     assert bs.kernel_name == "mfmac<6,3>"                   # (round 3: the LDS kernel takes two cones per side)
     bs.set_cone_constraints([0], [3], [0.25], [0, 2, 4], [2, 2, 2], [0.5, 1.5, 1.0])   # three

@@ -423,9 +423,16 @@ def test_mfmat_selection(hip_lib, monkeypatch):
     bs.solve()
     assert bs.kernel_name == "mfmat<6,3,10>"                       # fp32 recurrences are asked for to save time: no saving here
     monkeypatch.setenv("TINYMPC_HIP_STRICT_FP32", "1")
+    bs.reload_switches()                                           # (the environment is read once, at creation)
     bs.solve()
     assert bs.kernel_name == "stream4<6,3>"
     monkeypatch.delenv("TINYMPC_HIP_STRICT_FP32")
+    bs.reload_switches()
+    assert bs.effective_precision == 0                             # (what runs is reported: fp64 recurrences on the matrix cores)
+    bs.set_strict_precision(True)                                  # the API form of the same request
+    bs.solve()
+    assert bs.kernel_name == "stream4<6,3>" and bs.effective_precision == 1
+    bs.set_strict_precision(False)
     bs.set_precision(0)
     bs.solve()
     assert bs.kernel_name == "mfmat<6,3,10>"

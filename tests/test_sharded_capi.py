@@ -248,3 +248,71 @@ def test_sharded_chunked_solves_run_side_by_side(hip_lib, devices):
     assert np.array_equal(outs[0][1]["controls"], outs[1][1]["controls"])
     if devices[0] != devices[1]:
         assert secs[1] <= 0.85 * secs[0], secs             # two devices, half the batch each, side by side
+
+
+@pytest.mark.gpu
+def test_config5_full_size_eight_shards_one_device(hip_lib, oracle_built):
+    """BASELINE config 5 at its stated size — quadrotor (12,4,30), 2^20 instances (seed 3), tolerance 1e-3 checked every
+    10 iterations — through the in-process multi-GPU handle (tinympc_create_sharded, what a Julia host drives) with the
+    eight shards of 2^17 instances placed on the one device of this box (host fold).  Full-size properties: determinism
+    (two cold solves, bit-equal), feasibility, iteration counts on the check grid, the status fold equal to the
+    per-instance status; the instances on either side of every shard boundary bit-equal to a single-solver run; and
+    parity with the fp64 oracle on a stratified sample of 4 096 instances (every 256th)."""
+    from tests.util import parity_every_instance
+    B, S = 2 ** 20, 8
+    prob, x0 = t.problems.quadrotor(30), t.problems.quadrotor_x0(B, seed=3)
+    kw = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=10)
+    sh = t.ShardedBatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B, devices=[0] * S)
+    assert sh.n_shards == S and sh.fold_backend == "host"
+    assert [sh.shard(i)[1:3] for i in range(S)] == [(i * 2 ** 17, (i + 1) * 2 ** 17) for i in range(S)]
+    sh.update_settings(**kw)
+    sh.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    sh.set_warm_start(False)
+    sh.set_x0(x0)
+    status = sh.solve()
+    sol, st = sh.get_solution(), sh.get_status()
+    assert set(sh.kernel_names()) == {"mfma<12,4,30>"}
+    # full-size properties
+    assert np.isfinite(sol["states"]).all() and np.isfinite(sol["controls"]).all()
+    assert (sol["controls"] <= prob.u_max[:, :, None]).all() and (sol["controls"] >= prob.u_min[:, :, None]).all()
+    assert np.all(st["iter"] % 10 == 0) and st["iter"].min() >= 10 and st["iter"].max() == 100
+    assert np.all((st["solved"] == 1) | (st["iter"] == 100))
+    assert status == int(np.any(st["solved"] == 0))
+    res, unsolved = sh.global_status()
+    assert np.array_equal(res.astype(np.float32), st["residuals"].max(axis=0).astype(np.float32))
+    per_shard_unsolved = [(st["solved"][i * 2 ** 17:(i + 1) * 2 ** 17] == 0).sum() for i in range(S)]
+    assert unsolved == max(per_shard_unsolved)
+    u_first, it_first = sol["controls"].copy(), st["iter"].copy()
+    # determinism: a second cold solve of the same batch
+    sh.reset()
+    assert sh.solve() == status
+    again = sh.get_solution()["controls"]
+    assert np.array_equal(again, u_first) and np.array_equal(sh.get_status()["iter"], it_first)
+    del again
+    sh.close()
+    # the instances on either side of every shard boundary (and the batch's ends) on ONE plain solver
+    edge = np.concatenate([np.arange(0, 64)] + [np.arange(k * 2 ** 17 - 64, k * 2 ** 17 + 64) for k in range(1, S)] + [np.arange(B - 64, B)])
+    one = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=len(edge))
+    one.update_settings(**kw)
+    one.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    one.set_warm_start(False)
+    one.set_x0(np.asfortranarray(x0[:, edge]))
+    one.solve()
+    s1, q1 = one.get_solution(), one.get_status()
+    assert np.array_equal(s1["controls"], u_first[:, :, edge]) and np.array_equal(s1["states"], sol["states"][:, :, edge])
+    assert np.array_equal(q1["iter"], it_first[edge])
+    one.close()
+    # oracle parity on a stratified sample
+    pick = np.arange(0, B, 256)
+    xs = np.asfortranarray(x0[:, pick])
+    ref = oracle_built.solve_batch("orc64", prob, xs, nthreads=len(os.sched_getaffinity(0)), **kw)
+
+    def make(b=None):
+        o = oracle_built.CpuSolver("orc64", prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N)
+        o.update_settings(**kw)
+        o.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        return o
+    sub = dict(states=sol["states"][:, :, pick], controls=sol["controls"][:, :, pick])
+    frac = parity_every_instance(sub, {k: v[pick] for k, v in st.items()}, ref, make, xs, kw, prob.rho, min_same=0.99, tag="config 5, 2^20")
+    print(f"config 5 at 2^20 over 8 shards: mean iterations {st['iter'].mean():.1f}, unsolved {int((st['solved'] == 0).sum())}, "
+          f"sample of {len(pick)}: {frac:.4f} of the iteration counts agree with the oracle")

@@ -87,6 +87,7 @@ from .tinympc import (  # noqa: E402,F401
     set_warm_start,
     kernel_name,
     shard_range,
+    specialise,
     TinyMPCError,
     TinyMPCSolver,
     cleanup,

@@ -78,10 +78,7 @@ __global__ __launch_bounds__(256, (ONE ? 1 : 2)) void admm_lean_kernel(const Adm
     const bool active = b < P.batch;
     const int lane = tid & 63;
     // staging of a wavefront's solution for the final store (below): [64 instances][16 + 1 floats], or [64][nu (N-1)]
-    constexpr int STAGE = (64 * 17 > 64 * (EU | 1)) ? 64 * 17 : 64 * (EU | 1);
-    __shared__ float s_stage[4][STAGE];
-    __shared__ float s_fold[4][4];
-    __shared__ int s_unsolved[4];
+    __shared__ float s_stage[4][wave_stage_floats(EU)];
 
     const SBlock<double, L::NLOADS> blk(P.lean);
     const auto cM = blk.at(L::O_M), cK = blk.at(L::O_K), cB = blk.at(L::O_B), cC = blk.at(L::O_C);
@@ -309,51 +306,10 @@ __global__ __launch_bounds__(256, (ONE ? 1 : 2)) void admm_lean_kernel(const Adm
         const bool mine = active && !conv;
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(mine);
         if (mask) {
-            float *so = s_stage[tid >> 6];
             const long w0 = (long)blockIdx.x * 256 + (tid & ~63);          // the wavefront's first instance
-            float *__restrict__ xo = P.xout + w0 * EX, *__restrict__ uo = P.uout + w0 * EU;
-            const int sub = lane >> 4, off = lane & 15;
-            constexpr int NCH = (EX + 15) / 16;
-            // every instance of the wavefront stores (the usual case): no predicates; else bit `inst` of the mask decides
-            auto put_all = [&](auto full_tag) {
-                constexpr bool FULL = decltype(full_tag)::value;
-                sfor<0, NCH>([&](auto cc) {
-                    constexpr int c = decltype(cc)::value;
-#pragma unroll
-                    for (int j = 0; j < 16; ++j)
-                        if (c * 16 + j < EX) so[lane * 17 + j] = (float)X[(c * 16 + j) / NX][(c * 16 + j) % NX];
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    float v[16];
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) v[j] = so[(4 * j + sub) * 17 + off];   // piece j: instances 4 j .. 4 j + 3, 16 floats each
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const int inst = 4 * j + sub;
-                        const bool ok = (EX % 16 == 0 || c * 16 + off < EX) && (FULL || ((mask >> inst) & 1ull));
-                        if (ok) xo[inst * EX + c * 16 + off] = v[j];
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                });
-#pragma unroll
-                for (int e = 0; e < EU; ++e) so[lane * (EU | 1) + e] = Z[e / NU][e % NU];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                float w[EU];
-#pragma unroll
-                for (int j = 0; j < EU; ++j) {                             // flat element f of the wavefront's 64 x EU controls
-                    const int f = j * 64 + lane;
-                    w[j] = so[(f / EU) * (EU | 1) + f % EU];
-                }
-#pragma unroll
-                for (int j = 0; j < EU; ++j) {
-                    const int f = j * 64 + lane;
-                    if (FULL || ((mask >> (f / EU)) & 1ull)) uo[f] = w[j];
-                }
-            };
-            if (mask == ~0ull) put_all(std::true_type{});
-            else put_all(std::false_type{});
+            store_wave_coalesced<EX, EU>(s_stage[tid >> 6], P.xout + w0 * EX, P.uout + w0 * EU, lane, mask,
+                                         [&](auto ee) { constexpr int e = decltype(ee)::value; return (float)X[e / NX][e % NX]; },
+                                         [&](auto ee) { constexpr int e = decltype(ee)::value; return Z[e / NU][e % NU]; });
             if (mine) {
                 float *ro = P.res + b * 4;
                 P.iter[b] = P.iter_offset + it;
@@ -368,8 +324,7 @@ __global__ __launch_bounds__(256, (ONE ? 1 : 2)) void admm_lean_kernel(const Adm
         }
     }
 
-    {   // global status block: workgroup max of the residuals and count of unsolved instances, then ONE set of atomics per
-        // workgroup (fold_status's per-wavefront set: 1 024 wavefronts finishing together queue on five words)
+    {   // global status block: wavefront max of the residuals, count of unsolved instances
         float m0 = active ? res0 : 0.f, m1 = active ? res1 : 0.f, m2 = active ? res2 : 0.f, m3 = active ? res3 : 0.f;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -379,38 +334,12 @@ __global__ __launch_bounds__(256, (ONE ? 1 : 2)) void admm_lean_kernel(const Adm
             m3 = fmaxf(m3, __shfl_xor(m3, o, 64));
         }
         const unsigned long long unsolved = __builtin_amdgcn_ballot_w64(active && !conv);
-        if (lane == 0) {
-            s_fold[tid >> 6][0] = m0, s_fold[tid >> 6][1] = m1, s_fold[tid >> 6][2] = m2, s_fold[tid >> 6][3] = m3;
-            s_unsolved[tid >> 6] = __popcll(unsolved);
-        }
 #ifdef TMPC_LEAN_CLOCK_PROBE
         if (active) P.iter[b] = (int)(__builtin_amdgcn_s_memrealtime() & 0xFFFFFFull);     // stores issued
         __builtin_amdgcn_s_waitcnt(0);
         if (active) P.solved[b] = (int)(__builtin_amdgcn_s_memrealtime() & 0xFFFFFFull);   // ... and acknowledged
 #endif
-        __syncthreads();
-        if (tid == 0) {
-            float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f;
-            int un = 0;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                f0 = fmaxf(f0, s_fold[w][0]), f1 = fmaxf(f1, s_fold[w][1]), f2 = fmaxf(f2, s_fold[w][2]), f3 = fmaxf(f3, s_fold[w][3]);
-                un += s_unsolved[w];
-            }
-            atomicMax(&P.gacc[0], __float_as_uint(f0));
-            atomicMax(&P.gacc[1], __float_as_uint(f1));
-            atomicMax(&P.gacc[2], __float_as_uint(f2));
-            atomicMax(&P.gacc[3], __float_as_uint(f3));
-            if (un) atomicAdd(&P.gacc[4], (uint32_t)un);
-            __threadfence();  // this workgroup's contributions before its ticket
-            if (atomicAdd(&P.gacc[7], 1u) == gridDim.x - 1) {   // last workgroup: publish, hand the accumulator back zeroed (fold_status)
-                __threadfence();
-#pragma unroll
-                for (int i = 0; i < 5; ++i) P.gstat[i] = atomicExch(&P.gacc[i], 0u);
-                atomicExch(&P.gacc[6], 0u);
-                atomicExch(&P.gacc[7], 0u);
-            }
-        }
+        fold_status(P, m0, m1, m2, m3, __popcll(unsolved), tid);   // (one set of atomics per workgroup)
 #ifdef TMPC_LEAN_CLOCK_PROBE
         if (active) P.res[b * 4 + 3] = (float)(__builtin_amdgcn_s_memrealtime() & 0xFFFFFFull);   // after the status fold
 #endif

@@ -91,7 +91,13 @@ struct AdmmParams {
     const float *xref_seq, *uref_seq;
     // ---- lean kernel (admm_lean.hip.h): its fp64 coefficient pack (LeanPack), wave-uniform ----
     const double *lean;
+    // ---- launcher-side switches (read from the environment once per solver: Switches), not read by any kernel ----
+    int host_flags;   // HF_NO_REFILL | HF_NO_UNI | HF_NO_OS
+    // ---- generic kernel, precision 2 (fp64 end to end): the workspace kept between solves (Ws64) and the tolerances in fp64 ----
+    double *ws64;
+    double abs_pri_tol64, abs_dua_tol64;
 };
+enum : int { HF_NO_REFILL = 1, HF_NO_UNI = 2, HF_NO_OS = 4 };
 
 // Coefficient pack of the lean kernel (admm_lean.hip.h), fp64, all wave-uniform; filled by build_lean_pack (kernels.hip).
 struct LeanLayout {
@@ -108,20 +114,46 @@ constexpr LeanLayout lean_layout(int nx, int nu) {
 }
 
 #ifdef __HIPCC__
-// Folds one wavefront's residual maxima / unsolved count into the launch's status block without a host-side clear:
-// wavefronts accumulate in P.gacc; the last workgroup to finish (ticket in gacc[7]) publishes the totals to P.gstat
-// and hands the accumulator back zeroed to the next launch.  Every thread of the workgroup must call it.
+// Folds a workgroup's residual maxima / unsolved count into the launch's status block without a host-side clear: the
+// wavefronts of a workgroup (at most four) meet in LDS, ONE lane per workgroup accumulates in P.gacc (per-wavefront atomics
+// queue on five words when a thousand wavefronts finish together: round 4, lean kernel timeline); the last workgroup to
+// finish (ticket in gacc[7]) publishes the totals to P.gstat and hands the accumulator back zeroed to the next launch.
+// Every thread of the workgroup must call it; lane 0 of each wavefront carries that wavefront's values.
 __device__ __forceinline__ void fold_status(const AdmmParams &P, float m0, float m1, float m2, float m3,
                                             int unsolved_in_wave, int tid) {
+    __shared__ float s_fold_m[4][4];
+    __shared__ int s_fold_u[4];
+    const int w = tid >> 6, nw = ((int)blockDim.x + 63) >> 6;
+    const bool merged = nw <= 4;
     if ((tid & 63) == 0) {
-        atomicMax(&P.gacc[0], __float_as_uint(m0));
-        atomicMax(&P.gacc[1], __float_as_uint(m1));
-        atomicMax(&P.gacc[2], __float_as_uint(m2));
-        atomicMax(&P.gacc[3], __float_as_uint(m3));
-        if (unsolved_in_wave) atomicAdd(&P.gacc[4], (uint32_t)unsolved_in_wave);
+        if (merged) {
+            s_fold_m[w][0] = m0, s_fold_m[w][1] = m1, s_fold_m[w][2] = m2, s_fold_m[w][3] = m3;
+            s_fold_u[w] = unsolved_in_wave;
+        } else {
+            atomicMax(&P.gacc[0], __float_as_uint(m0));
+            atomicMax(&P.gacc[1], __float_as_uint(m1));
+            atomicMax(&P.gacc[2], __float_as_uint(m2));
+            atomicMax(&P.gacc[3], __float_as_uint(m3));
+            if (unsolved_in_wave) atomicAdd(&P.gacc[4], (uint32_t)unsolved_in_wave);
+        }
     }
     __syncthreads();
     if (tid == 0) {
+        if (merged) {
+            int un = 0;
+            for (int i = 0; i < nw; ++i) {
+                m0 = i ? fmaxf(m0, s_fold_m[i][0]) : s_fold_m[0][0];
+                m1 = i ? fmaxf(m1, s_fold_m[i][1]) : s_fold_m[0][1];
+                m2 = i ? fmaxf(m2, s_fold_m[i][2]) : s_fold_m[0][2];
+                m3 = i ? fmaxf(m3, s_fold_m[i][3]) : s_fold_m[0][3];
+                un += s_fold_u[i];
+            }
+            atomicMax(&P.gacc[0], __float_as_uint(m0));
+            atomicMax(&P.gacc[1], __float_as_uint(m1));
+            atomicMax(&P.gacc[2], __float_as_uint(m2));
+            atomicMax(&P.gacc[3], __float_as_uint(m3));
+            if (un) atomicAdd(&P.gacc[4], (uint32_t)un);
+        }
         __threadfence();  // this workgroup's contributions before its ticket
         if (atomicAdd(&P.gacc[7], 1u) == gridDim.x - 1) {
             __threadfence();

@@ -269,6 +269,64 @@ struct SBlock {
     };
     __device__ __forceinline__ View at(int off) const { return View{*this, off}; }
 };
+// One-lane-per-instance kernels: a wavefront's solution through LDS to HBM, so that a store instruction writes whole
+// 64-byte pieces (states: 16 consecutive floats of 4 instances) or one contiguous 256 bytes (controls) instead of 64
+// scattered 16-byte / 4-byte ones (with every wavefront of a launch finishing together the scattered form took 50 us of a
+// 300 us launch: 26 MB at 0.5 TB/s).  `so`: the wavefront's staging, at least max(64 x 17, 64 x (EU | 1)) floats; xo / uo:
+// the arrays at the wavefront's first instance; mask: the lanes whose instance is stored; getx(e) / getu(e): element e of
+// this lane's instance (compile-time e: the callers' trajectories are register arrays).
+template <int EX, int EU, class FX, class FU>
+__device__ __forceinline__ void store_wave_coalesced(float *so, float *__restrict__ xo, float *__restrict__ uo, int lane,
+                                                     unsigned long long mask, FX &&getx, FU &&getu) {
+    const int sub = lane >> 4, off = lane & 15;
+    constexpr int NCH = (EX + 15) / 16;
+    auto put_all = [&](auto full_tag) {   // every instance of the wavefront stores (the usual case): no predicates
+        constexpr bool FULL = decltype(full_tag)::value;
+        sfor<0, NCH>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            sfor<0, 16>([&](auto jj) {
+                constexpr int j = decltype(jj)::value;
+                if constexpr (c * 16 + j < EX) so[lane * 17 + j] = getx(std::integral_constant<int, c * 16 + j>{});
+            });
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = so[(4 * j + sub) * 17 + off];   // piece j: instances 4 j .. 4 j + 3, 16 floats each
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int inst = 4 * j + sub;
+                const bool ok = (EX % 16 == 0 || c * 16 + off < EX) && (FULL || ((mask >> inst) & 1ull));
+                if (ok) xo[inst * EX + c * 16 + off] = v[j];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        });
+        sfor<0, EU>([&](auto ee) {
+            constexpr int e = decltype(ee)::value;
+            so[lane * (EU | 1) + e] = getu(std::integral_constant<int, e>{});
+        });
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float w[EU];
+#pragma unroll
+        for (int j = 0; j < EU; ++j) {                             // flat element f of the wavefront's 64 x EU controls
+            const int f = j * 64 + lane;
+            w[j] = so[(f / EU) * (EU | 1) + f % EU];
+        }
+#pragma unroll
+        for (int j = 0; j < EU; ++j) {
+            const int f = j * 64 + lane;
+            if (FULL || ((mask >> (f / EU)) & 1ull)) uo[f] = w[j];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    if (mask == ~0ull) put_all(std::true_type{});
+    else put_all(std::false_type{});
+}
+constexpr int wave_stage_floats(int EU) { return 64 * 17 > 64 * (EU | 1) ? 64 * 17 : 64 * (EU | 1); }
+
 __device__ __forceinline__ float tfma(float a, float b, float c) { return fmaf(a, b, c); }
 __device__ __forceinline__ double tfma(double a, double b, double c) { return fma(a, b, c); }
 
@@ -1115,8 +1173,21 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
     }  // mpc step
 
     // ================= epilogue: solution, status, warm-start state =================
+    // solution = projected slack of the last executed iteration (admm.cpp:187-188,204-205)
+    constexpr bool CO_STORE = G == 1 && PL.lds_floats == 0;   // one lane per instance, LDS free: the coalesced form
+    if constexpr (CO_STORE) {
+        __shared__ float s_stage[CO_STORE ? 4 : 1][CO_STORE ? wave_stage_floats(EU) : 1];
+        if (!P.idx) {   // (with an index list a wavefront's instances are not neighbours in the arrays)
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(active);
+            const long w0 = (long)blockIdx.x * S::INST_PER_BLOCK + (tid & ~63);
+            if (mask)
+                store_wave_coalesced<EX, EU>(s_stage[tid >> 6], P.xout + w0 * EX, P.uout + w0 * EU, tid & 63, mask,
+                                             [&](auto ee) { constexpr int e = decltype(ee)::value; return w_get(e / NX, e % NX); },
+                                             [&](auto ee) { constexpr int e = decltype(ee)::value; return zw_get(e / NU, e % NU); });
+        }
+    }
     if (active) {
-        // solution = projected slack of the last executed iteration (admm.cpp:187-188,204-205)
+        if (!CO_STORE || P.idx) {
 #pragma unroll
         for (int m = 0; m < RX; ++m) {
             const int row = q * RX + m;
@@ -1132,6 +1203,7 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
 #pragma unroll
                 for (int k = 0; k < N - 1; ++k) P.uout[b * EU + k * NU + row] = zw_get(k, m);
             }
+        }
         }
         if (P.mpc_steps > 0) {
 #pragma unroll

@@ -164,7 +164,7 @@ int tinympc_update_settings(tinympc_solver *s, double abs_pri_tol, double abs_du
     st.check_termination = check_termination;
     st.en_state_bound = en_state_bound ? 1 : 0;
     st.en_input_bound = en_input_bound ? 1 : 0;
-    if (flags_changed) s->s.packs_dirty = true;
+    if (flags_changed) s->s.packs_dirty = true, s->s.route_gen += 1;
     return 0;
 }
 
@@ -172,6 +172,7 @@ int tinympc_enable_cones(tinympc_solver *s, int en_state_soc, int en_input_soc) 
     if (!s) return -1;
     s->s.st.en_state_soc = en_state_soc ? 1 : 0;
     s->s.st.en_input_soc = en_input_soc ? 1 : 0;
+    s->s.route_gen += 1;
     return 0;
 }
 
@@ -190,6 +191,7 @@ int tinympc_enable_linear(tinympc_solver *s, int en_state_linear, int en_input_l
     if (!s) return -1;
     s->s.st.en_state_linear = en_state_linear ? 1 : 0;
     s->s.st.en_input_linear = en_input_linear ? 1 : 0;
+    s->s.route_gen += 1;
     return 0;
 }
 
@@ -455,12 +457,42 @@ double tinympc_kernel_elapsed_mean_ms(tinympc_solver *s, int last_n) {
     return s ? s->s.kernel_elapsed_mean_ms(last_n) : -1.0;
 }
 int tinympc_set_precision(tinympc_solver *s, int precision) {
-    if (!s || precision < 0 || precision > 1) return -1;
-    if (s->s.precision != precision) s->s.packs_dirty = true;
+    if (!s || precision < 0 || precision > 2) return -1;
+    if (precision == 2 && s->s.hetero) {
+        set_error("set_precision: precision 2 is not available on a per-instance-family solver");
+        return -1;
+    }
+    if (s->s.precision != precision) {
+        s->s.packs_dirty = true;
+        // the workspace kept between solves does not carry over between the fp32 arrays and the fp64 block: cold restart
+        if ((s->s.precision == 2) != (precision == 2) && s->s.solved_once && s->s.reset()) return -1;
+    }
     s->s.precision = precision;
     return 0;
 }
 
+// tuning / test aid: the environment switches are read when a solver is created; this re-reads them for a live solver
+int tinympc_reload_switches(tinympc_solver *s) {
+    if (!s) return -1;
+    s->s.sw = tmpc::read_switches();
+    s->s.lean_enabled = !s->s.sw.no_lean;
+    s->s.route_gen += 1;
+    s->s.packs_dirty = true;
+    return 0;
+}
+int tinympc_set_strict_precision(tinympc_solver *s, int strict) {
+    if (!s) return -1;
+    s->s.strict_precision = strict != 0;
+    return 0;
+}
+int tinympc_effective_precision(tinympc_solver *s) {
+    if (!s) return -1;
+    tmpc::Solver &v = s->s;
+    if (v.select_kernel()) return -1;
+    // the matrix-core kernels and the lean kernel only exist with fp64 recurrences; every other family follows `precision`
+    const bool matrix = (v.ke && v.ke->G == 16) || v.ce != nullptr;
+    return v.precision == 2 ? 2 : (matrix ? 0 : v.precision);
+}
 const char *tinympc_kernel_name(tinympc_solver *s) { return s ? s->s.kernel_name.c_str() : ""; }
 const char *tinympc_last_launch_name(tinympc_solver *s) {
     if (!s) return "";
@@ -489,6 +521,13 @@ double tinympc_algorithmic_flops(tinympc_solver *s, int iters) {
 }
 
 const char *tinympc_last_error(void) { return tmpc::last_error(); }
+
+// Specialise the on-chip kernel of a shape now (what tinympc_create does by itself for a shape the library was not built with):
+// 1 = an on-chip kernel exists for the shape afterwards (built in, cached, or just compiled), 0 = none (run-time-shape kernels)
+int tinympc_specialise(int nx, int nu, int N, int verbose) {
+    if (tmpc::find_quad_kernel(nx, nu, N, -1) || tmpc::find_mfma_kernel(nx, nu, N) || tmpc::find_trans_kernel(nx, nu, N)) return 1;
+    return tmpc::jit_kernel_for(nx, nu, N, verbose) != nullptr ? 1 : 0;
+}
 
 int tinympc_host_precompute(const double *A, const double *B, const double *Q, const double *R,
                             double rho, int nx, int nu, double *Kinf, double *Pinf,

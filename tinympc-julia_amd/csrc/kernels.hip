@@ -1,5 +1,6 @@
 // Kernel table, generic-kernel launcher and its host-side pack builders.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -32,7 +33,7 @@ const KernelEntry *find_quad_kernel(int nx, int nu, int N, int group) {
     };
     for (const KernelEntry *e : table)
         if (e->nx == nx && e->nu == nu && e->N == N && (group < 0 || e->G == group)) return e;
-    return nullptr;
+    return jit_find(false, nx, nu, N, group);   // ... or one specialised at setup (jit.cpp)
 }
 
 const KernelEntry *mfma_entry_12_4_30();
@@ -50,13 +51,16 @@ const KernelEntry *find_mfma_kernel(int nx, int nu, int N) {
                                                mfma_entry_12_4_10()};
     for (const KernelEntry *e : table)
         if (e->nx == nx && e->nu == nu && e->N == N) return e;
-    return nullptr;
+    return jit_find(true, nx, nu, N, -1);   // ... or one specialised at setup (jit.cpp)
 }
 
 const LeanEntry *lean_entry_4_1_20();
+const LeanEntry *lean_entry_4_1_15();
+const LeanEntry *lean_entry_4_1_10();
+const LeanEntry *lean_entry_4_1_5();
 
 const LeanEntry *find_lean_kernel(int nx, int nu, int N) {
-    static const LeanEntry *const table[] = {lean_entry_4_1_20()};
+    static const LeanEntry *const table[] = {lean_entry_4_1_20(), lean_entry_4_1_15(), lean_entry_4_1_10(), lean_entry_4_1_5()};
     for (const LeanEntry *e : table)
         if (e->nx == nx && e->nu == nu && e->N == N) return e;
     return nullptr;
@@ -136,13 +140,14 @@ const ConeEntry *find_trans_kernel(int nx, int nu, int N) {
 }
 
 int device_cu_count() {
-    static int cus[64];
+    static std::atomic<int> cus[64];   // (a sharded handle's worker threads may ask for several devices at once)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 256;
-    int &c = cus[dev & 63];
+    int c = cus[dev & 63].load(std::memory_order_relaxed);
     if (c <= 0) {
         hipDeviceProp_t prop;
         c = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        cus[dev & 63].store(c, std::memory_order_relaxed);
     }
     return c;
 }
@@ -186,10 +191,12 @@ const StreamEntry *find_stream_kernel(int nx, int nu) {
 hipError_t launch_generic(const AdmmParams &P, int precision, hipStream_t stream) {
     const int threads = 256;
     const int grid = (P.batch + threads - 1) / threads;
-    if (precision == 0)
-        hipLaunchKernelGGL(admm_generic_kernel<double>, dim3(grid), dim3(threads), 0, stream, P);
+    if (precision == 2)
+        hipLaunchKernelGGL((admm_generic_kernel<double, double>), dim3(grid), dim3(threads), 0, stream, P);
+    else if (precision == 0)
+        hipLaunchKernelGGL((admm_generic_kernel<double, float>), dim3(grid), dim3(threads), 0, stream, P);
     else
-        hipLaunchKernelGGL(admm_generic_kernel<float>, dim3(grid), dim3(threads), 0, stream, P);
+        hipLaunchKernelGGL((admm_generic_kernel<float, float>), dim3(grid), dim3(threads), 0, stream, P);
     return hipGetLastError();
 }
 
@@ -234,7 +241,7 @@ static void fill_generic_coef(const Solver &sv, std::vector<unsigned char> &out)
 }
 
 void build_generic_coef(const Solver &sv, std::vector<unsigned char> &out) {
-    if (sv.precision == 0)
+    if (sv.precision != 1)
         fill_generic_coef<double>(sv, out);
     else
         fill_generic_coef<float>(sv, out);

@@ -100,7 +100,7 @@ template <int NX, int NU, int N, bool XB>
 hipError_t launch_mfma_refill(const AdmmParams &P, hipStream_t stream) {
     const int tiles = (P.batch + 63) / 64, ct = P.check_termination;
     if (!(P.abs_pri_tol > 0.f && P.abs_dua_tol > 0.f) || ct <= 0 || P.max_iter % ct != 0 || P.idx != nullptr ||
-        P.ref_mode == REF_PER_INSTANCE || P.x0d != nullptr || P.batch % 64 != 0 || std::getenv("TINYMPC_HIP_NO_REFILL"))
+        P.ref_mode == REF_PER_INSTANCE || P.x0d != nullptr || P.batch % 64 != 0 || (P.host_flags & HF_NO_REFILL))
         return hipErrorNotReady;
     const int cus = device_cu_count();   // (per device: a sharded handle launches on several)
 #define TMPC_MFMA_RF(REFS_)                                                                                          \
@@ -118,7 +118,8 @@ hipError_t launch_mfma_refill(const AdmmParams &P, hipStream_t stream) {
     return hipGetLastError();
 }
 
-// precision is ignored: the matrix cores run the recurrences in fp64 (the kernel is only selected for precision 0).
+// precision is ignored: the matrix cores run the recurrences in fp64 (precision = 1 solves of the shape run here too unless the
+// caller asked for strict precision: tinympc_set_strict_precision; tinympc_effective_precision reports what runs).
 // A launch that reads or keeps the workspace takes the WS variant (old slack parked in LDS).  `state_bounds_active`
 // here also covers "the workspace's state dual may be non-zero" (Solver::launch_pass) — only then is g carried.
 // adaptive rho (admm.cpp:147-174): the ADP variants — one-shot or workspace-carrying, no refill
@@ -145,9 +146,13 @@ hipError_t launch_mfma_adp(const AdmmParams &P, hipStream_t stream) {
 template <int NX, int NU, int N>
 hipError_t launch_mfma(const AdmmParams &P, int /*precision*/, bool state_bounds_active, hipStream_t stream) {
     if (P.adaptive_rho) {
+#ifdef TMPC_JIT_UNIT   // a unit specialised at setup (jit.cpp) carries no adaptive-rho variants: the solver never routes such a solve here
+        return hipErrorInvalidValue;
+#else
         const bool ws = !P.cold_start || P.save_state;
         if (state_bounds_active) return ws ? launch_mfma_adp<NX, NU, N, true, true>(P, stream) : launch_mfma_adp<NX, NU, N, true, false>(P, stream);
         return ws ? launch_mfma_adp<NX, NU, N, false, true>(P, stream) : launch_mfma_adp<NX, NU, N, false, false>(P, stream);
+#endif
     }
     if (!P.cold_start || P.save_state)
         return state_bounds_active ? launch_mfma_xb<NX, NU, N, true, true>(P, stream)
@@ -177,6 +182,14 @@ hipError_t launch_mfma(const AdmmParams &P, int /*precision*/, bool state_bounds
         static const KernelEntry e = {NX, NU, NN, 16, "mfma<" #NX "," #NU "," #NN ">", &build_mfma_coef<NX, NU, NN>, \
                                       &build_mfma_bounds<NX, NU, NN>, &launch_mfma<NX, NU, NN>, true};     \
         return &e;                                                                                         \
+    }
+
+// the same entry without adaptive-rho variants, under a fixed C name: what a unit specialised at setup exports (jit.cpp)
+#define TMPC_DEFINE_MFMA_JIT_ENTRY(NX, NU, NN)                                                                           \
+    extern "C" const void *tmpc_jit_entry() {                                                                            \
+        static const tmpc::KernelEntry e = {NX, NU, NN, 16, "mfma<" #NX "," #NU "," #NN ">", &tmpc::build_mfma_coef<NX, NU, NN>, \
+                                            &tmpc::build_mfma_bounds<NX, NU, NN>, &tmpc::launch_mfma<NX, NU, NN>, false, true}; \
+        return &e;                                                                                                       \
     }
 
 }  // namespace tmpc

@@ -1,6 +1,7 @@
 // Host-side pack builder + launcher for one (nx, nu, N) instantiation of the transposed-sets matrix-core kernel
 // (admm_mfmat.hip.h); the lane fields of the operand pack and the bound pack are the LDS kernel's (mfmac_entry.hip.h).
 #pragma once
+#include <atomic>
 #include "admm_mfmat.hip.h"
 #include "mfmac_entry.hip.h"
 
@@ -136,13 +137,14 @@ hipError_t launch_mfmat(const AdmmParams &P, bool ext, size_t lds, hipStream_t s
 #define TMPC_MFMAT_LAUNCH(REFS_, CXQ_, CUQ_, BV_)                                                                                    \
     do {                                                                                                                             \
         auto kfn = admm_mfmat_kernel<NX, NU, N, REFS_, (CXQ_) ? CXA : 0, CXQ_, (CUQ_) ? CUA : 0, CUQ_, BV_>;                             \
-        static int per_cu_dev[64];                                                                                                   \
+        static std::atomic<int> per_cu_dev[64];                                                                                                   \
         int dev = 0;                                                                                                                 \
         (void)hipGetDevice(&dev);                                                                                                    \
-        int &per_cu = per_cu_dev[dev & 63];                                                                                          \
+        int per_cu = per_cu_dev[dev & 63].load(std::memory_order_relaxed);                                                                                          \
         if (per_cu <= 0) {                                                                                                           \
             (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);              \
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 64, lds) != hipSuccess || per_cu <= 0) per_cu = 1;       \
+            per_cu_dev[dev & 63].store(per_cu, std::memory_order_relaxed);                                                            \
         }                                                                                                                            \
         const int grid = tiles < per_cu * cus ? tiles : per_cu * cus;                                                                \
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(64), lds, stream, P);                                                               \

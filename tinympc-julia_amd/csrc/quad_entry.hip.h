@@ -140,6 +140,9 @@ hipError_t launch_quad_adp(const AdmmParams &P, hipStream_t stream) {
 
 template <class S, class RT, bool XB>
 hipError_t launch_quad_rt(const AdmmParams &P, hipStream_t stream) {
+#ifdef TMPC_JIT_UNIT
+    if (P.adaptive_rho) return hipErrorInvalidValue;   // (no adaptive-rho variants in a unit specialised at setup)
+#else
     if (P.adaptive_rho) {
         if constexpr (S::G == 1) {
             // one lane per instance: the correction form — zero or shared references, fp64 recurrences (the solver selects
@@ -167,13 +170,14 @@ hipError_t launch_quad_rt(const AdmmParams &P, hipStream_t stream) {
             return hipErrorInvalidValue;   // (the solver never selects such an entry for an adaptive solve)
         }
     }
+#endif
     if constexpr (S::LOOPV != 0) {
         const bool oneshot = P.cold_start && !P.save_state && P.mpc_steps == 0;
         const bool uniform = oneshot && !(P.abs_pri_tol > 0.f && P.abs_dua_tol > 0.f);  // nobody can converge
         if constexpr ((S::LOOPV & 2) != 0)
-            if (uniform && !std::getenv("TINYMPC_HIP_NO_UNI")) return launch_quad_os<S, RT, XB, true, true>(P, stream);
+            if (uniform && !(P.host_flags & HF_NO_UNI)) return launch_quad_os<S, RT, XB, true, true>(P, stream);
         if constexpr ((S::LOOPV & 1) != 0)
-            if (oneshot && !std::getenv("TINYMPC_HIP_NO_OS")) return launch_quad_os<S, RT, XB, true, false>(P, stream);
+            if (oneshot && !(P.host_flags & HF_NO_OS)) return launch_quad_os<S, RT, XB, true, false>(P, stream);
     }
     return launch_quad_os<S, RT, XB, false, false>(P, stream);
 }
@@ -186,6 +190,9 @@ hipError_t launch_quad(const AdmmParams &P, int precision, bool state_bounds_act
     if (precision == 0)
         return state_bounds_active ? launch_quad_rt<S, double, true>(P, stream)
                                    : launch_quad_rt<S, double, false>(P, stream);
+#ifdef TMPC_JIT_UNIT   // a unit specialised at setup (jit.cpp) carries the fp64-recurrence kernels only (the solver's routing knows)
+    return hipErrorInvalidValue;
+#endif
     return state_bounds_active ? launch_quad_rt<S, float, true>(P, stream)
                                : launch_quad_rt<S, float, false>(P, stream);
 }
@@ -206,6 +213,15 @@ hipError_t launch_quad(const AdmmParams &P, int precision, bool state_bounds_act
         static const KernelEntry e = {NX, NU, NN, GG, "quad<" #NX "," #NU "," #NN ",g" #GG ">", \
                                       &build_quad_coef<S>, &build_quad_bounds<S>, &launch_quad<S>, S::ADP_OK}; \
         return &e;                                                                             \
+    }
+
+// the same entry under a fixed C name: what a unit specialised at setup exports (jit.cpp); no adaptive-rho variants
+#define TMPC_DEFINE_QUAD_JIT_ENTRY(NX, NU, NN, GG)                                                           \
+    extern "C" const void *tmpc_jit_entry() {                                                                \
+        using S = tmpc::QuadShape<NX, NU, NN, GG>;                                                           \
+        static const tmpc::KernelEntry e = {NX, NU, NN, GG, "quad<" #NX "," #NU "," #NN ",g" #GG ">",        \
+                                            &tmpc::build_quad_coef<S>, &tmpc::build_quad_bounds<S>, &tmpc::launch_quad<S>, false, true}; \
+        return &e;                                                                                           \
     }
 
 }  // namespace tmpc

@@ -271,15 +271,30 @@ int tinympc_sharded_solve_async(tinympc_sharded *s) {
     bool chunked = false;
     for (int i = 0; i < s->n(); ++i) chunked = chunked || s->shard[i]->s.chunk_iters > 0;
     if (chunked && s->n() > 1) {
+        (void)tmpc::device_cu_count();   // (per-device caches are filled by the first caller: not from several threads at once)
         std::vector<int> rc((size_t)s->n(), 0);
+        std::vector<std::string> err((size_t)s->n());   // last_error() is per thread: carried back to the caller's
         std::vector<std::thread> th;
         for (int i = 0; i < s->n(); ++i)
-            th.emplace_back([s, i, &rc] {
-                rc[(size_t)i] = hipSetDevice(s->dev[i]) == hipSuccess ? tinympc_solve_async(s->shard[i], s->stream[i]) : -1;
+            th.emplace_back([s, i, &rc, &err] {
+                if (hipSetDevice(s->dev[i]) != hipSuccess) {
+                    rc[(size_t)i] = -1;
+                    err[(size_t)i] = "hipSetDevice failed on a shard's worker thread";
+                    return;
+                }
+                rc[(size_t)i] = tinympc_solve_async(s->shard[i], s->stream[i]);
+                if (rc[(size_t)i]) err[(size_t)i] = tmpc::last_error();
             });
         for (std::thread &t : th) t.join();
-        for (int r : rc)
-            if (r) return -1;
+        for (int i = 0; i < s->n(); ++i)
+            if (rc[(size_t)i]) {
+                // the other shards have run to completion: drain every stream so that the handle's state (nothing
+                // pending) matches the devices', then report the first failing shard's message on THIS thread
+                for (int j = 0; j < s->n(); ++j)
+                    if (hipSetDevice(s->dev[j]) == hipSuccess) (void)hipStreamSynchronize(s->stream[j]);
+                set_error("shard " + std::to_string(i) + ": " + err[(size_t)i]);
+                return -1;
+            }
     } else {
         for (int i = 0; i < s->n(); ++i) {
             SH_TRY(hipSetDevice(s->dev[i]));

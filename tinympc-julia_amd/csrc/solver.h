@@ -22,7 +22,13 @@ struct KernelEntry {
     void (*build_bounds)(const Solver &, std::vector<float> &);
     hipError_t (*launch)(const AdmmParams &, int precision, bool state_bounds_active, hipStream_t);
     bool adp = false;  // the entry also carries the adaptive-rho kernels (QuadShape::ADP_OK)
+    bool jit = false;  // specialised at setup (jit.cpp): fp64-recurrence kernels only, no adaptive-rho variants
 };
+// Specialisation at setup (jit.cpp): compiles / loads the on-chip kernel of a shape the library was not built with and adds
+// it to what find_quad_kernel / find_mfma_kernel return; nullptr when nothing could be specialised (no compiler, no
+// sources, the state does not fit, TINYMPC_HIP_NO_JIT)
+const KernelEntry *jit_kernel_for(int nx, int nu, int N, int verbose);
+const KernelEntry *jit_find(bool mfma, int nx, int nu, int N, int group);
 // group < 0: the shape's default group size; otherwise that exact variant (nullptr if not built)
 const KernelEntry *find_quad_kernel(int nx, int nu, int N, int group = -1);
 // the variant best suited to `batch` instances (nullptr: no specialised kernel for the shape)
@@ -74,6 +80,17 @@ int device_cu_count();
 hipError_t launch_generic(const AdmmParams &, int precision, hipStream_t);
 void build_generic_coef(const Solver &, std::vector<unsigned char> &);
 void build_generic_bounds(const Solver &, std::vector<float> &);
+
+// Environment switches (tuning / test aids), read once per solver at creation (read_switches)
+struct Switches {
+    int group = 0;          // TINYMPC_HIP_GROUP = 1 | 2 | 4: that lanes-per-instance variant, no matrix-core kernels
+    bool strict_fp32 = false, no_quad = false, no_quad_adp = false, no_quad_adp1 = false, no_mfma = false, no_mfma_adp = false,
+         mfma_oneshot_only = false, no_stream = false, no_stream_adp = false, no_mfmar = false, no_mfmac = false, mfmac_all = false,
+         mfmac_wide = false, no_mfmat = false, mfmat_all = false, mfmat_ws_only = false, no_lean = false, no_refill = false,
+         no_uni = false, no_os = false;
+    int mfmac_debug = 0;    // timing probe builds only
+};
+Switches read_switches();
 
 struct Settings {
     double abs_pri_tol = 1e-3, abs_dua_tol = 1e-3;  // TinyMPC.jl:57-58
@@ -178,6 +195,8 @@ struct Solver {
     int unpin_host_range(void *p);
     int h2d_float(float *d, const double *in, size_t n);
     float *d_scratch = nullptr;
+    double *d_ws64 = nullptr;    // precision 2: the fp64 workspace block (admm_generic.hip.h, Ws64)
+    size_t ws64_cap = 0;
     float *d_mpc_x = nullptr, *d_mpc_u = nullptr;  // fused closed-loop logs
     int *d_mpc_iter = nullptr;
     int mpc_cap = 0, mpc_steps_last = 0;
@@ -189,7 +208,7 @@ struct Solver {
     static constexpr int EV_RING = 256;  // event pairs around the most recent launches (profiling mode)
     std::vector<hipEvent_t> ev_ring;     // [2 * EV_RING], created on first use
     long launches = 0;                   // launches recorded since profiling was switched on
-    int precision = 0;  // 0: fp64 recurrences (default), 1: all fp32
+    int precision = 0;  // 0: fp64 recurrences, fp32 state (default), 1: all fp32, 2: all fp64 (generic kernel)
 
     int ex() const { return nx * N; }
     int eu() const { return nu * (N - 1); }
@@ -207,7 +226,22 @@ struct Solver {
     hipEvent_t ev_done = nullptr;
     bool ev_done_pending = false;
     int wait_last_launch();
-    int select_kernel(bool rollout = false);  // rollout: the next launch is the fused closed loop (quad kernel only)
+    int select_kernel(bool rollout = false);  // rollout: the next launch is the fused closed loop
+    // routing (solver.hip, "kernel routing"): switches, the families' routes, the cached decision
+    Switches sw;
+    bool strict_precision = false;            // tinympc_set_strict_precision: precision = 1 really means fp32 recurrences
+    bool strict_fp32() const { return precision != 0 && (sw.strict_fp32 || strict_precision); }
+    bool extensions_active() const { return has_fdyn || cones_active() || lin_active(); }
+    bool rollout_on_quad() const { return sw.mfma_oneshot_only || !warm_start; }
+    const KernelEntry *route_quad(bool rollout) const;
+    const KernelEntry *route_mfma(bool rollout, const KernelEntry *quad) const;
+    const StreamEntry *route_stream() const;
+    const ConeEntry *route_cone(bool rollout, bool have_quad, bool have_stream) const;
+    const ConeEntry *route_trans(bool rollout, const ConeEntry *oneshot) const;
+    std::vector<long> routing_key(bool rollout) const;
+    std::vector<long> routed_key;
+    bool routed = false;
+    unsigned route_gen = 0;                   // bumped by setters whose effect on routing the key's scalars do not show
     void free_batch();
     int upload_packs();
     int upload_refs();

@@ -1,5 +1,6 @@
 // Host side of the batched solver: device memory, pack uploads, launches.
 #include "solver.h"
+#include "admm_generic.hip.h"   // Ws64 (layout of the precision-2 workspace)
 
 #include <cmath>
 #include <cstdio>
@@ -186,6 +187,7 @@ int Solver::copy_family_state(const Solver &o) {
     warm_start = o.warm_start;
     cache_overridden = o.cache_overridden;
     precision = o.precision;
+    strict_precision = o.strict_precision;
     chunk_iters = o.chunk_iters;
     packs_dirty = true;
     return select_kernel() || ensure_extension_buffers();
@@ -206,6 +208,8 @@ void Solver::free_batch() {
     dev_free(d_sg);
     dev_free(d_sv);
     dev_free(d_scratch);
+    dev_free(d_ws64);
+    ws64_cap = 0;
     dev_free(d_het_aux);
     dev_free(d_sgc);
     dev_free(d_svc);
@@ -248,7 +252,8 @@ int Solver::init(const double *A_, const double *B_, const double *Q_, const dou
     if (device_ < 0) HIP_TRY(hipGetDevice(&device_));
     device = device_;
     HIP_TRY(hipSetDevice(device));
-    lean_enabled = std::getenv("TINYMPC_HIP_NO_LEAN") == nullptr;   // tuning / test aid: keep such solves on the quad kernel
+    sw = read_switches();   // the environment, once per solver
+    lean_enabled = !sw.no_lean;
     nx = nx_;
     nu = nu_;
     N = N_;
@@ -261,6 +266,8 @@ int Solver::init(const double *A_, const double *B_, const double *Q_, const dou
         set_error("Riccati precompute failed: R + B'PB is singular");
         return -1;
     }
+    // a shape without an on-chip kernel in the library: specialise one now (jit.cpp; one-off, cached on disk)
+    if (!find_quad_kernel(nx, nu, N, -1) && !find_mfma_kernel(nx, nu, N) && !find_trans_kernel(nx, nu, N)) (void)jit_kernel_for(nx, nu, N, verbose);
     if (verbose)
         std::printf("tinympc_hip: setup nx=%d nu=%d N=%d rho=%g batch=%d (Riccati %d sweeps)\n", nx, nu,
                     N, rho, batch_, cache.riccati_iters);
@@ -312,126 +319,182 @@ int Solver::init_families(const double *A_, const double *B_, const double *Q_, 
     return select_kernel() || ensure_extension_buffers();
 }
 
-// Picks the kernel variant for (shape, batch).  TINYMPC_HIP_GROUP=1|2|4 forces a lanes-per-instance
-// variant (tuning aid); shapes without a specialised kernel run on the generic one.
+// ---- kernel routing ------------------------------------------------------------------------------------------------------
+// The environment switches (tuning / test aids) are read ONCE, when the solver is created; nothing on
+// the solve path calls getenv.
+Switches read_switches() {
+    auto on = [](const char *name) { return std::getenv(name) != nullptr; };
+    Switches w;
+    if (const char *g = std::getenv("TINYMPC_HIP_GROUP")) w.group = std::atoi(g);
+    w.strict_fp32 = on("TINYMPC_HIP_STRICT_FP32");
+    w.no_quad = on("TINYMPC_HIP_NO_QUAD");
+    w.no_quad_adp = on("TINYMPC_HIP_NO_QUAD_ADP");
+    w.no_quad_adp1 = on("TINYMPC_HIP_NO_QUAD_ADP1");
+    w.no_mfma = on("TINYMPC_HIP_NO_MFMA");
+    w.no_mfma_adp = on("TINYMPC_HIP_NO_MFMA_ADP");
+    w.mfma_oneshot_only = on("TINYMPC_HIP_MFMA_ONESHOT_ONLY");
+    w.no_stream = on("TINYMPC_HIP_NO_STREAM");
+    w.no_stream_adp = on("TINYMPC_HIP_NO_STREAM_ADP");
+    w.no_mfmar = on("TINYMPC_HIP_NO_MFMAR");
+    w.no_mfmac = on("TINYMPC_HIP_NO_MFMAC");
+    w.mfmac_all = on("TINYMPC_HIP_MFMAC_ALL");
+    w.mfmac_wide = on("TINYMPC_HIP_MFMAC_WIDE");
+    w.no_mfmat = on("TINYMPC_HIP_NO_MFMAT");
+    w.mfmat_all = on("TINYMPC_HIP_MFMAT_ALL");
+    w.mfmat_ws_only = on("TINYMPC_HIP_MFMAT_WS_ONLY");
+    w.no_lean = on("TINYMPC_HIP_NO_LEAN");
+    w.no_refill = on("TINYMPC_HIP_NO_REFILL");
+    w.no_uni = on("TINYMPC_HIP_NO_UNI");
+    w.no_os = on("TINYMPC_HIP_NO_OS");
+    if (const char *d = std::getenv("TINYMPC_HIP_MFMAC_DEBUG")) w.mfmac_debug = std::atoi(d);
+    return w;
+}
+
+// Capability table.  A kernel family is a route: `route_*` says whether the family takes the solver's shape, options and
+// calling pattern (its "supports"), and — within the family — which instantiation costs least for the batch (lanes per
+// instance by batch size: select_quad_kernel).  select_kernel asks the routes in order of preference, last word first:
+//   transposed-sets matrix-core kernel (mfmat: every calling pattern of its shapes)
+//   > one-shot matrix-core kernels with the affine term / cones (mfmar, compiled horizon; mfmac, LDS, any horizon)
+//   > matrix-core kernel of the box-only shapes (mfma, and its adaptive-rho variant)
+//   > lanes-per-instance kernels (quad, and their adaptive-rho variants)  > run-time-horizon stream kernel  > generic kernel.
+// The result is cached under the key of everything the routes read; a solve re-routes only when that key has changed.
+
+// lanes-per-instance family, its adaptive-rho variants included (precision = 1 — fp32 recurrences, asked for to save time —
+// stays here only where no matrix-core kernel exists, or with TINYMPC_HIP_STRICT_FP32: route_mfma)
+const KernelEntry *Solver::route_quad(bool rollout) const {
+    if (sw.no_quad || extensions_active() || hetero) return nullptr;
+    if (!st.adaptive_rho) {
+        const KernelEntry *k = sw.group ? find_quad_kernel(nx, nu, N, sw.group) : nullptr;
+        if (!k) k = select_quad_kernel(nx, nu, N, batch);
+        return (k && k->jit && precision != 0) ? nullptr : k;   // (a unit specialised at setup carries fp64 recurrences only)
+    }
+    // adaptive rho: the ADP variant where the shape has one (4 lanes per instance, coefficient rows in registers: the
+    // cartpole shapes) ...
+    const KernelEntry *ka = sw.no_quad_adp ? nullptr : find_quad_kernel(nx, nu, N, 4);
+    if (!(ka && ka->adp && chunk_iters == 0 && !rollout && !cache_overridden)) return nullptr;
+    // ... with ONE lane per instance — the benched variant of large batches — in the correction form (admm_quad.hip.h:
+    // dK = (rho_b - rho_family) dKinf/drho next to the family's wave-uniform coefficients): zero or shared references,
+    // fp64 recurrences, the adaptive state in closed form
+    if (batch >= 20480 && precision == 0 && !sw.group && !refs_device_owned && xref_kind <= 1 && uref_kind <= 1 &&
+        (adapt_pure || adapt_dirty) && !sw.no_quad_adp1)
+        if (const KernelEntry *k1 = find_quad_kernel(nx, nu, N, 1))
+            if (k1->adp) return k1;
+    return ka;
+}
+
+// matrix-core kernel of the box-only shapes: plain solves with fp64 recurrences (horizons the shape has no
+// lanes-per-instance kernel for — quadrotor N = 10, 15, 25 — included; the fused closed loop of a cold-started solver stays
+// on the quad kernel), and the adaptive-rho variant (the instance's own Kinf as a correction to the shared products) where
+// the quad family has none
+const KernelEntry *Solver::route_mfma(bool rollout, const KernelEntry *quad) const {
+    if (strict_fp32() || sw.group || sw.no_mfma || sw.no_quad) return nullptr;
+    const KernelEntry *m = find_mfma_kernel(nx, nu, N);
+    if (!m) return nullptr;
+    if (st.adaptive_rho)
+        return (!quad && m->adp && !extensions_active() && chunk_iters == 0 && !rollout && !cache_overridden &&
+                (adapt_pure || adapt_dirty) && !sw.no_mfma_adp) ? m : nullptr;
+    if (!(quad || !(extensions_active() || hetero))) return nullptr;
+    if (rollout && rollout_on_quad()) return nullptr;
+    if (!(!sw.mfma_oneshot_only || (!warm_start && chunk_iters == 0))) return nullptr;
+    return m;
+}
+
+// run-time-horizon stream kernel of (nx, nu): whatever no specialised kernel takes, if its LDS image fits
+const StreamEntry *Solver::route_stream() const {
+    const bool adp_ok = !extensions_active() && chunk_iters == 0 && !sw.no_stream_adp;
+    if ((st.adaptive_rho && !adp_ok) || sw.no_stream) return nullptr;
+    const StreamEntry *s2 = find_stream_kernel(nx, nu);
+    if (s2 && 16.0 * batch * std::max(nx, nu) >= 4.0e9) s2 = nullptr;   // 32-bit lane byte offsets into one knot's rows
+    if (s2 && s2->lds_bytes(N, precision) > 150 * 1024) s2 = nullptr;   // LDS image of coefficients + bounds
+    return s2;
+}
+
+// one-shot solves (cold start, workspace not kept) with the affine term and / or cones: the register-resident matrix-core
+// kernel where the horizon is compiled in (mfmar; box-only solves too where the entry says so: rocket N = 50, 4.3 ms
+// against 5.5 on the quad kernel), else the LDS-resident one (mfmac, any horizon).  Only where a workspace-carrying
+// kernel exists to fall back to (`fallback`).
+const ConeEntry *Solver::route_cone(bool rollout, bool have_quad, bool have_stream) const {
+    const ConeEntry *cn = sw.no_mfmar ? nullptr : find_cone_kernel(nx, nu, N);
+    if (cn && cn->supports && !cn->supports(*this)) cn = nullptr;
+    const bool plain_ok = sw.mfmac_all || (cn != nullptr && cn->plain);
+    if (!((have_stream || (have_quad && plain_ok)) && !warm_start && chunk_iters == 0 && !rollout && !strict_fp32() && !hetero &&
+          !st.adaptive_rho && (extensions_active() || plain_ok) && xref_kind < 2 && uref_kind < 2 &&
+          !(refs_device_owned && ref_mode == REF_PER_INSTANCE) && !sw.no_mfmac && !sw.group && !sw.no_mfma))
+        return nullptr;
+    const ConeEntry *c2 = cn ? cn : find_cone_kernel(nx, nu, 0);
+    if (c2 && c2->lds_bytes(*this) > 160 * 1024 - 1024) c2 = nullptr;   // horizon too long for one tile's LDS
+    // (two cones per side / linear rows: correct on mfmac but no faster than the stream kernel — the extra duals cost it a
+    // tile per CU, scripts/lin_rows_time.py — so only on request)
+    const bool wide = (st.en_state_soc && ncx > 1) || (st.en_input_soc && ncu > 1) || lin_active();
+    if ((st.en_state_soc && ncx > 2) || (st.en_input_soc && ncu > 2) || (wide && !sw.mfmac_wide)) c2 = nullptr;
+    return c2;
+}
+
+// transposed-sets matrix-core kernel: every kind of solve (one-shot, warm-started, workspace kept, chunked, the fused closed
+// loop) of a shape that has it, with the affine term / at most one cone per side (box-only problems where the entry says so)
+const ConeEntry *Solver::route_trans(bool rollout, const ConeEntry *oneshot) const {
+    if (sw.no_mfmat || sw.no_mfma || sw.group) return nullptr;
+    const ConeEntry *ct = find_trans_kernel(nx, nu, N);
+    if (ct && ct->supports && !ct->supports(*this)) ct = nullptr;
+    if (!ct) return nullptr;
+    if (strict_fp32() || hetero || lin_active() || st.adaptive_rho || (refs_per_instance() && ref_seq_steps > 0) || st.max_iter < 1 ||
+        !(has_fdyn || cones_active() || ct->plain || sw.mfmat_all) || ct->lds_bytes(*this) > 160 * 1024 - 1024 ||
+        (double)batch * ex() >= 2.0e9)
+        return nullptr;
+    if (sw.mfmat_ws_only && !warm_start && chunk_iters == 0 && !rollout && oneshot) return nullptr;   // (tests hold the families against each other)
+    return ct;
+}
+
+// everything the routes read, in one comparable value
+std::vector<long> Solver::routing_key(bool rollout) const {
+    return {nx, nu, N, batch, precision, warm_start, chunk_iters, has_fdyn, cones_active(), lin_active(), hetero, st.adaptive_rho,
+            cache_overridden, refs_device_owned, xref_kind, uref_kind, ref_mode, adapt_pure, adapt_dirty, ref_seq_steps,
+            st.max_iter < 1, st.en_state_soc, st.en_input_soc, ncx, ncu, Acx[0], qcx[0], Acu[0], qcu[0], mlx, mlu, rollout, (long)route_gen};
+}
+
 int Solver::select_kernel(bool rollout) {
-    const char *genv = std::getenv("TINYMPC_HIP_GROUP");
-    // precision = 1 asks for fp32 recurrences to save time.  Where the shape has a matrix-core kernel that is no saving —
-    // quadrotor N = 30: 7.2 ms on the fp32 lanes-per-instance kernel (which spills at that shape) against 4.3 on the fp64
-    // matrix cores, rocket N = 50 box 3.8 / 8.8 (workspace kept) against 2.8 — so such solves run on the matrix cores too
-    // (more digits, less time).  TINYMPC_HIP_STRICT_FP32=1 keeps them on the fp32 kernels (tests, tuning).
-    const bool strict_fp32 = precision != 0 && std::getenv("TINYMPC_HIP_STRICT_FP32") != nullptr;
-    const KernelEntry *k = genv ? find_quad_kernel(nx, nu, N, std::atoi(genv)) : nullptr;
-    if (!k) k = select_quad_kernel(nx, nu, N, batch);
-    if (has_fdyn || cones_active() || lin_active() || hetero) k = nullptr;  // extensions run on the stream / generic kernels
-    if (st.adaptive_rho) {
-        if (hetero) {
-            set_error("adaptive_rho is not available on a per-instance-family solver");
+    std::vector<long> key = routing_key(rollout);
+    if (routed && key == routed_key) return 0;
+    if (st.adaptive_rho && hetero) {
+        set_error("adaptive_rho is not available on a per-instance-family solver");
+        return -1;
+    }
+    if (precision == 2) {   // fp64 end to end: the generic kernel's double-state form, whatever the shape
+        if (hetero || rollout) {
+            set_error(hetero ? "precision 2 is not available on a per-instance-family solver" : "precision 2 has no fused closed loop (step it from the host)");
             return -1;
         }
-        // adaptive rho: the quad kernel's ADP variant where the shape has one (4 lanes per instance, coefficient rows in
-        // registers: the cartpole shapes), else the stream kernel's (box sets), else the generic kernel
-        const KernelEntry *ka = std::getenv("TINYMPC_HIP_NO_QUAD_ADP") ? nullptr : find_quad_kernel(nx, nu, N, 4);
-        const bool quad_adp_ok = ka && ka->adp && !has_fdyn && !cones_active() && !lin_active() && chunk_iters == 0 &&
-                                 !rollout && !cache_overridden;
-        k = quad_adp_ok ? ka : nullptr;
-        // ... with ONE lane per instance — the benched variant of large batches — in the correction form (admm_quad.hip.h:
-        // dK = (rho_b - rho_family) dKinf/drho next to the family's wave-uniform coefficients): zero or shared references,
-        // fp64 recurrences, the adaptive state in closed form.  TINYMPC_HIP_NO_QUAD_ADP1: tuning / test aid
-        if (quad_adp_ok && batch >= 20480 && precision == 0 && !genv && !refs_device_owned && xref_kind <= 1 && uref_kind <= 1 &&
-            (adapt_pure || adapt_dirty) && !std::getenv("TINYMPC_HIP_NO_QUAD_ADP1")) {
-            const KernelEntry *k1 = find_quad_kernel(nx, nu, N, 1);
-            if (k1 && k1->adp) k = k1;
+        if (nx > GEN_MAX_NX || nu > GEN_MAX_NU) {
+            set_error("problem shape exceeds the generic kernel limits (nx <= 64, nu <= 32)");
+            return -1;
         }
-        // the matrix-core kernel's ADP variant (round 3; the quadrotor shapes — what the reference's adaptive rho is built
-        // for): an instance's own Kinf as a correction to the shared products.  TINYMPC_HIP_NO_MFMA_ADP: tuning / test aid
-        if (!k && !strict_fp32 && !has_fdyn && !cones_active() && !lin_active() && chunk_iters == 0 && !rollout && !cache_overridden &&
-            (adapt_pure || adapt_dirty) &&
-            !genv && !std::getenv("TINYMPC_HIP_NO_MFMA") && !std::getenv("TINYMPC_HIP_NO_MFMA_ADP") && !std::getenv("TINYMPC_HIP_NO_QUAD"))
-            if (const KernelEntry *m = find_mfma_kernel(nx, nu, N))
-                if (m->adp) k = m;
+        if (ke || se || ce) packs_dirty = true;
+        ke = nullptr, se = nullptr, ce = nullptr;
+        rollout_quad = false;
+        kernel_name = "generic<f64>";
+        routed_key = std::move(key);
+        routed = true;
+        return 0;
     }
-    if (std::getenv("TINYMPC_HIP_NO_QUAD")) k = nullptr;    // tuning aid: time the fallback kernels on any shape
-    // plain solves with fp64 recurrences: the matrix-core kernel of the shape (the fused closed loop stays on the quad
-    // kernel; TINYMPC_HIP_MFMA_ONESHOT_ONLY=1 keeps workspace-carrying solves there too — tuning aid)
-    const bool mfma_ws_ok = !std::getenv("TINYMPC_HIP_MFMA_ONESHOT_ONLY");
-    if (rollout && (!mfma_ws_ok || !warm_start)) rollout_quad = true;  // else: rollout_steps() on the matrix-core kernel
-    else rollout_quad = false;
-    // (horizons the shape has no lanes-per-instance kernel for — quadrotor N = 10, 15, 25 — run their plain fp64 solves
-    // there too; what the matrix-core kernel does not take then goes to the stream kernel as before)
-    const bool plain_box = !(has_fdyn || cones_active() || lin_active() || hetero);
-    if ((k || plain_box) && !st.adaptive_rho && !(rollout && rollout_quad) && (mfma_ws_ok || (!warm_start && chunk_iters == 0)) &&
-        !strict_fp32 && !genv && !std::getenv("TINYMPC_HIP_NO_MFMA") && !std::getenv("TINYMPC_HIP_NO_QUAD"))
-        if (const KernelEntry *m = find_mfma_kernel(nx, nu, N)) k = m;
+    const KernelEntry *q = route_quad(rollout), *m = route_mfma(rollout, q), *k = m ? m : q;
     if (!k && (nx > GEN_MAX_NX || nu > GEN_MAX_NU)) {
         set_error("problem shape exceeds the generic kernel limits (nx <= 64, nu <= 32)");
         return -1;
     }
-    // shapes / options without a quad kernel: the stream kernel for (nx, nu) if its LDS image fits
-    const StreamEntry *s2 = nullptr;
-    const bool adp_ok = !cones_active() && !lin_active() && !has_fdyn && chunk_iters == 0 && !std::getenv("TINYMPC_HIP_NO_STREAM_ADP");
-    if (!k && (!st.adaptive_rho || adp_ok) && !std::getenv("TINYMPC_HIP_NO_STREAM")) {
-        s2 = find_stream_kernel(nx, nu);
-        // 32-bit lane byte offsets into one knot's rows; LDS image of coefficients + bounds
-        if (s2 && 16.0 * batch * std::max(nx, nu) >= 4.0e9) s2 = nullptr;
-        if (s2 && s2->lds_bytes(N, precision) > 150 * 1024) s2 = nullptr;
-    }
+    const StreamEntry *s2 = k ? nullptr : route_stream();
     if (hetero && !s2) {
         set_error("per-instance families need a stream-kernel instantiation for (nx, nu) (nx in {2,3,4,6,8,10,12}, nu <= 4)");
         return -1;
     }
-    // one-shot solves (cold start, workspace not kept) with the affine term and / or cones: the LDS-resident matrix-core
-    // kernel of the shape (TINYMPC_HIP_NO_MFMAC: tuning / test aid).  TINYMPC_HIP_MFMAC_ALL=1 also sends box-only
-    // one-shot solves of the shape there.
-    const ConeEntry *c2 = nullptr;
-    // box-only one-shot solves go there too where the horizon is compiled in (rocket N = 50: 4.3 ms on mfmar against
-    // 5.5 ms on the quad kernel, which spills at this horizon); TINYMPC_HIP_MFMAC_ALL extends that to the LDS kernel
-    const ConeEntry *cn = std::getenv("TINYMPC_HIP_NO_MFMAR") ? nullptr : find_cone_kernel(nx, nu, N);
-    if (cn && cn->supports && !cn->supports(*this)) cn = nullptr;
-    const bool plain_ok = std::getenv("TINYMPC_HIP_MFMAC_ALL") != nullptr || (cn != nullptr && cn->plain);
-    if ((s2 || (k && plain_ok)) && !warm_start && chunk_iters == 0 && !rollout && !strict_fp32 && !hetero &&
-        !st.adaptive_rho && (has_fdyn || cones_active() || lin_active() || plain_ok) && xref_kind < 2 && uref_kind < 2 &&
-        !(refs_device_owned && ref_mode == REF_PER_INSTANCE) && !std::getenv("TINYMPC_HIP_NO_MFMAC") && !genv &&
-        !std::getenv("TINYMPC_HIP_NO_MFMA")) {
-        c2 = cn;                                                             // horizon compiled in
-        if (!c2) c2 = find_cone_kernel(nx, nu, 0);
-        if (c2 && c2->lds_bytes(*this) > 160 * 1024 - 1024) c2 = nullptr;   // horizon too long for one tile's LDS
-        // (the compiled-horizon kernels take one cone per side and no linear rows — their `supports` says so — the LDS
-        // kernel two cones per side and linear rows.  It is correct on those (tests/test_mfmac_gpu.py) but not faster than
-        // the stream kernel: the extra duals cost it a tile per CU — rocket N = 30, 32 768 instances: 7.9 ms against 7.7
-        // with two state cones, 8.6 against 7.9 with a linear row, scripts/lin_rows_time.py — so they go there only when
-        // asked: TINYMPC_HIP_MFMAC_WIDE=1)
-        const bool wide = (st.en_state_soc && ncx > 1) || (st.en_input_soc && ncu > 1) || lin_active();
-        if ((st.en_state_soc && ncx > 2) || (st.en_input_soc && ncu > 2) || (wide && !std::getenv("TINYMPC_HIP_MFMAC_WIDE"))) c2 = nullptr;
-        if (c2) {
-            k = nullptr;
-            s2 = nullptr;
-        }
-    }
-    // every kind of solve (one-shot, warm-started, workspace kept, chunked, the fused closed loop) of a shape that has the
-    // transposed-sets matrix-core kernel, with the affine term / at most one cone per side (box-only problems where the
-    // entry says so).  TINYMPC_HIP_NO_MFMAT: tuning / test aid; TINYMPC_HIP_MFMAT_WS_ONLY: one-shot solves stay on the
-    // three-wavefront kernels (tests hold the two families against each other)
-    const ConeEntry *ct = (std::getenv("TINYMPC_HIP_NO_MFMAT") || std::getenv("TINYMPC_HIP_NO_MFMA") || genv) ? nullptr : find_trans_kernel(nx, nu, N);
-    if (ct && ct->supports && !ct->supports(*this)) ct = nullptr;
-    // (per-instance references: a second set of LDS cells per tile; the per-step reference shift of the closed loop is for
-    // shared references)
-    if (ct && (strict_fp32 || hetero || lin_active() || st.adaptive_rho || (refs_per_instance() && ref_seq_steps > 0) || st.max_iter < 1 ||
-               !(has_fdyn || cones_active() || ct->plain || std::getenv("TINYMPC_HIP_MFMAT_ALL")) ||
-               ct->lds_bytes(*this) > 160 * 1024 - 1024 || (double)batch * ex() >= 2.0e9))
-        ct = nullptr;
-    if (ct && std::getenv("TINYMPC_HIP_MFMAT_WS_ONLY") && !warm_start && chunk_iters == 0 && !rollout && c2) ct = nullptr;
-    if (ct) {
-        c2 = ct;
-        k = nullptr;
-        s2 = nullptr;
-        rollout_quad = false;
-    }
+    const ConeEntry *c2 = route_cone(rollout, k != nullptr, s2 != nullptr), *ct = route_trans(rollout, c2);
+    if (ct) c2 = ct;
+    if (c2) k = nullptr, s2 = nullptr;
+    rollout_quad = rollout && rollout_on_quad() && !ct;   // else: rollout_steps() on the matrix-core kernel / mfmat's fused loop
     if (k != ke || s2 != se || c2 != ce) packs_dirty = true;
-    ke = k;
-    se = s2;
-    ce = c2;
+    ke = k, se = s2, ce = c2;
     kernel_name = ke ? ke->name : (se ? se->name : (ce ? ce->name : "generic"));
+    routed_key = std::move(key);
+    routed = true;
     return 0;
 }
 
@@ -498,6 +561,7 @@ int Solver::reset() {
         HIP_TRY(hipMemset(d_syl, 0, Bn * EU * sizeof(float)));
         HIP_TRY(hipMemset(d_szl, 0, Bn * EU * sizeof(float)));
     }
+    if (d_ws64) HIP_TRY(hipMemset(d_ws64, 0, ws64_cap * sizeof(double)));
     adapt_dirty = true;  // adapted (rho, Kinf, Pinf) go back to the family's cache
     g_maybe_nonzero = false;
     return 0;
@@ -702,6 +766,7 @@ int Solver::upload_refs() {
 }
 
 int Solver::set_bounds(const double *xmin, const double *xmax, const double *umin, const double *umax) {
+    route_gen += 1;   // (array-valued state the routes read: the routing key only carries scalars)
     x_min.assign(xmin, xmin + ex());
     x_max.assign(xmax, xmax + ex());
     u_min.assign(umin, umin + eu());
@@ -713,6 +778,7 @@ int Solver::set_bounds(const double *xmin, const double *xmax, const double *umi
 }
 
 int Solver::set_fdyn(const double *f) {
+    route_gen += 1;   // (array-valued state the routes read: the routing key only carries scalars)
     bool nz = false;
     for (int i = 0; i < nx; ++i) {
         fdyn[i] = f ? f[i] : 0.0;
@@ -725,6 +791,7 @@ int Solver::set_fdyn(const double *f) {
 
 int Solver::set_cones(const int *Acu_, const int *qcu_, const double *cu_, int ncu_, const int *Acx_,
                       const int *qcx_, const double *cx_, int ncx_) {
+    route_gen += 1;
     if (ncu_ > 8 || ncx_ > 8) {
         set_error("set_cone_constraints: at most 8 cones per knot and side");
         return -1;
@@ -758,6 +825,7 @@ int Solver::set_cones(const int *Acu_, const int *qcu_, const double *cu_, int n
 
 // UNPINNED (bindings.cpp:413-450): Alin_x (mx x nx), Alin_u (mu x nu) column-major; enables the non-empty halves
 int Solver::set_linear(const double *Ax, int mx, const double *bx, const double *Au, int mu, const double *bu) {
+    route_gen += 1;   // (array-valued state the routes read: the routing key only carries scalars)
     if (mx < 0 || mu < 0 || mx > LIN_MAX_ROWS || mu > LIN_MAX_ROWS) {
         set_error("set_linear_constraints: at most 8 rows per side");
         return -1;
@@ -847,6 +915,16 @@ int Solver::ensure_extension_buffers() {
     if (ke) return 0;  // (a quad kernel running an adaptive solve: the adaptive state above is all it needs)
     const size_t sets = (size_t)constraint_sets();
     size_t need = Bn * ((2 + 3 * sets) * EX + (3 + 3 * sets) * EU);  // generic kernel: admm_generic.hip.h
+    if (precision == 2) {   // fp64 state: the scratch arrays are doubles, and the workspace kept between solves is the fp64 block
+        need *= 2;
+        const size_t w = (size_t)Ws64::doubles((long)Bn, (long)EX, (long)EU, 3);
+        if (ws64_cap < w) {
+            dev_free(d_ws64);
+            if (dev_alloc(d_ws64, w)) return -1;
+            HIP_TRY(hipMemset(d_ws64, 0, w * sizeof(double)));
+            ws64_cap = w;
+        }
+    }
     if (se) need = std::max(need, Bn * se->scratch_floats(N, (int)sets));
     if (ce) need = ce->scratch_floats(*this);
     if (scratch_cap < need) {
@@ -1105,6 +1183,10 @@ int Solver::launch_pass(hipStream_t stream, int mpc_steps, const int *idx, int n
     const bool lean = ke && le && lean_ok && precision == 0 && cold && !save && mpc_steps == 0 && !idx && !carry_g &&
                       ref_mode == REF_ZERO && !st.adaptive_rho && max_iter_pass >= 1;
     P.lean = d_lean;
+    P.ws64 = d_ws64;
+    P.abs_pri_tol64 = st.abs_pri_tol;
+    P.abs_dua_tol64 = st.abs_dua_tol;
+    P.host_flags = (sw.no_refill ? HF_NO_REFILL : 0) | (sw.no_uni ? HF_NO_UNI : 0) | (sw.no_os ? HF_NO_OS : 0);
     last_launch_name = lean ? le->name : kernel_name;
     if (lean) {
         HIP_TRY(le->launch(P, st.abs_pri_tol > 0.0 && st.abs_dua_tol > 0.0, lean_knot_bounds, stream));
@@ -1340,6 +1422,15 @@ int Solver::get_workspace(double *d, double *y, double *g, double *v, double *z)
     HIP_TRY(hipSetDevice(device));
     if (wait_last_launch()) return -1;
     const size_t Bn = (size_t)batch, EX = (size_t)ex(), EU = (size_t)eu();
+    if (precision == 2 && d_ws64) {   // the fp64 block itself: no widening
+        const Ws64 w(d_ws64, (long)Bn, (long)EX, (long)EU);
+        auto get = [&](double *dst, const double *src, size_t n) { return !dst || hipMemcpy(dst, src, n * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess; };
+        if (!(get(d, w.sd, Bn * EU) && get(y, w.sy, Bn * EU) && get(z, w.sz, Bn * EU) && get(g, w.sg, Bn * EX) && get(v, w.sv, Bn * EX))) {
+            set_error("get_workspace: copy failed");
+            return -1;
+        }
+        return 0;
+    }
     if (d2h_double(d_sd, d, Bn * EU) || d2h_double(d_sy, y, Bn * EU) || d2h_double(d_sz, z, Bn * EU) ||
         d2h_double(d_sg, g, Bn * EX) || d2h_double(d_sv, v, Bn * EX))
         return -1;
@@ -1351,6 +1442,16 @@ int Solver::set_workspace(const double *d, const double *y, const double *g, con
     HIP_TRY(hipSetDevice(device));
     if (wait_last_launch()) return -1;
     const size_t Bn = (size_t)batch, EX = (size_t)ex(), EU = (size_t)eu();
+    if (precision == 2) {
+        if (select_kernel() || ensure_extension_buffers()) return -1;
+        const Ws64 w(d_ws64, (long)Bn, (long)EX, (long)EU);
+        auto put = [&](double *dst, const double *src, size_t n) { return !src || hipMemcpy(dst, src, n * sizeof(double), hipMemcpyHostToDevice) == hipSuccess; };
+        if (!(put(w.sd, d, Bn * EU) && put(w.sy, y, Bn * EU) && put(w.sz, z, Bn * EU) && put(w.sg, g, Bn * EX) && put(w.sv, v, Bn * EX))) {
+            set_error("set_workspace: copy failed");
+            return -1;
+        }
+        return 0;
+    }
     if (h2d_float(d_sd, d, Bn * EU) || h2d_float(d_sy, y, Bn * EU) || h2d_float(d_sz, z, Bn * EU) ||
         h2d_float(d_sg, g, Bn * EX) || h2d_float(d_sv, v, Bn * EX))
         return -1;

@@ -123,6 +123,10 @@ SIGNATURES = {
     "tinympc_set_precision": (c_int, [c_vp, c_int]),
     "tinympc_kernel_name": (ctypes.c_char_p, [c_vp]),
     "tinympc_last_launch_name": (ctypes.c_char_p, [c_vp]),
+    "tinympc_set_strict_precision": (c_int, [c_vp, c_int]),
+    "tinympc_effective_precision": (c_int, [c_vp]),
+    "tinympc_reload_switches": (c_int, [c_vp]),
+    "tinympc_specialise": (c_int, [c_int, c_int, c_int, c_int]),
     "tinympc_algorithmic_bytes": (c_dbl, [c_vp]),
     "tinympc_algorithmic_flops": (c_dbl, [c_vp, c_int]),
     "tinympc_last_error": (ctypes.c_char_p, []),
@@ -810,8 +814,21 @@ class BatchSolver:
         return float(self.lib.tinympc_kernel_elapsed_mean_ms(self.h, int(last_n)))
 
     def set_precision(self, precision):
-        """0: fp64 recurrences (default), 1: all fp32"""
+        """0: fp64 recurrences, fp32 state (default); 1: all fp32; 2: all fp64 like the reference (generic kernel, slow)"""
         self._chk(self.lib.tinympc_set_precision(self.h, int(precision)), "set_precision")
+
+    def reload_switches(self):
+        """re-read the TINYMPC_HIP_* environment switches (they are read once, at creation)"""
+        self._chk(self.lib.tinympc_reload_switches(self.h), "reload_switches")
+
+    def set_strict_precision(self, strict):
+        """True: precision = 1 means fp32 recurrences even where a (faster) fp64 matrix-core kernel exists for the shape"""
+        self._chk(self.lib.tinympc_set_strict_precision(self.h, 1 if strict else 0), "set_strict_precision")
+
+    @property
+    def effective_precision(self):
+        """recurrence precision the current options run with: 0 fp64, 1 fp32"""
+        return int(self.lib.tinympc_effective_precision(self.h))
 
     @property
     def kernel_name(self):
@@ -827,6 +844,12 @@ class BatchSolver:
 
     def algorithmic_flops(self, iters):
         return float(self.lib.tinympc_algorithmic_flops(self.h, int(iters)))
+
+
+def specialise(nx, nu, N, verbose=False):
+    """compile / load the on-chip kernel of a shape the library was not built with, ahead of time (what BatchSolver does by
+    itself at creation): True if the shape has an on-chip kernel afterwards"""
+    return bool(load_library().tinympc_specialise(int(nx), int(nu), int(N), 1 if verbose else 0))
 
 
 def shard_range(batch, n_shards, shard):
