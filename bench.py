@@ -85,6 +85,8 @@ def parse(argv=None):
     ap.add_argument("--check-termination", type=int, default=0, help="check interval (default 1; 10 with --tol)")
     ap.add_argument("--compaction", type=int, default=0, help="tolerance-terminated: chunk size of tinympc_set_compaction")
     ap.add_argument("--precision", type=int, default=0, help="0: fp64 recurrences (default), 1: all fp32")
+    ap.add_argument("--keep-workspace", action="store_true",
+                    help="the reference's default calling pattern: the workspace persists between solves (admm.cpp:111-115) instead of cold one-shot solves")
     ap.add_argument("--mode", default="solve", choices=["solve", "mpc"],
                     help="solve: the headline.  mpc: additionally the warm-started closed loop (SURVEY 8f)")
     ap.add_argument("--mpc-steps", type=int, default=50)
@@ -150,7 +152,18 @@ def make_workload(t, name, batch, seed, lo=0, hi=None):
     return prob, np.asfortranarray(x0[:, lo:hi]), refs, label
 
 
-def build_solver(t, name, prob, x0, refs, device, iters, tol, check, precision, compaction=0):
+def pattern_of(tol, keep_workspace=False, adaptive=False, state_bound=None):
+    """the calling pattern a counter pass belongs to (profiles/traffic.json `pattern`)"""
+    if adaptive:
+        return "adaptive_rho"
+    if state_bound is not None:
+        return "state_bound"
+    if keep_workspace:
+        return "workspace_kept"
+    return "cold" if tol <= 0 else ("check_live" if tol < 1e-20 else "tol")
+
+
+def build_solver(t, name, prob, x0, refs, device, iters, tol, check, precision, compaction=0, keep_workspace=False):
     bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=x0.shape[1], device=device)
     bs.update_settings(abs_pri_tol=tol, abs_dua_tol=tol, max_iter=iters, check_termination=check)
     bs._bench_check, bs._bench_tol = check, tol
@@ -159,7 +172,7 @@ def build_solver(t, name, prob, x0, refs, device, iters, tol, check, precision, 
     if name == "rocket_soc":
         bs.set_fdyn(prob.fdyn)
         bs.set_cone_constraints([0], [3], [prob.extra["cone_mu_u"]], [0], [3], [prob.extra["cone_mu_x"]])
-    bs.set_warm_start(False)          # cold start, no state I/O: compulsory traffic only
+    bs.set_warm_start(bool(keep_workspace))   # default: cold start, no state I/O: compulsory traffic only
     if compaction > 0:
         bs.set_compaction(compaction)
     bs.set_x0(x0)                     # H2D once; inputs stay resident in HBM
@@ -173,7 +186,7 @@ def build_solver(t, name, prob, x0, refs, device, iters, tol, check, precision, 
 # ----------------------------------------------------------------------------------------------------------------------
 # committed counter measurements (static: NOT measured in this run)
 # ----------------------------------------------------------------------------------------------------------------------
-def committed_counters(family, precision, batch, kernel):
+def committed_counters(family, precision, batch, kernel, pattern="cold"):
     """rocprofv3 --pmc results committed under profiles/ for exactly this (family, batch, kernel): HBM bytes per launch
     (separate FETCH_SIZE / WRITE_SIZE passes, FETCH doubled as the gfx950 guide prescribes) and the SQ issue counters.
     They are replayed from files, not measured here; each carries its source so a stale number can be told."""
@@ -190,13 +203,13 @@ def committed_counters(family, precision, batch, kernel):
 
     if os.path.isfile(path):
         for e in json.load(open(path)):
-            if (e["family"], e["precision"], e["batch"], e["kernel"]) == (family, precision, batch, kernel):
+            if (e["family"], e["precision"], e["batch"], e["kernel"], e.get("pattern", "cold")) == (family, precision, batch, kernel, pattern):
                 out["traffic"] = e["hbm_bytes_per_launch"]
                 out["source"] = ("profiles/traffic.json (committed rocprofv3 --pmc passes, " + e.get("tag", "r01") + "; " +
                                  lib_note(e) + ")")
-    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{family}_sq_counters.json"))):
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{family}*_sq_counters.json"))):
         e = json.load(open(p))
-        if (e.get("kernel"), e.get("batch")) == (kernel, batch) and precision == 0:
+        if (e.get("kernel"), e.get("batch"), e.get("pattern", "cold")) == (kernel, batch, pattern) and precision == 0:
             out["valu_issue"] = e.get("derived_valu_issue_utilisation")
             out["mfma_issue"] = e.get("derived_mfma_issue_utilisation")
             out["valu_insts"] = e.get("SQ_INSTS_VALU")
@@ -212,7 +225,7 @@ def bs_can_converge(bs):
     return bool(getattr(bs, "_bench_tol", 0.0) > 0.0)
 
 
-def roofline_of(bs, family, precision, batch, iters_done, k_ms):
+def roofline_of(bs, family, precision, batch, iters_done, k_ms, pattern="cold"):
     """roofline + valu objects of one configuration from its kernel time.  Bytes and FLOPs are SURVEY 8(d)'s
     algorithmic figures (state on chip) x the instances x iterations of one launch."""
     alg_bytes = bs.algorithmic_bytes()
@@ -220,7 +233,7 @@ def roofline_of(bs, family, precision, batch, iters_done, k_ms):
     sec = k_ms * 1e-3
     ach_gbs, ach_tf = alg_bytes / sec / 1e9, alg_flops / sec / 1e12
     launched = bs.last_launch_name            # the family's kernel or the variant this calling pattern took (e.g. lean<4,1,20>)
-    cc = committed_counters(family, precision, batch, launched)
+    cc = committed_counters(family, precision, batch, launched, pattern)
     hbm = {"achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS}
     # What bounds the path is instruction issue (~430-950 FLOP/B against a machine balance of ~20), so the
     # dominant kernel is priced in FLOP/s.  `frac` keeps SURVEY 8(d)'s definition for every round — algorithmic FLOPs (all of
@@ -387,15 +400,11 @@ def time_config(t, torch, dev, stream, name, batch, seed, iters=100, tol=0.0, ch
         k_ms = bs.kernel_elapsed_ms(steps)
         if compaction > 0 and tol > 0.0:
             k_ms, launches_per_step = ms, None      # several launches + compaction kernels per solve: wall time is the figure
-        roof, valu = roofline_of(bs, name, 0, batch, it_mean, k_ms if k_ms > 0 else ms)
-        if adaptive or keep_workspace or tol != 0.0 or state_bound is not None:
-            # the committed counter passes are of the plain cold fixed-iteration launch of the family: another kernel variant /
-            # calling pattern moves other bytes and issues other instructions
-            roof["traffic"], roof["traffic_source"] = None, "not profiled in this calling pattern"
-            if isinstance(valu, dict):
-                for kk in ("issue_utilisation", "counters_source", "executed_flops_upper_bound", "executed_frac_of_fp64_vector_peak"):
-                    if kk in valu:
-                        valu[kk] = None
+        pat = pattern_of(tol, keep_workspace, adaptive, state_bound)
+        roof, valu = roofline_of(bs, name, 0, batch, it_mean, k_ms if k_ms > 0 else ms, pat)
+        roof["pattern"] = pat
+        if roof["traffic"] is None:
+            roof["traffic_source"] = "not profiled in this calling pattern"
         out = {"workload": f"{label}, batch={batch}, " + (f"tol={tol:g} check every {check}, max_iter={iters}" if tol > 0
                                                          else f"fixed {iters} ADMM iters") +
                            (", workspace kept between solves (warm start)" if keep_workspace else ", cold start"),
@@ -604,7 +613,7 @@ def main():
             prob, x0, refs, label = make_workload(t, name, total, seed, lo, hi)
         else:
             prob, x0, refs, label = make_workload(t, name, n_local, seed)
-        bs = build_solver(t, name, prob, x0, refs, local_rank, args.iters, tol, check, args.precision, args.compaction)
+        bs = build_solver(t, name, prob, x0, refs, local_rank, args.iters, tol, check, args.precision, args.compaction, args.keep_workspace)
         stream = torch.cuda.current_stream(dev)
         gstat = sharding.device_tensor(bs.device_buffers()["gstat"], (8,), torch.int32, dev)
 
@@ -707,7 +716,9 @@ def main():
             kk = k_ms if k_ms > 0 else avg_step_ms
             if args.compaction > 0 and tol > 0:
                 kk = avg_step_ms      # several launches per solve
-            out["roofline"], out["valu"] = roofline_of(bs, name, args.precision, n_local, it_mean, kk)
+            pat = pattern_of(tol, args.keep_workspace)
+            out["roofline"], out["valu"] = roofline_of(bs, name, args.precision, n_local, it_mean, kk, pat)
+            out["config"]["pattern"] = pat
             out["mean_iters"] = it_mean
     if not args.dry and rank == 0 and world == 1 and not dist_on:
         if args.mode == "mpc":

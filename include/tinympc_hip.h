@@ -65,6 +65,7 @@ int get_states_f32(float *states_buffer, int *rows, int *cols);
 int get_controls_f32(float *controls_buffer, int *rows, int *cols);
 /* Page-lock / release a caller-owned host array that is reused with the fp32 forms above (direct DMA instead of a bounce
  * through pageable memory).  The library never registers caller memory on its own; unpin before the array is freed. */
+int set_precision(int precision);   /* tinympc_set_precision on the process-global solver: 0 default, 1 all fp32, 2 all fp64 */
 int pin_host_buffer(void *ptr, size_t bytes);
 int unpin_host_buffer(void *ptr);
 /* replaces bindings.cpp:336-376.  en_*_soc / en_*_linear switch the sets given to set_cone_constraints /

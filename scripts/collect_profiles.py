@@ -4,7 +4,8 @@ import csv, glob, json, os, shutil, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 traffic = []
-for cfg in ("cartpole", "quadrotor", "rocket_soc"):
+for cfg in ("cartpole", "quadrotor", "rocket_soc", "rocket_soc_workspace_kept", "rocket_soc_check_live", "cartpole_check_live"):
+    family = "rocket_soc" if cfg.startswith("rocket_soc") else cfg.split("_")[0]
     ks = sorted(glob.glob(f"{root}/gpurun_out/prof_{tag}_{cfg}/*/*_kernel_stats.csv"), key=os.path.getmtime)
     if not ks:
         continue
@@ -22,7 +23,7 @@ for cfg in ("cartpole", "quadrotor", "rocket_soc"):
                 w.writerow([r[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "Counter_Name", "Counter_Value")])
     # SQ counters: one row per dispatch and counter; average over the dispatches of the ADMM kernel
     sq = {}
-    for d in sorted(glob.glob(f"{root}/gpurun_out/pmcS_{tag}_{cfg}_*")):
+    for d in sorted(glob.glob(f"{root}/gpurun_out/pmcS_{tag}_{cfg}_SQ*") + glob.glob(f"{root}/gpurun_out/pmcS_{tag}_{cfg}_MFMA")):   # (not the passes of `cfg`_<pattern>)
         fs = sorted(glob.glob(f"{d}/*/*_counter_collection.csv"), key=os.path.getmtime)
         if not fs:
             continue
@@ -45,10 +46,10 @@ for cfg in ("cartpole", "quadrotor", "rocket_soc"):
     line = [l for l in log.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     if sq:
-        sq["family"], sq["kernel"], sq["batch"] = cfg, d["config"]["kernel"], d["config"]["batch_per_gpu"]
+        sq["family"], sq["kernel"], sq["batch"], sq["pattern"] = family, d["config"]["kernel"], d["config"]["batch_per_gpu"], d["config"].get("pattern", "cold")
         sq["library_sha256"] = d.get("library_sha256")
         json.dump(sq, open(f"{root}/profiles/{tag}_{cfg}_sq_counters.json", "w"), indent=1)
-    traffic.append({"tag": tag, "library_sha256": d.get("library_sha256"), "family": cfg, "precision": 0, "batch": d["config"]["batch_per_gpu"], "kernel": d["config"]["kernel"],
+    traffic.append({"tag": tag, "library_sha256": d.get("library_sha256"), "family": family, "pattern": d["config"].get("pattern", "cold"), "precision": 0, "batch": d["config"]["batch_per_gpu"], "kernel": d["config"]["kernel"],
                     "FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"],
                     "hbm_bytes_per_launch": (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
                     "algorithmic_bytes_per_launch": d["roofline"]["algorithmic_bytes_per_launch"],

@@ -18,6 +18,7 @@ for label, make in (("quadrotor N=10 (built in)", lambda: (t.problems.quadrotor(
                     ("rocket (6,3) N=10 box (built in)", lambda: (t.problems.rocket(10), t.problems.rocket_x0(65536, 2))),
                     ("(8,2) N=25", lambda: fam(8, 2, 25)),
                     ("(8,2) N=10", lambda: fam(8, 2, 10)),
+                    ("(5,2) N=18", lambda: fam(5, 2, 18)),
                     ("cartpole N=12", lambda: (t.problems.cartpole(12, u_bound=0.5), t.problems.cartpole_x0(65536, 0)))):
     prob, x0 = make()
     t0 = time.perf_counter()

@@ -129,7 +129,10 @@ def test_workspace_kept_closed_loop_in_fp64(hip_lib, oracle_built, case):
                 assert e_ <= TIGHT, f"step {k} instance {b} workspace {key}: {e_:.3e}"
             xn[:, b] = _f32(prob.A @ x[:, b] + prob.B @ r["u"][:, 0] + f)      # (what set_x0 hands the kernel: fp32)
         x = xn
-    assert converged >= B // 2                                  # converged exits (v, z one iteration old) are in the sample
+    if case == "rocket_cones_fdyn":
+        assert converged >= B // 2                              # converged exits (v, z one iteration old) are in the sample
+    else:
+        assert np.abs(bs.get_workspace()["g"]).max() > 1e-3     # the state bound binds: the state dual is live
     for o in orcs:
         o.close()
     bs.close()

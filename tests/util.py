@@ -85,7 +85,10 @@ def parity_every_instance(sol, st, ref, make_oracle, x0, settings, rho, xref=Non
     B = len(it_g)
     pt, dt = float(settings["abs_pri_tol"]), float(settings["abs_dua_tol"])
     ct = max(1, int(settings.get("check_termination", 1)))
-    mism = np.nonzero(it_g != it_r)[0]
+    so_r = np.asarray(ref["solved"]) if "solved" in ref else so_g
+    # (an instance that reaches max_iter with its residual within rounding of the tolerance has the same iteration count on
+    # both sides and the other solved flag: the same marginal decision as stopping one check apart, handled the same way)
+    mism = np.nonzero((it_g != it_r) | (so_g != so_r))[0]
     assert len(mism) <= (1.0 - min_same) * B + 1e-9, f"{tag}: {len(mism)} of {B} iteration counts differ"
     X, U = np.array(ref["x"], dtype=np.float64), np.array(ref["u"], dtype=np.float64)
     for b in mism:
@@ -103,7 +106,7 @@ def parity_every_instance(sol, st, ref, make_oracle, x0, settings, rho, xref=Non
         assert r["iter"] == it_g[b] and r["solved"] == so_g[b]
         scale = max(1.0, np.abs(r["x"]).max(), np.abs(r["u"]).max())
         band = 2.0 * tol * max(1.0, rho) * scale / min(pt, dt)
-        if it_g[b] < it_r[b]:      # the GPU saw convergence where the oracle, at the same iteration, did not (ratio >= 1)
+        if it_g[b] < it_r[b] or (it_g[b] == it_r[b] and so_g[b] == 1):   # the GPU saw convergence where the oracle, at the same iteration, did not (ratio >= 1)
             ratio = _ratio(r["res"], pt, dt)
             assert 1.0 <= ratio <= 1.0 + band, f"{tag}: instance {b} left early at ratio {ratio:.4f} (band {band:.3g})"
         else:                      # the oracle converged (ratio < 1) where the GPU went on
@@ -116,7 +119,4 @@ def parity_every_instance(sol, st, ref, make_oracle, x0, settings, rho, xref=Non
     wx, wu = int(np.argmax(ex / lim)), int(np.argmax(eu / lim))
     assert ex[wx] <= lim[wx], f"{tag}: x of instance {wx} off by {ex[wx]:.3e} (limit {lim[wx]:.1e}, iter {it_g[wx]})"
     assert eu[wu] <= lim[wu], f"{tag}: u of instance {wu} off by {eu[wu]:.3e} (limit {lim[wu]:.1e}, iter {it_g[wu]})"
-    if "solved" in ref:
-        same = it_g == it_r
-        assert np.array_equal(so_g[same], np.asarray(ref["solved"])[same]), tag
     return 1.0 - len(mism) / B

@@ -630,6 +630,11 @@ int set_warm_start(int warm_start) {
     if (need_global("set_warm_start")) return -1;
     return each_global([&](tinympc_solver *h) { return tinympc_set_warm_start(h, warm_start); });
 }
+// recurrence / state precision of the global solver (tinympc_set_precision): 0 default, 1 all fp32, 2 all fp64 like the reference
+int set_precision(int precision) {
+    if (need_global("set_precision")) return -1;
+    return each_global([&](tinympc_solver *h) { return tinympc_set_precision(h, precision); });
+}
 const char *get_kernel_name(void) {
     if (!g_solver) return "";
     return (g_sharded ? global_shard(0)->s : g_solver->s).kernel_name.c_str();

@@ -145,12 +145,15 @@ const KernelEntry *jit_find(bool mfma, int nx, int nu, int N, int group) {
 }
 
 // The family that suits a shape without a built-in on-chip kernel, compiled / loaded once per process:
-//   nx + nu >= 12 rows of a 16-row matrix-core tile (and nx <= 12, nu <= 4): the matrix-core kernel, else four lanes per
-//   instance.  Returns nullptr when nothing could be specialised.
+//   seven or more state rows (nx <= 12, nu <= 4): the matrix-core kernel, else four lanes per instance.  Returns nullptr when
+//   nothing could be specialised.
 const KernelEntry *jit_kernel_for(int nx, int nu, int N, int verbose) {
     if (std::getenv("TINYMPC_HIP_NO_JIT")) return nullptr;
     if (nx > 12 || nu > 4 || N < 2 || N > 64) return nullptr;   // (beyond: the state does not fit a lane group / tile either way)
-    const bool mfma = nx + nu >= 12;
+    // matrix-core time per knot does not depend on the shape (one 16-row tile per 16 instances: ~128 us per knot and 65 536
+    // instances, quadrotor N = 10 .. 30), four-lanes-per-instance time grows with nx^2 (43 us per knot for (4,1), 134-225 for
+    // (8,2): scripts/jit_time.py) — from seven state rows on the matrix cores win
+    const bool mfma = nx >= 7;
     std::ostringstream name, src;
     if (mfma) {
         name << "mfma_" << nx << "_" << nu << "_" << N;

@@ -449,7 +449,8 @@ const ConeEntry *Solver::route_trans(bool rollout, const ConeEntry *oneshot) con
 std::vector<long> Solver::routing_key(bool rollout) const {
     return {nx, nu, N, batch, precision, warm_start, chunk_iters, has_fdyn, cones_active(), lin_active(), hetero, st.adaptive_rho,
             cache_overridden, refs_device_owned, xref_kind, uref_kind, ref_mode, adapt_pure, adapt_dirty, ref_seq_steps,
-            st.max_iter < 1, st.en_state_soc, st.en_input_soc, ncx, ncu, Acx[0], qcx[0], Acu[0], qcu[0], mlx, mlu, rollout, (long)route_gen};
+            st.max_iter < 1, st.en_state_soc, st.en_input_soc, ncx, ncu, Acx[0], qcx[0], Acu[0], qcu[0], mlx, mlu, rollout, strict_precision,
+            (long)route_gen};
 }
 
 int Solver::select_kernel(bool rollout) {

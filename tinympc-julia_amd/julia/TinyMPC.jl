@@ -21,7 +21,7 @@ module TinyMPC
 
 export TinyMPCSolver, setup, solve, get_solution, get_solution!, pin_host!, unpin_host!, get_status, set_x0, set_x_ref, set_u_ref, set_ref_sequence, mpc_rollout,
        set_bound_constraints, set_linear_constraints, set_equality_constraints, set_cone_constraints, update_settings,
-       set_cache_terms, set_batch_size, set_gpus, get_gpus, set_warm_start, kernel_name, reset_workspace, print_problem_data,
+       set_cache_terms, set_batch_size, set_gpus, get_gpus, set_warm_start, set_precision, kernel_name, reset_workspace, print_problem_data,
        compute_sensitivity_autograd, set_sensitivity, get_adaptive_rho
 
 using LinearAlgebra, Libdl, Printf
@@ -108,6 +108,14 @@ get_gpus() = Int(ccall((:get_gpus, _lib_path()), Int32, ()))
 
 # on = false: every solve() starts from the zero workspace and keeps none (one-shot solves: the benchmark regime, served by
 # the on-chip kernels); true (default): the reference's semantics, the workspace persists between solves
+# Arithmetic of the solver: 0 = fp64 recurrences over fp32 state (default, 1e-5 of the reference), 1 = all fp32 (faster on
+# shapes without a matrix-core kernel, does not hold 1e-5 on every instance), 2 = fp64 end to end like the reference
+# (types.hpp:15) — for validation against the CPU solver; slow.
+function set_precision(solver::TinyMPCSolver, precision::Integer)
+    _need(solver)
+    _ok(ccall((:set_precision, _lib_path()), Int32, (Int32,), precision), "Failed to set precision")
+end
+
 function set_warm_start(solver::TinyMPCSolver, on::Bool)
     _need(solver)
     _ok(ccall((:set_warm_start, _lib_path()), Int32, (Int32,), on ? 1 : 0), "Failed to set warm start")

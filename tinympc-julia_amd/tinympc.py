@@ -110,6 +110,7 @@ SIGNATURES = {
     "get_states_f32": (c_int, [c_fp, c_ip, c_ip]),
     "get_controls_f32": (c_int, [c_fp, c_ip, c_ip]),
     "pin_host_buffer": (c_int, [c_vp, ctypes.c_size_t]),
+    "set_precision": (c_int, [c_int]),
     "unpin_host_buffer": (c_int, [c_vp]),
     "tinympc_set_ref_sequence": (c_int, [c_vp, c_dp, c_int, c_int, c_dp, c_int, c_int, c_int]),
     "tinympc_set_profiling": (c_int, [c_vp, c_int]),
