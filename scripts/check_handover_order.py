@@ -48,7 +48,7 @@ def decode(lines, NX, NU, N):
             if addr not in base:
                 continue
             o = base[addr]
-            g = lambda n: int(re.search(n + r":(\d+)", rest).group(1)) if re.search(n + r":(\d+)", rest) else 0
+            g = lambda n: int(re.search(n + r":(0x[0-9a-fA-F]+|\d+)", rest).group(1), 0) if re.search(n + r":(0x[0-9a-fA-F]+|\d+)", rest) else 0   # (inline asm prints hex)
             if op == "ds_write_b32":
                 writes.append((i, o + g("offset")))
             elif op == "ds_write2_b32":

@@ -29,7 +29,7 @@ def test_specialise_compiles_links_and_loads_a_unit(hip_lib, jit_on):
     assert t.specialise(4, 1, 20) is True                      # built in: nothing to do
     assert t.specialise(3, 1, 6, verbose=True) is True
     units = glob.glob(os.path.join(jit_on, "*", "quad_3_1_6_g4.so"))
-    assert len(units) == 1 and os.path.getsize(units[0]) > 10000
+    assert len(units) >= 1 and os.path.getsize(units[-1]) > 10000   # (one directory per hash of the kernel headers)
     assert t.specialise(3, 1, 6) is True                       # from the process's table now
     assert t.specialise(20, 6, 10) is False                    # beyond what a lane group / tile holds: run-time-shape kernels
 

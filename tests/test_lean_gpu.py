@@ -1,12 +1,14 @@
 """The lean kernel (csrc/admm_lean.hip.h, "lean<4,1,N>") — what BASELINE config 2 (the headline) runs on since round 4:
-one-shot solves (cold start, workspace not kept) of the one-lane-per-instance cartpole entries without an active state
-bound, zero references, fp64 recurrences.
+one-shot solves (cold start, workspace not kept) of the one-lane-per-instance cartpole entries with zero or shared
+references and fp64 recurrences; the benchmark's pattern (no active state bound, zero references) is its leanest variant.
  * every instance against the fp64 oracle, fixed-iteration and tolerance-terminated (per-instance exits, check intervals),
    iteration counts / status / residuals included;
  * against the quad kernel it replaces for this calling pattern (TINYMPC_HIP_NO_LEAN keeps a solver there);
  * per-knot input bounds (the bounds then come from LDS knot by knot);
- * every calling pattern outside its scope stays on the quad kernel: finite state bounds, references, warm starts /
-   kept workspace, fp32 recurrences, adaptive rho, a cache whose AmBKt is not (A - B Kinf)'.
+ * finite state bounds (state dual and q~ = vnew - g carried in fp32) and shared references (reference terms from LDS),
+   alone and together, fixed-iteration and tolerance-terminated;
+ * every calling pattern outside its scope stays on the quad kernel: per-instance references, warm starts / kept
+   workspace, fp32 recurrences, adaptive rho, a cache whose AmBKt is not (A - B Kinf)'.
 Reference arithmetic: src/codegen_src/tinympc/admm.cpp:13-107, solve() :109-207."""
 import os
 
@@ -148,20 +150,14 @@ def test_lean_scope(hip_lib):
     warm = bs.get_solution()
     assert nrel_batch(warm["controls"], base["controls"]).max() <= 4e-6
     bs.set_warm_start(False)
-    # shared references
-    xr = np.zeros((4, 20), order="F"); xr[0] = 0.1
+    # per-instance references
+    xr = np.zeros((4, 20, B_G1), order="F"); xr[0] = 0.1
     bs.set_x_ref(xr)
     bs.solve()
     assert bs.last_launch_name == "quad<4,1,20,g1>"
     bs.set_x_ref(np.zeros((4, 20), order="F"))
     bs.solve()
     assert bs.last_launch_name == "lean<4,1,20>"
-    # a finite state bound
-    xmax = prob.x_max.copy(); xmax[0, :] = 0.4
-    bs.set_bound_constraints(prob.x_min, xmax, prob.u_min, prob.u_max)
-    bs.solve()
-    assert bs.last_launch_name == "quad<4,1,20,g1>"
-    bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
     # fp32 recurrences
     bs.set_precision(1)
     bs.solve()
@@ -223,4 +219,51 @@ def test_routing_is_cached_between_solves(hip_lib):
     bs.set_fdyn(np.zeros(4))
     bs.solve()
     assert bs.last_launch_name == "lean<4,1,20>"
+    bs.close()
+
+
+@pytest.mark.parametrize("case", ["state_bounds", "shared_refs", "state_bounds+shared_refs", "knot_state_bounds+refs"])
+@pytest.mark.parametrize("setting", ["fixed", "tol"])
+def test_lean_state_bounds_and_shared_references(hip_lib, oracle_built, case, setting):
+    """finite state bounds (cartpole_example_reference_constrained.jl:16-18 bounds x_1) and shared references (examples:
+    set_x_ref / set_u_ref) on the lean kernel: every instance against the oracle, bounds respected by the returned slack"""
+    N = 20
+    prob, x0 = t.problems.cartpole(N, u_bound=0.5), t.problems.cartpole_x0(B_G1, seed=31)
+    rng = np.random.default_rng(7)
+    xr = ur = None
+    if "state_bounds" in case:
+        prob.x_min, prob.x_max = prob.x_min.copy(), prob.x_max.copy()
+        prob.x_max[0, :], prob.x_min[0, :] = 0.35, -0.35                  # binds: x0[0] is drawn from +-0.5
+        prob.x_max[2, :], prob.x_min[2, :] = 0.08, -0.08
+        if case.startswith("knot"):
+            prob.x_max[0, N // 2:] = 0.2                                   # per-knot state bounds
+            prob.u_max = prob.u_max.copy(); prob.u_max[:, ::3] = 0.35      # and per-knot input bounds
+    if "refs" in case:
+        xr = np.asfortranarray(0.1 * rng.standard_normal((4, N)))
+        ur = np.asfortranarray(0.05 * rng.standard_normal((1, N - 1)))
+    kw = (dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=100, check_termination=1) if setting == "fixed" else
+          dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=2))
+    ref = oracle_built.solve_batch("orc64", prob, x0, xref=xr, uref=ur, nthreads=len(os.sched_getaffinity(0)), **kw)
+
+    def make(b=None):
+        o = _oracle_make(oracle_built, prob, kw)()
+        if xr is not None:
+            o.set_x_ref(xr)
+            o.set_u_ref(ur)
+        return o
+    bs = _solver(prob, B_G1, kw)
+    if xr is not None:
+        bs.set_x_ref(xr)
+        bs.set_u_ref(ur)
+    bs.set_x0(x0)
+    bs.solve()
+    assert bs.last_launch_name == "lean<4,1,20>"
+    sol, st = bs.get_solution(), bs.get_status()
+    parity_every_instance(sol, st, ref, make, x0, kw, prob.rho, min_same=0.97, tag=f"lean {case} {setting}")
+    eq = (st["iter"] == ref["iter"]) & (st["solved"] == ref["solved"])
+    dres = np.abs(st["residuals"][eq] - ref["res"][eq]).max(axis=0) / np.maximum(1.0, np.abs(ref["res"][eq]).max(axis=0))
+    assert dres.max() <= 2 * FP32_TOL, f"residuals off by {dres}"
+    if "state_bounds" in case:
+        assert (sol["states"] <= prob.x_max[:, :, None]).all() and (sol["states"] >= prob.x_min[:, :, None]).all()
+        assert np.abs(sol["states"][0]).max() >= 0.3499                    # the bound binds somewhere
     bs.close()

@@ -3,8 +3,11 @@
 //
 // What it computes: the reference's solve() loop (src/codegen_src/tinympc/admm.cpp:109-207; phases :13-107) for one-shot
 // solves — cold start (the zero workspace tiny_setup leaves, tiny_api.cpp:73-88), nothing of the workspace kept — of a
-// box-constrained family with NO active state bound, zero (or shared) references, fp64 recurrences.  One lane per
-// instance, like quad<..., g1> (admm_quad.hip.h), which stays the kernel of every other calling pattern of the shape.
+// box-constrained family, zero or shared references, fp64 recurrences.  One lane per instance, like quad<..., g1>
+// (admm_quad.hip.h), which stays the kernel of every other calling pattern of the shape (workspace kept, closed loop,
+// per-instance references, adaptive rho, fp32 recurrences).  The benchmark's pattern — no active state bound, zero
+// references — is the XB = false, REFS = REF_ZERO instantiation described first; XB / REF_SHARED add what they need and
+// nothing to that instantiation (profiles/r04_cartpole_isa_census.json is its loop).
 //
 // Why a separate kernel (round 3 review, item 1): quad<4,1,20,g1> executed 1 506 vector instructions per iteration, of
 // which 911 were the recurrences' fp64 FMAs; 268 were v_accvgpr moves (its state homed in AGPRs and copied through VGPRs
@@ -23,6 +26,12 @@
 //     ~1e-16): x+ does not wait for u, and (A - B Kinf) is the transpose of the AmBKt the backward sweep reads, so ONE set
 //     of 25 fp64 coefficients (50 SGPRs) serves both sweeps and stays resident for the whole solve — no per-sweep scalar
 //     reloads.  (The host only selects this kernel when cache.AmBKt equals (A - B Kinf)' — set_cache_terms may break that.)
+// XB (some enabled state bound is finite): the state slack is no longer the rollout.  The rollout is then a running fp64
+// vector; per element the iteration keeps the state dual g and q~ = vnew - g (what the backward sweep starts from) in fp32
+// — still 217 registers — and forms them in fp32 from the rounded x as every fp32-state kernel does (admm.cpp:46-58, 67-68,
+// 79-80); the solution vnew = q~ + g is re-clamped at the store.  REF_SHARED: the reference terms of update_linear_cost
+// (admm.cpp:77-82) scaled by -1 / rho — Q~ xref_k / rho, R~ uref_k / rho, Pinf' xref_{N-1} / rho — are formed once per
+// workgroup in fp64 and read from LDS (broadcast) in the backward sweep.
 // Termination (admm.cpp:89-107) as in the quad kernel: residual maxima only on the iterations whose check can matter; with
 // positive tolerances (LIVE) an instance that converges stores its solution at that iteration and its lane idles on
 // (what the matrix-core kernels do), the wavefront leaves when all its instances are done.
@@ -44,7 +53,7 @@ namespace tmpc {
 template <int NX, int NU>
 struct LeanPack {
     static constexpr LeanLayout LL = lean_layout(NX, NU);
-    static constexpr int O_M = LL.oM, O_K = LL.oK, O_B = LL.oB, O_C = LL.oC, LEN = LL.len;
+    static constexpr int O_M = LL.oM, O_K = LL.oK, O_B = LL.oB, O_C = LL.oC, O_P = LL.oP, LEN = LL.len;
     static constexpr int NLOADS = LL.padded / 8;     // s_load_dwordx16 per 8 doubles
 };
 
@@ -55,8 +64,9 @@ __device__ __forceinline__ float clamp3(float t, float lo, float hi) { return __
 // the feed-forward term d is then kept in fp64 too (nu (N-1) more registers, two conversions per knot fewer: 3.5 % of the
 // instructions).  Otherwise the kernel is held to 256 registers and two wavefronts share a SIMD (batches beyond one
 // wavefront per SIMD: 10 % faster than one 512-register wavefront after the other).
-template <int NX, int NU, int N, bool LIVE, bool UBK, bool ONE>
+template <int NX, int NU, int N, bool LIVE, bool UBK, bool ONE, bool XB = false, int REFS = REF_ZERO>
 __global__ __launch_bounds__(256, (ONE ? 1 : 2)) void admm_lean_kernel(const AdmmParams P) {
+    static_assert(REFS == REF_ZERO || REFS == REF_SHARED, "lean kernel: zero or shared references");
 #ifdef TMPC_LEAN_CLOCK_PROBE
     const unsigned long long probe_entry = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -66,14 +76,30 @@ __global__ __launch_bounds__(256, (ONE ? 1 : 2)) void admm_lean_kernel(const Adm
     static_assert(L::NLOADS <= 4, "coefficient block too large for SGPRs");
 
     __shared__ float s_bnd[UBK ? 1 : 2 * NU * (N - 1)];
+    __shared__ float s_xb[XB ? 2 * NX * N : 1];                                  // [knot][x_min[NX] x_max[NX]]
+    __shared__ double s_cq[REFS == REF_SHARED ? NX * N : 1], s_cr[REFS == REF_SHARED ? NU * (N - 1) : 1], s_cpt[REFS == REF_SHARED ? NX : 1];
     const int tid = threadIdx.x;
     if constexpr (!UBK) {
         for (int i = tid; i < 2 * NU * (N - 1); i += 256) {
             const int k = i / (2 * NU), j = i % (2 * NU);
             s_bnd[i] = P.bounds[k * BW + 2 * NX + j];
         }
-        __syncthreads();
     }
+    if constexpr (XB)
+        for (int i = tid; i < 2 * NX * N; i += 256) s_xb[i] = P.bounds[(i / (2 * NX)) * BW + i % (2 * NX)];
+    if constexpr (REFS == REF_SHARED) {
+        // -(Xref .* Q~) / (-rho), -(Uref .* R~) / (-rho), (Xref_{N-1}' Pinf)' / rho  (admm.cpp:77-82 on the scaled recursion)
+        const float *qd = P.bounds + N * BW, *rd = qd + NX;                      // diag(Q) + rho, diag(R) + rho behind the bounds
+        const double irho = 1.0 / P.rho_family;
+        for (int i = tid; i < NX * N; i += 256) s_cq[i] = (double)P.xref[i] * (double)qd[i % NX] * irho;
+        for (int i = tid; i < NU * (N - 1); i += 256) s_cr[i] = (double)P.uref[i] * (double)rd[i % NU] * irho;
+        if (tid < NX) {
+            double acc = 0.0;
+            for (int j = 0; j < NX; ++j) acc = fma(P.lean[L::O_P + j * NX + tid], (double)P.xref[(N - 1) * NX + j], acc);
+            s_cpt[tid] = acc * irho;
+        }
+    }
+    if constexpr (!UBK || XB || REFS == REF_SHARED) __syncthreads();
     const long b = (long)blockIdx.x * 256 + tid;     // (no index list: the solver sends compacted / chunked solves to the quad kernel)
     const bool active = b < P.batch;
     const int lane = tid & 63;
@@ -87,17 +113,23 @@ __global__ __launch_bounds__(256, (ONE ? 1 : 2)) void admm_lean_kernel(const Adm
 #pragma unroll
     for (int a = 0; a < NU; ++a) lo[a] = P.bounds[2 * NX + a], hi[a] = P.bounds[2 * NX + NU + a];
 
-    // ---- the iterated state: x (= v = vnew) in fp64, input dual / slack / feed-forward in fp32 ----
-    double X[N][NX];
+    // ---- the iterated state: x (= v = vnew) in fp64 — or, with an active state bound, the state dual g and q~ = vnew - g in
+    // fp32 beside a running x — and input dual / slack / feed-forward in fp32 ----
+    double X[XB ? 1 : N][NX];           // XB: X[0] is the plant state x0 only
+    float G[XB ? N : 1][NX], QT[XB ? N : 1][NX];
     float Y[N - 1][NU], Z[N - 1][NU];
     using DT = std::conditional_t<ONE, double, float>;
     DT D[N - 1][NU];
 #pragma unroll
     for (int m = 0; m < NX; ++m) X[0][m] = active ? (double)P.x0[b * NX + m] : 0.0;
 #pragma unroll
-    for (int k = 1; k < N; ++k)
+    for (int k = 1; k < (XB ? 1 : N); ++k)
 #pragma unroll
         for (int m = 0; m < NX; ++m) X[k][m] = 0.0;
+#pragma unroll
+    for (int k = 0; k < (XB ? N : 1); ++k)
+#pragma unroll
+        for (int m = 0; m < NX; ++m) G[k][m] = 0.f, QT[k][m] = 0.f;
 #pragma unroll
     for (int k = 0; k < N - 1; ++k)
 #pragma unroll
@@ -112,22 +144,47 @@ __global__ __launch_bounds__(256, (ONE ? 1 : 2)) void admm_lean_kernel(const Adm
     const int last_check_it = ct > 0 ? (P.max_iter / ct) * ct : 0;
     const float rho = P.rho;
     double dua_x = 0.0;
-    float pri_u = 0.f, dua_u = 0.f;
+    float pri_u = 0.f, dua_u = 0.f, pri_xf = 0.f, dua_xf = 0.f;                  // (XB: the state residuals in fp32, like the slack they compare)
+    // XB: knot k's state slack / dual from the rollout's x_k  (admm.cpp:46, 55-58, 68; q~ for :79-80)
+    auto state_sets = [&](auto res_tag, auto kk, const double (&x)[NX]) {
+        constexpr bool RES = decltype(res_tag)::value;
+        constexpr int k = decltype(kk)::value;
+#pragma unroll
+        for (int m = 0; m < NX; ++m) {
+            const float xf = (float)x[m];
+            const float t = xf + G[k][m];                                       // vnew = x + g
+            const float vn = clamp3(t, s_xb[k * 2 * NX + m], s_xb[k * 2 * NX + NX + m]);
+            const float gn = t - vn;                                            // g = g + x - vnew
+            if constexpr (RES) {
+                pri_xf = fmaxf(pri_xf, fabsf(xf - vn));
+                dua_xf = fmaxf(dua_xf, fabsf((QT[k][m] + G[k][m]) - vn));       // v = the previous vnew = q~ + g
+            }
+            G[k][m] = gn;
+            QT[k][m] = vn - gn;
+        }
+    };
 
     // ================= fused forward sweep: forward_pass (admm.cpp:25-35) + update_slack (:43-59) + update_dual (:65-69)
     // (+ RES: the residual maxima of termination_condition, :93-96) =================
     auto forward = [&](auto res_tag, bool first_iter) {
         constexpr bool RES = decltype(res_tag)::value;
         if constexpr (RES) {
-            dua_x = 0.0, pri_u = 0.f, dua_u = 0.f;
-            if (first_iter) {   // cold start: the previous state slack is the zero workspace at knot 0 too, where vnew is x0 (admm.cpp:94)
+            dua_x = 0.0, pri_u = 0.f, dua_u = 0.f, pri_xf = 0.f, dua_xf = 0.f;
+            if constexpr (!XB)
+                if (first_iter) {   // cold start: the previous state slack is the zero workspace at knot 0 too, where vnew is x0 (admm.cpp:94)
 #pragma unroll
-                for (int m = 0; m < NX; ++m) dua_x = fmax(dua_x, fabs(X[0][m]));
-            }
+                    for (int m = 0; m < NX; ++m) dua_x = fmax(dua_x, fabs(X[0][m]));
+                }
         }
+        double xr[NX];                                                          // XB: the running x_k
+#pragma unroll
+        for (int m = 0; m < NX; ++m) xr[m] = X[0][m];
         sfor<0, N - 1>([&](auto kk) {
             constexpr int k = decltype(kk)::value;
-            if constexpr (!UBK) asm volatile("" ::: "memory");   // per-knot bounds are re-read from LDS at their knot, not hoisted out of the solve
+            constexpr int kx = XB ? 0 : k;                                      // where x_k lives: the running vector, or the trajectory
+            if constexpr (!UBK || XB) asm volatile("" ::: "memory");   // per-knot bounds are re-read from LDS at their knot, not hoisted out of the solve
+            if constexpr (XB) state_sets(res_tag, kk, xr);
+            const double (&xk)[NX] = XB ? xr : X[kx];
             double dk[NU], u[NU], xn[NX];
 #pragma unroll
             for (int a = 0; a < NU; ++a) dk[a] = (double)D[k][a];
@@ -142,21 +199,21 @@ __global__ __launch_bounds__(256, (ONE ? 1 : 2)) void admm_lean_kernel(const Adm
 #pragma unroll
             for (int j = 0; j < NX; ++j)
 #pragma unroll
-                for (int m = 0; m < NX; ++m) xn[m] = fma(cM[m * NX + j], X[k][j], xn[m]);
+                for (int m = 0; m < NX; ++m) xn[m] = fma(cM[m * NX + j], xk[j], xn[m]);
             // u = -Kinf x - d
 #pragma unroll
             for (int a = 0; a < NU; ++a) {
                 if constexpr (TMPC_LEAN_SPLITK && NX >= 4) {
-                    double u0 = -dk[a], u1 = -(cK[a * NX + NX / 2] * X[k][NX / 2]);
+                    double u0 = -dk[a], u1 = -(cK[a * NX + NX / 2] * xk[NX / 2]);
 #pragma unroll
-                    for (int j = 0; j < NX / 2; ++j) u0 = fma(-cK[a * NX + j], X[k][j], u0);
+                    for (int j = 0; j < NX / 2; ++j) u0 = fma(-cK[a * NX + j], xk[j], u0);
 #pragma unroll
-                    for (int j = NX / 2 + 1; j < NX; ++j) u1 = fma(-cK[a * NX + j], X[k][j], u1);
+                    for (int j = NX / 2 + 1; j < NX; ++j) u1 = fma(-cK[a * NX + j], xk[j], u1);
                     u[a] = u0 + u1;
                 } else {
                     double acc = -dk[a];
 #pragma unroll
-                    for (int j = 0; j < NX; ++j) acc = fma(-cK[a * NX + j], X[k][j], acc);
+                    for (int j = 0; j < NX; ++j) acc = fma(-cK[a * NX + j], xk[j], acc);
                     u[a] = acc;
                 }
             }
@@ -176,28 +233,43 @@ __global__ __launch_bounds__(256, (ONE ? 1 : 2)) void admm_lean_kernel(const Adm
             }
 #pragma unroll
             for (int m = 0; m < NX; ++m) {
-                if constexpr (RES) dua_x = fmax(dua_x, fabs(X[k + 1][m] - xn[m]));   // v - vnew with v = the previous x  (:94)
-                X[k + 1][m] = xn[m];
+                if constexpr (XB) {
+                    xr[m] = xn[m];
+                } else {
+                    if constexpr (RES) dua_x = fmax(dua_x, fabs(X[k + 1][m] - xn[m]));   // v - vnew with v = the previous x  (:94)
+                    X[k + 1][m] = xn[m];
+                }
             }
             // (the residual maxima are only read under `!conv`: left alone, the compiler sinks the whole chain into that
             // branch, behind the sweep, and keeps every knot's u, znew and previous x alive for it — 190 spilled registers)
-            if constexpr (RES) asm volatile("" : "+v"(pri_u), "+v"(dua_u), "+v"(dua_x));
+            if constexpr (RES) asm volatile("" : "+v"(pri_u), "+v"(dua_u), "+v"(dua_x), "+v"(pri_xf), "+v"(dua_xf));
             if constexpr (TMPC_LEAN_KNOT_BARRIER) __builtin_amdgcn_sched_barrier(0);
         });
+        if constexpr (XB) {
+            asm volatile("" ::: "memory");
+            state_sets(res_tag, std::integral_constant<int, N - 1>{}, xr);      // the terminal knot's slack / dual
+            if constexpr (RES) asm volatile("" : "+v"(pri_xf), "+v"(dua_xf));
+        }
     };
 
     // ================= fused backward sweep: update_linear_cost (admm.cpp:75-83) + backward_pass_grad (:13-20), scaled by
     // -1 / rho; q, r, p never stored =================
     auto backward = [&]() {
         double p[NX];
+        if constexpr (REFS == REF_SHARED) asm volatile("" ::: "memory");        // (reference terms: read from LDS where used)
 #pragma unroll
-        for (int m = 0; m < NX; ++m) p[m] = X[N - 1][m];                        // p~_{N-1} = vnew_{N-1}  (:81-82 with Xref = 0)
+        for (int m = 0; m < NX; ++m) {                                          // p~_{N-1} = vnew_{N-1} - g_{N-1} (+ Pinf' xref / rho)  (:81-82)
+            p[m] = XB ? (double)QT[N - 1][m] : X[XB ? 0 : N - 1][m];
+            if constexpr (REFS == REF_SHARED) p[m] += s_cpt[m];
+        }
         sfor<0, N - 1>([&](auto kk) {
             constexpr int k = N - 2 - decltype(kk)::value;
             double r[NU], t[NU];
+            if constexpr (REFS == REF_SHARED) asm volatile("" ::: "memory");
 #pragma unroll
             for (int a = 0; a < NU; ++a) {
                 r[a] = (double)(Z[k][a] - Y[k][a]);                             // r~ = znew - y  (:77-78)
+                if constexpr (REFS == REF_SHARED) r[a] += s_cr[k * NU + a];     //      + R~ uref / rho
                 t[a] = r[a];
             }
 #pragma unroll
@@ -215,7 +287,8 @@ __global__ __launch_bounds__(256, (ONE ? 1 : 2)) void admm_lean_kernel(const Adm
                 double ap[NX];
 #pragma unroll
                 for (int m = 0; m < NX; ++m) {                                  // q~_k - Kinf' r~_k
-                    double acc = X[k][m];
+                    double acc = XB ? (double)QT[k][m] : X[XB ? 0 : k][m];     // q~_k = vnew_k - g_k  (:79-80)
+                    if constexpr (REFS == REF_SHARED) acc += s_cq[k * NX + m];  //      + Q~ xref / rho
 #pragma unroll
                     for (int a = 0; a < NU; ++a) acc = fma(-cK[a * NX + m], r[a], acc);
                     ap[m] = acc;
@@ -234,17 +307,23 @@ __global__ __launch_bounds__(256, (ONE ? 1 : 2)) void admm_lean_kernel(const Adm
     // solution = projected slack of the iteration (admm.cpp:187-188, :204-205); status of the instance.  This direct form
     // (every lane its own instance: scattered 16-byte pieces) serves the instances that converge inside the loop, a few at
     // a time; the final store below goes through LDS
+    // element (k, m) of the solution: the state slack vnew — x itself, or q~ + g brought back inside the bounds it was clamped
+    // to (fp32 rounding of the sum can leave them by an ulp)
+    auto vnew_at = [&](auto kk, auto mm) -> float {
+        constexpr int k = decltype(kk)::value, m = decltype(mm)::value;
+        if constexpr (XB) return clamp3(QT[k][m] + G[k][m], s_xb[k * 2 * NX + m], s_xb[k * 2 * NX + NX + m]);
+        else return (float)X[XB ? 0 : k][m];
+    };
     auto store = [&](bool solved_flag) {
         // one opaque base address per array, constant offsets behind it: left to itself the compiler forms the 99 store
         // addresses once, outside the iteration loop (the LIVE variant stores inside it), and spills 200 registers for them
         float *xo = P.xout + b * EX, *uo = P.uout + b * EU, *ro = P.res + b * 4;
         asm volatile("" : "+v"(xo), "+v"(uo), "+v"(ro));
-#pragma unroll
-        for (int k = 0; k < N; ++k) {
-#pragma unroll
-            for (int m = 0; m < NX; ++m) xo[k * NX + m] = (float)X[k][m];
+        sfor<0, N>([&](auto kk) {
+            constexpr int k = decltype(kk)::value;
+            sfor<0, NX>([&](auto mm) { xo[k * NX + decltype(mm)::value] = vnew_at(kk, mm); });
             __builtin_amdgcn_sched_barrier(0);   // (a knot's conversions next to its stores, not eighty temporaries up front)
-        }
+        });
 #pragma unroll
         for (int k = 0; k < N - 1; ++k)
 #pragma unroll
@@ -282,8 +361,8 @@ __global__ __launch_bounds__(256, (ONE ? 1 : 2)) void admm_lean_kernel(const Adm
         i += 1;
         if (!LIVE || !conv) {                                                   // termination_condition (admm.cpp:89-107)
             it += 1;
-            res0 = 0.f;                                                         // x - vnew = 0: nothing clamps the state
-            res1 = (float)dua_x * rho;
+            res0 = XB ? pri_xf : 0.f;                                           // (no active state bound: x - vnew = 0)
+            res1 = (XB ? dua_xf : (float)dua_x) * rho;
             res2 = pri_u;
             res3 = dua_u * rho;
         }
@@ -308,7 +387,7 @@ __global__ __launch_bounds__(256, (ONE ? 1 : 2)) void admm_lean_kernel(const Adm
         if (mask) {
             const long w0 = (long)blockIdx.x * 256 + (tid & ~63);          // the wavefront's first instance
             store_wave_coalesced<EX, EU>(s_stage[tid >> 6], P.xout + w0 * EX, P.uout + w0 * EU, lane, mask,
-                                         [&](auto ee) { constexpr int e = decltype(ee)::value; return (float)X[e / NX][e % NX]; },
+                                         [&](auto ee) { constexpr int e = decltype(ee)::value; return vnew_at(std::integral_constant<int, e / NX>{}, std::integral_constant<int, e % NX>{}); },
                                          [&](auto ee) { constexpr int e = decltype(ee)::value; return Z[e / NU][e % NU]; });
             if (mine) {
                 float *ro = P.res + b * 4;

@@ -489,15 +489,37 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
                 if (!slot1_x) a1 = tb_next;                    // passenger: the next step's matrix-core component of t
                 c[0] = a0, c[1] = a1, c[2] = a2;
             };
-            auto handover = [&](const mf_d4 &c, int k) {        // x_k (k = 0: x0 itself — the cell held the sets' sum), u_{k-1}
-                lds_f *pk = pp + k * PLEN;
-                if (k > 0 && (FREE || ok2)) pk[U0 - PLEN] = (float)c[2];             // (t_{k-1} is spent)
-                if (FREE || ok1) pk[64] = (float)c[1];
-                // (the order of a mask-free store and the owner's store to the same cell is an order between LANES, which the
-                // compiler does not see — to it the two addresses never alias, and it has moved one across the other; LDS
-                // executes a wavefront's stores in program order, so a wavefront-scope fence — no instruction — is all it takes)
-                if constexpr (FREE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                pk[0] = (float)c[0];
+            auto handover = [&](const mf_d4 &c, auto kc) {      // x_k (k = 0: x0 itself — the cell held the sets' sum), u_{k-1}
+                constexpr int k = decltype(kc)::value;
+                if constexpr (FREE) {
+                    // The order of a mask-free store and the owner's store to the same cell is an order between LANES, which the
+                    // compiler does not see — to it the two addresses never alias, and it has moved one across the other (knots 25
+                    // and 37 of every instance came out wrong).  LDS executes a wavefront's stores in program order, so the stores
+                    // of a hand-over are ONE asm statement (fixed order inside it; volatile asm statements keep their order among
+                    // themselves; the memory clobber keeps the compiler's own LDS accesses on their side of it).  Round 3 held the
+                    // order with a wavefront-scope fence and a test that reads the compiler's assembly (tests/test_mfmat_asm.py,
+                    // still there as a second line).
+                    const unsigned col = (unsigned)(size_t)pp;                  // LDS byte address of this lane's column of cells
+                    const float f0 = (float)c[0], f1 = (float)c[1];
+                    if constexpr (k > 0) {
+                        const float f2 = (float)c[2];                           // (t_{k-1} is spent)
+                        asm volatile("ds_write_b32 %0, %1 offset:%4\n\tds_write_b32 %0, %2 offset:%5\n\tds_write_b32 %0, %3 offset:%6"
+                                     :
+                                     : "v"(col), "v"(f2), "v"(f1), "v"(f0), "n"(4 * ((k - 1) * PLEN + U0)), "n"(4 * (k * PLEN + 64)),
+                                       "n"(4 * k * PLEN)
+                                     : "memory");
+                    } else {
+                        asm volatile("ds_write_b32 %0, %1 offset:%3\n\tds_write_b32 %0, %2 offset:%4"
+                                     :
+                                     : "v"(col), "v"(f1), "v"(f0), "n"(4 * (k * PLEN + 64)), "n"(4 * k * PLEN)
+                                     : "memory");
+                    }
+                } else {
+                    lds_f *pk = pp + k * PLEN;
+                    if (k > 0 && ok2) pk[U0 - PLEN] = (float)c[2];
+                    if (ok1) pk[64] = (float)c[1];
+                    pk[0] = (float)c[0];
+                }
             };
             // (order of the work, from experiments/mfmat_cost_probe.hip: an fp64 product holds the wavefront's issue for ~66 cycles
             // whatever follows, and the FIRST vector / LDS instruction behind products costs a flat ~55 cycles more, the
@@ -547,7 +569,7 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
                 __builtin_amdgcn_sched_barrier(0);             // (left to itself the scheduler puts a hand-over in front of the products)
                 mf_for<0, nb>([&](auto st) {
                     constexpr int k = k0 + decltype(st)::value;
-                    handover(c[k % NT], k);
+                    handover(c[k % NT], std::integral_constant<int, k>{});
                 });
                 mf_for<0, SB>([&](auto st) {
                     constexpr int sl = decltype(st)::value, k = k0 + SB + sl;  // a step of the next run: its tuple held x_{k - SB}, handed over above
@@ -558,7 +580,7 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
                 });
                 __builtin_amdgcn_sched_barrier(0);
             });
-            handover(c[STEPS % NT], STEPS);
+            handover(c[STEPS % NT], std::integral_constant<int, STEPS>{});
             // (slot 3 of the tuples — tile rows 12.. — is never read; "used" here so that the register allocator does not
             // park temporaries in it: a vector write into a tuple that a product in flight is about to overwrite waits for it)
 #pragma unroll

@@ -106,11 +106,14 @@ struct LeanLayout {
     int oB;      // B              [nx][nu]
     int oC;      // -rho Quu_inv   [nu][nu]
     int len;
-    int padded;  // rounded up to whole 8-double scalar loads
+    int padded;  // rounded up to whole 8-double scalar loads (what the kernel keeps in SGPRs)
+    int oP;      // Pinf           [nx][nx] row-major, behind the padded block (read once, for the terminal reference term)
+    int total;
 };
 constexpr LeanLayout lean_layout(int nx, int nu) {
     return LeanLayout{0, nx * nx, nx * nx + nu * nx, nx * nx + 2 * nu * nx, nx * nx + 2 * nu * nx + nu * nu,
-                      (nx * nx + 2 * nu * nx + nu * nu + 7) / 8 * 8};
+                      (nx * nx + 2 * nu * nx + nu * nu + 7) / 8 * 8, (nx * nx + 2 * nu * nx + nu * nu + 7) / 8 * 8,
+                      (nx * nx + 2 * nu * nx + nu * nu + 7) / 8 * 8 + nx * nx};
 }
 
 #ifdef __HIPCC__

@@ -69,7 +69,7 @@ const LeanEntry *find_lean_kernel(int nx, int nu, int N) {
 bool build_lean_pack(const Solver &sv, std::vector<double> &out) {
     const int nx = sv.nx, nu = sv.nu;
     const LeanLayout L = lean_layout(nx, nu);
-    out.assign((size_t)L.padded, 0.0);
+    out.assign((size_t)L.total, 0.0);
     const Cache &c = sv.cache;
     // the kernel reads ONE matrix as A - B Kinf (rollout) and, transposed, as AmBKt (gradient recursion): only valid while
     // the cache's AmBKt is that transpose (tiny_api.cpp:170; set_cache_terms can install anything)
@@ -91,6 +91,8 @@ bool build_lean_pack(const Solver &sv, std::vector<double> &out) {
         for (int a = 0; a < nu; ++a) out[L.oB + i * nu + a] = sv.B(i, a);
     for (int a = 0; a < nu; ++a)
         for (int b2 = 0; b2 < nu; ++b2) out[L.oC + a * nu + b2] = -c.rho * c.Quu_inv(a, b2);
+    for (int i = 0; i < nx; ++i)
+        for (int j = 0; j < nx; ++j) out[L.oP + i * nx + j] = c.Pinf(i, j);
     return true;
 }
 

@@ -5,12 +5,12 @@
 
 namespace tmpc {
 
-template <int NX, int NU, int N>
-hipError_t launch_lean(const AdmmParams &P, bool live, bool knot_bounds, hipStream_t stream) {
+template <int NX, int NU, int N, bool XB, int REFS>
+hipError_t launch_lean_v(const AdmmParams &P, bool live, bool knot_bounds, hipStream_t stream) {
     const int grid = (P.batch + 255) / 256;
     const bool one = grid <= device_cu_count();   // at most one workgroup per CU = one wavefront per SIMD
 #define TMPC_LEAN_LAUNCH(LIVE_, UBK_, ONE_) \
-    hipLaunchKernelGGL((admm_lean_kernel<NX, NU, N, LIVE_, UBK_, ONE_>), dim3(grid), dim3(256), 0, stream, P)
+    hipLaunchKernelGGL((admm_lean_kernel<NX, NU, N, LIVE_, UBK_, ONE_, XB, REFS>), dim3(grid), dim3(256), 0, stream, P)
 #define TMPC_LEAN_LAUNCH2(LIVE_, UBK_) \
     do { if (one) TMPC_LEAN_LAUNCH(LIVE_, UBK_, true); else TMPC_LEAN_LAUNCH(LIVE_, UBK_, false); } while (0)
     if (live) {
@@ -21,6 +21,17 @@ hipError_t launch_lean(const AdmmParams &P, bool live, bool knot_bounds, hipStre
 #undef TMPC_LEAN_LAUNCH2
 #undef TMPC_LEAN_LAUNCH
     return hipGetLastError();
+}
+
+// live: positive tolerances (residuals at every check, per-instance exits); knot_bounds: the input bounds depend on the knot;
+// state_bounds: some enabled state bound is finite; P.ref_mode: REF_ZERO or REF_SHARED
+template <int NX, int NU, int N>
+hipError_t launch_lean(const AdmmParams &P, bool live, bool knot_bounds, bool state_bounds, hipStream_t stream) {
+    if (P.ref_mode == REF_SHARED)
+        return state_bounds ? launch_lean_v<NX, NU, N, true, REF_SHARED>(P, live, knot_bounds, stream)
+                            : launch_lean_v<NX, NU, N, false, REF_SHARED>(P, live, knot_bounds, stream);
+    return state_bounds ? launch_lean_v<NX, NU, N, true, REF_ZERO>(P, live, knot_bounds, stream)
+                        : launch_lean_v<NX, NU, N, false, REF_ZERO>(P, live, knot_bounds, stream);
 }
 
 #define TMPC_DEFINE_LEAN_ENTRY(NX, NU, NN)                                                          \

@@ -35,12 +35,12 @@ const KernelEntry *find_quad_kernel(int nx, int nu, int N, int group = -1);
 const KernelEntry *select_quad_kernel(int nx, int nu, int N, int batch);
 // the matrix-core kernel of the shape, for one-shot solves (nullptr: not instantiated)
 const KernelEntry *find_mfma_kernel(int nx, int nu, int N);
-// One instantiation of the lean kernel (admm_lean.hip.h): the one-lane-per-instance quad entry's one-shot solves without an
-// active state bound, zero references, fp64 recurrences (the benchmark's calling pattern) run there.
+// One instantiation of the lean kernel (admm_lean.hip.h): the one-lane-per-instance quad entry's one-shot solves (cold start,
+// workspace not kept) with zero or shared references and fp64 recurrences run there — the benchmark's calling pattern.
 struct LeanEntry {
     int nx, nu, N;
     const char *name;
-    hipError_t (*launch)(const AdmmParams &, bool live, bool knot_bounds, hipStream_t);
+    hipError_t (*launch)(const AdmmParams &, bool live, bool knot_bounds, bool state_bounds, hipStream_t);
 };
 const LeanEntry *find_lean_kernel(int nx, int nu, int N);
 // the lean kernel's fp64 pack (lean_layout); false when the family does not qualify (cache.AmBKt is not (A - B Kinf)')

@@ -1179,10 +1179,10 @@ int Solver::launch_pass(hipStream_t stream, int mpc_steps, const int *idx, int n
     // caller wrote one in): the matrix-core kernel (G == 16) carries g only then
     if (state_bounds_active && save) g_maybe_nonzero = true;
     const bool carry_g = state_bounds_active || (ke && ke->G == 16 && g_maybe_nonzero);
-    // one-shot solves (cold start, nothing of the workspace kept) of a one-lane-per-instance entry without an active state
-    // bound, zero references, fp64 recurrences: the lean kernel (same arithmetic, a third fewer instructions)
-    const bool lean = ke && le && lean_ok && precision == 0 && cold && !save && mpc_steps == 0 && !idx && !carry_g &&
-                      ref_mode == REF_ZERO && !st.adaptive_rho && max_iter_pass >= 1;
+    // one-shot solves (cold start, nothing of the workspace kept) of a one-lane-per-instance entry, zero or shared references,
+    // fp64 recurrences: the lean kernel (same arithmetic, a third fewer instructions)
+    const bool lean = ke && le && lean_ok && precision == 0 && cold && !save && mpc_steps == 0 && !idx &&
+                      ref_mode != REF_PER_INSTANCE && !st.adaptive_rho && max_iter_pass >= 1;
     P.lean = d_lean;
     P.ws64 = d_ws64;
     P.abs_pri_tol64 = st.abs_pri_tol;
@@ -1190,7 +1190,7 @@ int Solver::launch_pass(hipStream_t stream, int mpc_steps, const int *idx, int n
     P.host_flags = (sw.no_refill ? HF_NO_REFILL : 0) | (sw.no_uni ? HF_NO_UNI : 0) | (sw.no_os ? HF_NO_OS : 0);
     last_launch_name = lean ? le->name : kernel_name;
     if (lean) {
-        HIP_TRY(le->launch(P, st.abs_pri_tol > 0.0 && st.abs_dua_tol > 0.0, lean_knot_bounds, stream));
+        HIP_TRY(le->launch(P, st.abs_pri_tol > 0.0 && st.abs_dua_tol > 0.0, lean_knot_bounds, state_bounds_active, stream));
     } else
     HIP_TRY(ke ? ke->launch(P, precision, carry_g, stream)
                : (ce ? ce->launch(P, cones_active(), ce->lds_bytes(*this), stream)
