@@ -264,6 +264,7 @@ def test_lean_state_bounds_and_shared_references(hip_lib, oracle_built, case, se
     dres = np.abs(st["residuals"][eq] - ref["res"][eq]).max(axis=0) / np.maximum(1.0, np.abs(ref["res"][eq]).max(axis=0))
     assert dres.max() <= 2 * FP32_TOL, f"residuals off by {dres}"
     if "state_bounds" in case:
-        assert (sol["states"] <= prob.x_max[:, :, None]).all() and (sol["states"] >= prob.x_min[:, :, None]).all()
+        # (the kernel clamps to the fp32 value of a bound: float(0.2) is 3e-9 above 0.2)
+        assert (sol["states"] <= prob.x_max[:, :, None] + 1e-7).all() and (sol["states"] >= prob.x_min[:, :, None] - 1e-7).all()
         assert np.abs(sol["states"][0]).max() >= 0.3499                    # the bound binds somewhere
     bs.close()
