@@ -15,7 +15,10 @@ HIPCC = "/opt/rocm/bin/hipcc"
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
-def test_handover_store_order_in_the_compiled_rollout(tmp_path):
+@pytest.mark.parametrize("form", [0, 2])
+def test_handover_store_order_in_the_compiled_rollout(tmp_path, form):
+    """form 0: the shipped one (plain stores behind a wavefront fence: this test is its guard); form 2: the fallback for a
+    toolchain on which form 0 fails (one asm statement per hand-over, -DTMPC_MFMAT_HANDOVER=2) — known good here too"""
     from check_handover_order import decode, kernels
     csrc = os.path.join(ROOT, "tinympc-julia_amd", "csrc")
     src, out = str(tmp_path / "one.hip"), str(tmp_path / "one.s")
@@ -25,7 +28,7 @@ def test_handover_store_order_in_the_compiled_rollout(tmp_path):
                 "template __global__ void admm_mfmat_kernel<6, 3, 50, 1, 0, 0, 0, 0, false>(const AdmmParams);\n}\n")
     # the Makefile's flags for the matrix-core instantiations
     subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form",
-                    f"-I{csrc}", "--cuda-device-only", "-S", src, "-o", out], check=True)
+                    f"-DTMPC_MFMAT_HANDOVER={form}", f"-I{csrc}", "--cuda-device-only", "-S", src, "-o", out], check=True)
     ks = kernels(out)
     assert len(ks) == 2                                        # cones, plain box
     for lines in ks:

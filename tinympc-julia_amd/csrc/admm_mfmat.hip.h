@@ -428,6 +428,19 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
 #else
 #define TMPC_TPROBE(x)
 #endif
+#ifndef TMPC_MFMAT_HANDOVER
+// hand-over stores of the rollout (see `handover`): 0 = plain LDS stores behind a wavefront-scope fence, their order in the
+// compiler's assembly checked by tests/test_mfmat_asm.py on every CPU run (default: the compiler pairs and schedules them,
+// config 4 3.14 ms); 2 = ONE asm statement per hand-over, an order no compiler can change (3.22 ms: three unpaired stores the
+// scheduler cannot place — measured on one box, scripts/ab_variants.py); 1 = 2 without the memory clobber (same time).
+// A toolchain on which the assembly test fails builds with -DTMPC_MFMAT_HANDOVER=2 (make MFMAC_FLAGS=-DTMPC_MFMAT_HANDOVER=2).
+#define TMPC_MFMAT_HANDOVER 0
+#endif
+#if TMPC_MFMAT_HANDOVER == 2
+#define TMPC_MFMAT_HANDOVER_CLOBBER "memory"
+#else
+#define TMPC_MFMAT_HANDOVER_CLOBBER
+#endif
 #ifndef TMPC_MFMAT_SB
 #define TMPC_MFMAT_SB 2                                      // steps of the time recurrences per run of matrix-core products
 #endif
@@ -491,14 +504,22 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
             };
             auto handover = [&](const mf_d4 &c, auto kc) {      // x_k (k = 0: x0 itself — the cell held the sets' sum), u_{k-1}
                 constexpr int k = decltype(kc)::value;
-                if constexpr (FREE) {
+                if constexpr (FREE && TMPC_MFMAT_HANDOVER == 0) {   // plain stores, fence, the assembly test (tests/test_mfmat_asm.py)
+                    // (the order of a mask-free store and the owner's store to the same cell is an order between LANES, which the
+                    // compiler does not see — to it the two addresses never alias, and it has moved one across the other; LDS
+                    // executes a wavefront's stores in program order, so a wavefront-scope fence — no instruction — pins it)
+                    lds_f *pk = pp + k * PLEN;
+                    if (k > 0) pk[U0 - PLEN] = (float)c[2];
+                    pk[64] = (float)c[1];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    pk[0] = (float)c[0];
+                } else if constexpr (FREE) {
                     // The order of a mask-free store and the owner's store to the same cell is an order between LANES, which the
                     // compiler does not see — to it the two addresses never alias, and it has moved one across the other (knots 25
                     // and 37 of every instance came out wrong).  LDS executes a wavefront's stores in program order, so the stores
                     // of a hand-over are ONE asm statement (fixed order inside it; volatile asm statements keep their order among
-                    // themselves; the memory clobber keeps the compiler's own LDS accesses on their side of it).  Round 3 held the
-                    // order with a wavefront-scope fence and a test that reads the compiler's assembly (tests/test_mfmat_asm.py,
-                    // still there as a second line).
+                    // themselves; the memory clobber keeps the compiler's own LDS accesses on their side of it): the form for a
+                    // toolchain on which the default's assembly test fails.
                     const unsigned col = (unsigned)(size_t)pp;                  // LDS byte address of this lane's column of cells
                     const float f0 = (float)c[0], f1 = (float)c[1];
                     if constexpr (k > 0) {
@@ -507,12 +528,12 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
                                      :
                                      : "v"(col), "v"(f2), "v"(f1), "v"(f0), "n"(4 * ((k - 1) * PLEN + U0)), "n"(4 * (k * PLEN + 64)),
                                        "n"(4 * k * PLEN)
-                                     : "memory");
+                                     : TMPC_MFMAT_HANDOVER_CLOBBER);
                     } else {
                         asm volatile("ds_write_b32 %0, %1 offset:%3\n\tds_write_b32 %0, %2 offset:%4"
                                      :
                                      : "v"(col), "v"(f1), "v"(f0), "n"(4 * (k * PLEN + 64)), "n"(4 * k * PLEN)
-                                     : "memory");
+                                     : TMPC_MFMAT_HANDOVER_CLOBBER);
                     }
                 } else {
                     lds_f *pk = pp + k * PLEN;
