@@ -52,6 +52,14 @@ elif mode == "sweep":
     for B in (20480, 32768, 65536, 98304, 131072, 196608, 262144, 524288, 1048576):
         ms, name, _ = run(B, fixed, reps=12)
         print(f"{tag:34s} {name:18s} batch {B:8d}: {ms:.4f} ms  {B / ms * 1e3:.3e} solves/s", flush=True)
+elif mode == "big":      # two wavefronts per SIMD (256 registers) against the 512-register variant in turn (TINYMPC_HIP_LEAN_ONE), by pattern
+    for B in (131072, 262144):
+        for label, kw, xb in (("fixed 100", fixed, False),
+                              ("check live (tol 1e-30)", dict(abs_pri_tol=1e-30, abs_dua_tol=1e-30, max_iter=100, check_termination=1), False),
+                              ("finite state bound, fixed 100", fixed, True),
+                              ("state bound + check live", dict(abs_pri_tol=1e-30, abs_dua_tol=1e-30, max_iter=100, check_termination=1), True)):
+            ms, name, _ = run(B, kw, reps=12, xb=xb)
+            print(f"LEAN_ONE={os.environ.get('TINYMPC_HIP_LEAN_ONE', '0')} {name:14s} batch {B:7d} {label:32s}: {ms:.4f} ms", flush=True)
 elif mode == "patterns":
     for label, kw, xb in (("fixed 100", fixed, False),
                           ("check live (tol 1e-30)", dict(abs_pri_tol=1e-30, abs_dua_tol=1e-30, max_iter=100, check_termination=1), False),
@@ -74,3 +82,5 @@ for lib in libs:
     subprocess.run([sys.executable, "-c", code, lib, "sweep"], cwd=ROOT, check=False)
 subprocess.run([sys.executable, "-c", code, "-", "patterns"], cwd=ROOT, check=False)
 subprocess.run([sys.executable, "-c", code, "-", "patterns"], cwd=ROOT, check=False, env=dict(os.environ, TINYMPC_HIP_NO_LEAN="1"))
+subprocess.run([sys.executable, "-c", code, "-", "big"], cwd=ROOT, check=False)
+subprocess.run([sys.executable, "-c", code, "-", "big"], cwd=ROOT, check=False, env=dict(os.environ, TINYMPC_HIP_LEAN_ONE="1"))

@@ -92,12 +92,12 @@ struct AdmmParams {
     // ---- lean kernel (admm_lean.hip.h): its fp64 coefficient pack (LeanPack), wave-uniform ----
     const double *lean;
     // ---- launcher-side switches (read from the environment once per solver: Switches), not read by any kernel ----
-    int host_flags;   // HF_NO_REFILL | HF_NO_UNI | HF_NO_OS
+    int host_flags;   // HF_NO_REFILL | HF_NO_UNI | HF_NO_OS | HF_LEAN_ONE
     // ---- generic kernel, precision 2 (fp64 end to end): the workspace kept between solves (Ws64) and the tolerances in fp64 ----
     double *ws64;
     double abs_pri_tol64, abs_dua_tol64;
 };
-enum : int { HF_NO_REFILL = 1, HF_NO_UNI = 2, HF_NO_OS = 4 };
+enum : int { HF_NO_REFILL = 1, HF_NO_UNI = 2, HF_NO_OS = 4, HF_LEAN_ONE = 8 };
 
 // Coefficient pack of the lean kernel (admm_lean.hip.h), fp64, all wave-uniform; filled by build_lean_pack (kernels.hip).
 struct LeanLayout {

@@ -8,7 +8,11 @@ namespace tmpc {
 template <int NX, int NU, int N, bool XB, int REFS>
 hipError_t launch_lean_v(const AdmmParams &P, bool live, bool knot_bounds, hipStream_t stream) {
     const int grid = (P.batch + 255) / 256;
-    const bool one = grid <= device_cu_count();   // at most one workgroup per CU = one wavefront per SIMD
+    // The 512-register variant when the launch has at most one workgroup per CU (= one wavefront per SIMD), and — at any batch —
+    // for tolerance-terminated solves: held to 256 registers the LIVE variants spill (73-187 registers) and lose to 512-register
+    // wavefronts taking turns (batch 131 072, check live: 0.92 against 0.69 ms; with a state bound 2.95 against 1.05;
+    // fixed-iteration solves: 0.47 / 0.61 against 0.46 / 0.69 — scripts/lean_time.py "big").  TINYMPC_HIP_LEAN_ONE: always (tuning aid).
+    const bool one = grid <= device_cu_count() || live || (P.host_flags & HF_LEAN_ONE);
 #define TMPC_LEAN_LAUNCH(LIVE_, UBK_, ONE_) \
     hipLaunchKernelGGL((admm_lean_kernel<NX, NU, N, LIVE_, UBK_, ONE_, XB, REFS>), dim3(grid), dim3(256), 0, stream, P)
 #define TMPC_LEAN_LAUNCH2(LIVE_, UBK_) \

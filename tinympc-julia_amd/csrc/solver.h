@@ -87,7 +87,7 @@ struct Switches {
     bool strict_fp32 = false, no_quad = false, no_quad_adp = false, no_quad_adp1 = false, no_mfma = false, no_mfma_adp = false,
          mfma_oneshot_only = false, no_stream = false, no_stream_adp = false, no_mfmar = false, no_mfmac = false, mfmac_all = false,
          mfmac_wide = false, no_mfmat = false, mfmat_all = false, mfmat_ws_only = false, no_lean = false, no_refill = false,
-         no_uni = false, no_os = false;
+         no_uni = false, no_os = false, lean_one = false;   // lean_one: TINYMPC_HIP_LEAN_ONE — the lean kernel's 512-register variant at any batch
     int mfmac_debug = 0;    // timing probe builds only
 };
 Switches read_switches();
@@ -146,6 +146,7 @@ struct Solver {
     // one problem family PER INSTANCE: per-instance A, B (column-major, concatenated),
     // Riccati caches and diag/rho scalars; runs on the stream kernel with per-lane coefficient columns
     bool hetero = false;
+    bool no_specialise = false;   // init() does not compile an on-chip unit for the shape (jit.cpp)
     std::vector<double> het_A, het_B;
     std::vector<Cache> het_cache;
     float *d_het_aux = nullptr;

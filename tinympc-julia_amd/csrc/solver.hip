@@ -267,7 +267,8 @@ int Solver::init(const double *A_, const double *B_, const double *Q_, const dou
         return -1;
     }
     // a shape without an on-chip kernel in the library: specialise one now (jit.cpp; one-off, cached on disk)
-    if (!find_quad_kernel(nx, nu, N, -1) && !find_mfma_kernel(nx, nu, N) && !find_trans_kernel(nx, nu, N)) (void)jit_kernel_for(nx, nu, N, verbose);
+    if (!no_specialise && !find_quad_kernel(nx, nu, N, -1) && !find_mfma_kernel(nx, nu, N) && !find_trans_kernel(nx, nu, N))
+        (void)jit_kernel_for(nx, nu, N, verbose);
     if (verbose)
         std::printf("tinympc_hip: setup nx=%d nu=%d N=%d rho=%g batch=%d (Riccati %d sweeps)\n", nx, nu,
                     N, rho, batch_, cache.riccati_iters);
@@ -290,6 +291,7 @@ int Solver::init(const double *A_, const double *B_, const double *Q_, const dou
 // the host in fp64 (threaded); bounds, settings and references behave as in the single-family solver.
 int Solver::init_families(const double *A_, const double *B_, const double *Q_, const double *R_, const double *rho_,
                           int nx_, int nu_, int N_, int batch_, int device_, int verbose_) {
+    no_specialise = true;   // (a per-instance-family solver runs on the stream kernel: nothing to specialise at setup)
     if (init(A_, B_, Q_, R_, rho_[0], nx_, nu_, N_, batch_, device_, verbose_)) return -1;
     hetero = true;
     const size_t Bn = (size_t)batch, nxx = (size_t)nx * nx, nxu = (size_t)nx * nu, nuu = (size_t)nu * nu;
@@ -346,6 +348,7 @@ Switches read_switches() {
     w.no_refill = on("TINYMPC_HIP_NO_REFILL");
     w.no_uni = on("TINYMPC_HIP_NO_UNI");
     w.no_os = on("TINYMPC_HIP_NO_OS");
+    w.lean_one = on("TINYMPC_HIP_LEAN_ONE");
     if (const char *d = std::getenv("TINYMPC_HIP_MFMAC_DEBUG")) w.mfmac_debug = std::atoi(d);
     return w;
 }
@@ -1187,7 +1190,7 @@ int Solver::launch_pass(hipStream_t stream, int mpc_steps, const int *idx, int n
     P.ws64 = d_ws64;
     P.abs_pri_tol64 = st.abs_pri_tol;
     P.abs_dua_tol64 = st.abs_dua_tol;
-    P.host_flags = (sw.no_refill ? HF_NO_REFILL : 0) | (sw.no_uni ? HF_NO_UNI : 0) | (sw.no_os ? HF_NO_OS : 0);
+    P.host_flags = (sw.no_refill ? HF_NO_REFILL : 0) | (sw.no_uni ? HF_NO_UNI : 0) | (sw.no_os ? HF_NO_OS : 0) | (sw.lean_one ? HF_LEAN_ONE : 0);
     last_launch_name = lean ? le->name : kernel_name;
     if (lean) {
         HIP_TRY(le->launch(P, st.abs_pri_tol > 0.0 && st.abs_dua_tol > 0.0, lean_knot_bounds, state_bounds_active, stream));
