@@ -17,8 +17,8 @@ hipError_t launch_lean_v(const AdmmParams &P, bool live, bool knot_bounds, hipSt
     hipLaunchKernelGGL((admm_lean_kernel<NX, NU, N, LIVE_, UBK_, ONE_, XB, REFS>), dim3(grid), dim3(256), 0, stream, P)
 #define TMPC_LEAN_LAUNCH2(LIVE_, UBK_) \
     do { if (one) TMPC_LEAN_LAUNCH(LIVE_, UBK_, true); else TMPC_LEAN_LAUNCH(LIVE_, UBK_, false); } while (0)
-    if (live) {
-        if (knot_bounds) TMPC_LEAN_LAUNCH2(true, false); else TMPC_LEAN_LAUNCH2(true, true);
+    if (live) {   // (always the 512-register variant: the 256-register LIVE kernels are not even built)
+        if (knot_bounds) TMPC_LEAN_LAUNCH(true, false, true); else TMPC_LEAN_LAUNCH(true, true, true);
     } else {
         if (knot_bounds) TMPC_LEAN_LAUNCH2(false, false); else TMPC_LEAN_LAUNCH2(false, true);
     }
