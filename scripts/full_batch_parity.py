@@ -26,13 +26,13 @@ for fam in ("cartpole", "quadrotor"):
         bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
         bs.update_settings(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=100, check_termination=1)
         bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
-        os.environ["TINYMPC_HIP_STRICT_FP32"] = "1"   # precision 1 means the fp32 kernels here, also where the matrix cores would be faster
+        bs.set_strict_precision(True)   # precision 1 means the fp32 kernels here, also where the matrix cores would be faster
         bs.set_precision(prec); bs.set_warm_start(False); bs.set_x0(x0)
         bs.solve()
         sol = bs.get_solution()
         ex, eu = nrel_batch(sol["states"], ref["x"]), nrel_batch(sol["controls"], ref["u"])
         key = f"{fam}_{'f64rec' if prec == 0 else 'f32'}"
-        out[key] = dict(kernel=bs.kernel_name, batch=B, x_max=float(ex.max()), u_max=float(eu.max()),
+        out[key] = dict(kernel=bs.last_launch_name, batch=B, x_max=float(ex.max()), u_max=float(eu.max()),
                         x_p999=float(np.quantile(ex, 0.999)), u_p999=float(np.quantile(eu, 0.999)),
                         x_median=float(np.median(ex)), u_median=float(np.median(eu)),
                         n_over_1e5=int(((ex > 1e-5) | (eu > 1e-5)).sum()), oracle_seconds=t_cpu, oracle_threads=cores)

@@ -1,5 +1,5 @@
 """Instruction census of the headline kernel's ADMM iteration from the compiler's own assembly (hipcc -S of csrc/linst_4_1_20.hip):
-admm_lean_kernel<4,1,20, LIVE=false, UBK=true, ONE=true> — the benchmark's instantiation (tolerances <= 0, bounds constant over
+admm_lean_kernel<4,1,20, LIVE=false, UBK=true, ONE=true, XB=false, REFS=zero> — the benchmark's instantiation (tolerances <= 0, bounds constant over
 the knots, one wavefront per SIMD) — its innermost loop (the iterations that do not form residuals: 99 of 100), counted by class,
 next to round 3's census of quad<4,1,20,g1>.  Output: profiles/<tag>_cartpole_isa_census.json"""
 import collections, json, os, re, subprocess, sys
@@ -10,7 +10,7 @@ subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-
                 "-I" + os.path.join(ROOT, "tinympc-julia_amd/csrc"), "-S", os.path.join(ROOT, "tinympc-julia_amd/csrc/linst_4_1_20.hip"), "-o", asm], check=True,
                stderr=subprocess.DEVNULL)
 lines = open(asm).read().splitlines()
-want = "_ZN4tmpc16admm_lean_kernelILi4ELi1ELi20ELb0ELb1ELb1EEEvNS_10AdmmParamsE:"
+want = "_ZN4tmpc16admm_lean_kernelILi4ELi1ELi20ELb0ELb1ELb1ELb0ELi0EEEvNS_10AdmmParamsE:"
 start = next(i for i, l in enumerate(lines) if l.startswith(want))
 end = next(i for i in range(start + 1, len(lines)) if lines[i].startswith(".Lfunc_end"))
 body = lines[start:end]
@@ -46,7 +46,7 @@ valu = sum(v for k, v in counts.items() if k.split()[0] in ("fp64", "fp32", "AGP
 meta = {}
 for l in lines:
     pass
-out = {"kernel": "lean<4,1,20> = admm_lean_kernel<4,1,20, LIVE=false, UBK=true, ONE=true> (the benchmark's instantiation)",
+out = {"kernel": "lean<4,1,20> = admm_lean_kernel<4,1,20, LIVE=false, UBK=true, ONE=true, XB=false, REFS=zero> (the benchmark's instantiation)",
        "instructions_per_iteration": sum(counts.values()), "by_class": counts, "valu_instructions": valu,
        "necessary_fp64_fma": counts["fp64 FMA / mul / add (the recurrences)"],
        "necessary_share_of_valu": counts["fp64 FMA / mul / add (the recurrences)"] / valu,

@@ -62,8 +62,9 @@ __device__ __forceinline__ float clamp3(float t, float lo, float hi) { return __
 
 // ONE: the launch has at most one wavefront per SIMD (batch <= 256 x CUs), so the kernel may take the whole register file:
 // the feed-forward term d is then kept in fp64 too (nu (N-1) more registers, two conversions per knot fewer: 3.5 % of the
-// instructions).  Otherwise the kernel is held to 256 registers and two wavefronts share a SIMD (batches beyond one
-// wavefront per SIMD: 10 % faster than one 512-register wavefront after the other).
+// instructions).  Otherwise (fixed-iteration solves of larger batches) the kernel is held to 256 registers and two wavefronts
+// share a SIMD: within 3 % of 512-register wavefronts taking turns without a state bound, 12 % better with one; the
+// tolerance-terminated (LIVE) kernels spill at 256 registers and are only built in the ONE form (lean_entry.hip.h).
 template <int NX, int NU, int N, bool LIVE, bool UBK, bool ONE, bool XB = false, int REFS = REF_ZERO>
 __global__ __launch_bounds__(256, (ONE ? 1 : 2)) void admm_lean_kernel(const AdmmParams P) {
     static_assert(REFS == REF_ZERO || REFS == REF_SHARED, "lean kernel: zero or shared references");
