@@ -268,3 +268,36 @@ def test_lean_state_bounds_and_shared_references(hip_lib, oracle_built, case, se
         assert (sol["states"] <= prob.x_max[:, :, None] + 1e-7).all() and (sol["states"] >= prob.x_min[:, :, None] - 1e-7).all()
         assert np.abs(sol["states"][0]).max() >= 0.3499                    # the bound binds somewhere
     bs.close()
+
+
+@pytest.mark.parametrize("case", ["plain", "state_bounds+shared_refs", "tol"])
+def test_lean_beyond_one_wavefront_per_simd(hip_lib, oracle_built, case):
+    """a batch of more than 256 workgroups x CUs instances: fixed-iteration solves take the 256-register kernels (two
+    wavefronts per SIMD, the feed-forward term in fp32), tolerance-terminated ones the 512-register kernels in turn"""
+    B, N = 70000, 20
+    prob, x0 = t.problems.cartpole(N, u_bound=0.5), t.problems.cartpole_x0(B, seed=41)
+    xr = ur = None
+    if "state_bounds" in case:
+        prob.x_min, prob.x_max = prob.x_min.copy(), prob.x_max.copy()
+        prob.x_max[0, :], prob.x_min[0, :] = 0.35, -0.35
+        rng = np.random.default_rng(9)
+        xr, ur = np.asfortranarray(0.1 * rng.standard_normal((4, N))), np.asfortranarray(0.05 * rng.standard_normal((1, N - 1)))
+    kw = (dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1) if case == "tol" else
+          dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=100, check_termination=1))
+    ref = oracle_built.solve_batch("orc64", prob, x0, xref=xr, uref=ur, nthreads=len(os.sched_getaffinity(0)), **kw)
+
+    def make(b=None):
+        o = _oracle_make(oracle_built, prob, kw)()
+        if xr is not None:
+            o.set_x_ref(xr)
+            o.set_u_ref(ur)
+        return o
+    bs = _solver(prob, B, kw)
+    if xr is not None:
+        bs.set_x_ref(xr)
+        bs.set_u_ref(ur)
+    bs.set_x0(x0)
+    bs.solve()
+    assert bs.last_launch_name == "lean<4,1,20>"
+    parity_every_instance(bs.get_solution(), bs.get_status(), ref, make, x0, kw, prob.rho, min_same=0.97, tag=f"lean 70 000 {case}")
+    bs.close()
