@@ -119,3 +119,34 @@ def test_specialised_kernels_vs_oracle(hip_lib, oracle_built, jit_on, shape):
     bs.solve()
     assert bs.kernel_name == want
     bs.close()
+
+
+LAYOUT_UNITS = {
+    # name: (nx, nu, N, refs, cxa, cxq, cua, cuq, bv, cxa2, cxq2, cua2, cuq2, mlx, mlu)
+    "two_state_cones_rows_both_sides": (6, 3, 17, 1, 0, 3, 0, 3, "false", 3, 3, 0, 0, 1, 2),
+    "two_input_cones_knot_bounds": (6, 4, 17, 1, 1, 4, 0, 2, "true", 0, 0, 2, 2, 0, 0),
+    "rows_only_per_instance_refs": (6, 3, 12, 2, 0, 0, 0, 0, "false", 0, 0, 0, 0, 2, 0),
+    "five_states_two_inputs": (5, 2, 9, 0, 0, 3, 0, 2, "false", 3, 2, 0, 0, 0, 1),
+    "eight_states": (8, 2, 12, 1, 0, 4, 0, 2, "false", 4, 4, 0, 0, 1, 0),
+}
+
+
+@pytest.mark.parametrize("unit", list(LAYOUT_UNITS))
+def test_constraint_layout_units_compile(unit, tmp_path):
+    """what csrc/jit.cpp::jit_trans_for writes for a solver whose constraint layout no built-in `mfmat` entry has — two cones on
+    a side, linear rows, other shapes — compiles for gfx950 with the flags it uses (device code only: no GPU, no link), and
+    the kernel holds its hand-over stores in the asm form no compiler can reorder (ds_write_b32 triples of one statement)"""
+    import subprocess
+    p = LAYOUT_UNITS[unit]
+    csrc = os.path.join(os.path.dirname(os.path.abspath(t.__file__)), "csrc")
+    src = tmp_path / "unit.hip"
+    src.write_text('#include "mfmat_entry.hip.h"\nTMPC_DEFINE_MFMAT_JIT_ENTRY("mfmat<test>", ' + ", ".join(str(v) for v in p) + ")\n")
+    out = tmp_path / "unit.s"
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-honor-nans", "-DTMPC_JIT_UNIT",
+                    "-DTMPC_MFMAT_HANDOVER=2", "-mllvm", "-amdgpu-mfma-vgpr-form", "-I" + csrc, "-S", "--cuda-device-only", str(src), "-o", str(out)],
+                   check=True, capture_output=True, timeout=600)
+    asm = out.read_text()
+    assert "admm_mfmat_kernel" in asm and "v_mfma_f64_16x16x4" in asm
+    import re
+    spills = [int(m) for m in re.findall(r"\.vgpr_spill_count:\s+(\d+)", asm)]
+    assert spills and max(spills) <= 160, spills             # (the built-in N = 20 kernels spill 110 under their two-waves cap)

@@ -75,28 +75,47 @@ struct TransShape {
     static constexpr size_t lds_floats(int nk, bool pi = false) {
         return (size_t)PLEN * N + ((S::bounds_len(nk) + 1) & ~1) + (pi ? (size_t)PLEN * N : (((size_t)NROW * N + 2) & ~(size_t)1));
     }
-    // registers of the sets layout per lane and knot group: duals + previous slack of every set
-    static constexpr int group_regs(int cxq, int cuq) { return (NX + cxq + NU + cuq) + (NX + (cxq ? NX : 0) + NU + (cuq ? NU : 0)); }
-    static constexpr int state_regs(int cxq, int cuq) { return NG * group_regs(cxq, cuq); }
+    // registers of the sets layout per lane and knot group: duals + previous slack of every set (cxq / cuq: rows of all the
+    // cones of a side together; lx / lu: the side has linear-inequality rows — a third slack / dual pair of full size)
+    static constexpr int group_regs(int cxq, int cuq, bool lx = false, bool lu = false) {
+        return (NX + cxq + NU + cuq) + (NX + (cxq ? NX : 0) + NU + (cuq ? NU : 0)) + (lx ? 2 * NX : 0) + (lu ? 2 * NU : 0);
+    }
+    static constexpr int state_regs(int cxq, int cuq, bool lx = false, bool lu = false) { return NG * group_regs(cxq, cuq, lx, lu); }
     // the last group's state in LDS instead: when everything together would not fit the 512-entry file
-    static constexpr bool spill_last(int cxq, int cuq) { return NG >= 2 && state_regs(cxq, cuq) + 70 > 450; }
-    static constexpr size_t lds_bytes(int nk, int cxq, int cuq, bool pi = false) {
-        return sizeof(float) * (lds_floats(nk, pi) + (spill_last(cxq, cuq) ? (size_t)64 * group_regs(cxq, cuq) : 0)) +
+    static constexpr bool spill_last(int cxq, int cuq, bool lx = false, bool lu = false) {
+        return NG >= 2 && state_regs(cxq, cuq, lx, lu) + 70 > 450;
+    }
+    static constexpr size_t lds_bytes(int nk, int cxq, int cuq, bool pi = false, bool lx = false, bool lu = false) {
+        return sizeof(float) * (lds_floats(nk, pi) + (spill_last(cxq, cuq, lx, lu) ? (size_t)64 * (group_regs(cxq, cuq, lx, lu) + 6) : 0)) +   // (+ 6: an absent set still has a one-entry array)
                sizeof(double) * ((pi ? 16 * NX : 8) + 16 * NX + 4 * NKC);
     }
 };
 
+// What the built-in entries do not have and a unit specialised at setup can (jit.cpp): a second cone per side and
+// linear-inequality rows (bindings.cpp:414-490 takes cone LISTS and row blocks).  All compile-time, as the first cone is:
+// a cone's rows and a row's coefficients are then plain registers / scalar constants of the lane that owns the knot.
+struct TransNoExtra {
+    static constexpr int CXA2 = 0, CXQ2 = 0, CUA2 = 0, CUQ2 = 0, MLX = 0, MLU = 0;
+};
+template <int CXA2_, int CXQ2_, int CUA2_, int CUQ2_, int MLX_, int MLU_>
+struct TransExtra {
+    static constexpr int CXA2 = CXA2_, CXQ2 = CXQ2_, CUA2 = CUA2_, CUQ2 = CUQ2_, MLX = MLX_, MLU = MLU_;
+};
+
 // wavefronts per SIMD the register allocation is held to: the state registers + ~80 for everything else
-template <int NX, int NU, int N, int CXQ, int CUQ>
+template <int NX, int NU, int N, int CXQ, int CUQ, class GX = TransNoExtra>
 constexpr int mfmat_waves_per_simd() {
-    const int need = TransShape<NX, NU, N>::state_regs(CXQ, CUQ) + 80;
+    // (a second cone, rows and wider states add to the working set of a knot group: held to two wavefronts they spill — 188
+    // registers for (8, 2, 12) with two state cones and a row, tests/test_jit.py)
+    const int need = TransShape<NX, NU, N>::state_regs(CXQ + GX::CXQ2, CUQ + GX::CUQ2, GX::MLX > 0, GX::MLU > 0) + 80 +
+                     4 * (GX::MLX + GX::MLU) + (GX::CXQ2 + GX::CUQ2 > 0 ? 16 : 0) + (NX > 6 ? 8 * (NX - 6) : 0);
     return need <= 128 ? 4 : (need <= 168 ? 3 : (need <= 256 ? 2 : 1));
 }
 
 // CXA, CXQ / CUA, CUQ: first row and dimension of the state / input cone (dimension 0: none) — compile-time, so that a
 // cone's rows are plain registers of the lane.
-template <int NX, int NU, int N, int REFS, int CXA, int CXQ, int CUA, int CUQ, bool BV>
-__global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) void admm_mfmat_kernel(const AdmmParams P) {
+template <int NX, int NU, int N, int REFS, int CXA, int CXQ, int CUA, int CUQ, bool BV, class GX = TransNoExtra>
+__global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ, GX>())) void admm_mfmat_kernel(const AdmmParams P) {
     using S = ConeShape<NX, NU>;
     using T = TransShape<NX, NU, N>;
     constexpr int XS = S::XS, NROW = S::NROW, PLEN = T::PLEN, NG = T::NG;
@@ -104,7 +123,15 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
     static_assert(NX >= 4, "state slot 0 is full");
     static_assert(CXQ == 0 || (CXQ >= 2 && CXA >= 0 && CXA + CXQ <= NX), "state cone rows");
     static_assert(CUQ == 0 || (CUQ >= 2 && CUA >= 0 && CUA + CUQ <= NU), "input cone rows");
-    constexpr int NCX = CXQ > 0 ? CXQ : 1, NVX = CXQ > 0 ? NX : 1, NCU = CUQ > 0 ? CUQ : 1, NVU = CUQ > 0 ? NU : 1;
+    // second cone of a side (behind the first in the dual arrays; the cone slack is full size anyway), linear rows
+    constexpr int CXA2 = GX::CXA2, CXQ2 = GX::CXQ2, CUA2 = GX::CUA2, CUQ2 = GX::CUQ2, MLX = GX::MLX, MLU = GX::MLU;
+    static_assert(CXQ2 == 0 || (CXQ > 0 && CXQ2 >= 2 && CXA2 >= CXA + CXQ && CXA2 + CXQ2 <= NX), "second state cone: behind the first, disjoint");
+    static_assert(CUQ2 == 0 || (CUQ > 0 && CUQ2 >= 2 && CUA2 >= CUA + CUQ && CUA2 + CUQ2 <= NU), "second input cone: behind the first, disjoint");
+    static_assert(MLX >= 0 && MLX <= LIN_MAX_ROWS && MLU >= 0 && MLU <= LIN_MAX_ROWS, "linear rows");
+    constexpr bool LX = MLX > 0, LU = MLU > 0;
+    constexpr int QX = CXQ + CXQ2, QU = CUQ + CUQ2;            // cone rows of a side
+    constexpr int NCX = QX > 0 ? QX : 1, NVX = CXQ > 0 ? NX : 1, NCU = QU > 0 ? QU : 1, NVU = CUQ > 0 ? NU : 1;
+    constexpr int NLX = LX ? NX : 1, NLU = LU ? NU : 1;
     extern __shared__ __align__(16) unsigned char s_raw_t[];
     constexpr int nk = BV ? N : 1;   // BV: the bounds depend on the knot (per-knot pack in LDS), else scalars
     float *s_cells = reinterpret_cast<float *>(s_raw_t);
@@ -115,7 +142,7 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
     float *s_ref = s_bnd + ((S::bounds_len(nk) + 1) & ~1);
     double *s_pterm = reinterpret_cast<double *>(s_ref + (PI ? (size_t)PLEN * N : (((size_t)NROW * N + 2) & ~(size_t)1)));   // [NX] (PI: [NX][16])
     double *s_plant = s_pterm + (PI ? 16 * NX : 8);           // closed loop: the plant state of the tile's instances, [16][NX]
-    constexpr bool SPILL = T::spill_last(CXQ, CUQ);
+    constexpr bool SPILL = T::spill_last(QX, QU, LX, LU);
     // every lane's slot addresses stay inside the cells and the reference pack, and a lane without a row only ever reads
     // finite values that meet a zero operand column: the matrix-layout phases then run without lane masks
     constexpr bool FREE = XS == 2 && NROW >= 8 && NU >= 2;
@@ -160,6 +187,9 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
     float mux = 1.f, rmux = 1.f, muu = 1.f, rmuu = 1.f;
     if constexpr (CXQ > 0) mux = uni(P.cx[0]), rmux = uni(1.f / P.cx[0]);
     if constexpr (CUQ > 0) muu = uni(P.cu[0]), rmuu = uni(1.f / P.cu[0]);
+    float mux2 = 1.f, rmux2 = 1.f, muu2 = 1.f, rmuu2 = 1.f;
+    if constexpr (CXQ2 > 0) mux2 = uni(P.cx[1]), rmux2 = uni(1.f / P.cx[1]);
+    if constexpr (CUQ2 > 0) muu2 = uni(P.cu[1]), rmuu2 = uni(1.f / P.cu[1]);
     for (int i = l; i < S::bounds_len(nk); i += 64) s_bnd[i] = P.bounds[i];
     const int ct = P.check_termination;
     const bool can_converge = P.abs_pri_tol > 0.f && P.abs_dua_tol > 0.f;
@@ -245,13 +275,16 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
     //   LDS         (SPILL) the last group, where N is not a multiple of 4 and some of its lanes have no knot anyway.
     // Shapes whose state fits the arch VGPRs of their occupancy keep everything there (AREG = false).
     constexpr int NGR = SPILL ? NG - 1 : NG;
-    constexpr bool AREG = T::state_regs(CXQ, CUQ) + 80 > 256;
-    constexpr int DG = NX + NCX + NU + NCU;                     // duals per group
+    constexpr bool AREG = T::state_regs(QX, QU, LX, LU) + 80 > 256;
+    constexpr int RLX = LX ? NX : 0, RLU = LU ? NU : 0;
+    constexpr int DG = NX + NCX + NU + NCU + RLX + RLU;         // duals per group
     constexpr int MD = AREG ? (NGR < 150 / DG ? NGR : 150 / DG) : NGR;
     constexpr int MDA = MD > 0 ? MD : 1;
     float a1x[MDA][NX], a2x[MDA][NCX], a1u[MDA][NU], a2u[MDA][NCU];     // duals g, gc | y, yc of the groups in arch VGPRs
     float b1x[NGR][NX], b2x[NGR][NCX], b1u[NGR][NU], b2u[NGR][NCU];     // ... of the groups behind MD (AREG: AGPRs)
     float vbx[NGR][NX], vcx[NGR][NVX], vbu[NGR][NU], vcu[NGR][NVU];     // previous slack v, vc | z, zc (AREG: AGPRs)
+    float a3x[MDA][NLX], a3u[MDA][NLU], b3x[NGR][NLX], b3u[NGR][NLU];   // linear rows: duals gl | yl, as a1 / b1
+    float vlx[NGR][NLX], vlu[NGR][NLU];                                 // ... and previous slack vl | zl
     auto aget = [](const float &areg) -> float {
         float r;
         asm("v_accvgpr_read_b32 %0, %1" : "=v"(r) : "a"(areg));
@@ -260,11 +293,17 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
     auto aset = [](float &areg, float v) { asm("v_accvgpr_write_b32 %0, %1" : "=a"(areg) : "v"(v)); };
     lds_f *const sl = (lds_f *)s_last + l;
     // value r of array ID of group m, wherever it lives (r a compile-time constant after unrolling)
-    enum { S_A1X, S_A2X, S_A1U, S_A2U, S_VBX, S_VCX, S_VBU, S_VCU };
+    enum { S_A1X, S_A2X, S_A1U, S_A2U, S_VBX, S_VCX, S_VBU, S_VCU, S_A3X, S_A3U, S_VLX, S_VLU };
+    constexpr int SG_ = DG + NX + NVX + NU + NVU;              // (the four linear-row arrays behind everything else)
     auto sld = [&](auto id, auto mt, int r) -> float {
         constexpr int ID = decltype(id)::value, m = decltype(mt)::value;
-        constexpr int LOFF[8] = {0, NX, NX + NCX, NX + NCX + NU, DG, DG + NX, DG + NX + NVX, DG + NX + NVX + NU};
+        constexpr int LOFF[12] = {0, NX, NX + NCX, NX + NCX + NU, DG, DG + NX, DG + NX + NVX, DG + NX + NVX + NU,
+                                  NX + NCX + NU + NCU, NX + NCX + NU + NCU + RLX, SG_, SG_ + RLX};
         if constexpr (SPILL && m == NG - 1) return sl[64 * (LOFF[ID] + r)];
+        else if constexpr (ID == S_A3X) { if constexpr (m < MD) return a3x[m][r]; else return aget(b3x[m][r]); }
+        else if constexpr (ID == S_A3U) { if constexpr (m < MD) return a3u[m][r]; else return aget(b3u[m][r]); }
+        else if constexpr (ID == S_VLX) { if constexpr (AREG) return aget(vlx[m][r]); else return vlx[m][r]; }
+        else if constexpr (ID == S_VLU) { if constexpr (AREG) return aget(vlu[m][r]); else return vlu[m][r]; }
         else if constexpr (ID == S_A1X) { if constexpr (m < MD) return a1x[m][r]; else return aget(b1x[m][r]); }
         else if constexpr (ID == S_A2X) { if constexpr (m < MD) return a2x[m][r]; else return aget(b2x[m][r]); }
         else if constexpr (ID == S_A1U) { if constexpr (m < MD) return a1u[m][r]; else return aget(b1u[m][r]); }
@@ -276,8 +315,13 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
     };
     auto sst = [&](auto id, auto mt, int r, float v) {
         constexpr int ID = decltype(id)::value, m = decltype(mt)::value;
-        constexpr int LOFF[8] = {0, NX, NX + NCX, NX + NCX + NU, DG, DG + NX, DG + NX + NVX, DG + NX + NVX + NU};
+        constexpr int LOFF[12] = {0, NX, NX + NCX, NX + NCX + NU, DG, DG + NX, DG + NX + NVX, DG + NX + NVX + NU,
+                                  NX + NCX + NU + NCU, NX + NCX + NU + NCU + RLX, SG_, SG_ + RLX};
         if constexpr (SPILL && m == NG - 1) sl[64 * (LOFF[ID] + r)] = v;
+        else if constexpr (ID == S_A3X) { if constexpr (m < MD) a3x[m][r] = v; else aset(b3x[m][r], v); }
+        else if constexpr (ID == S_A3U) { if constexpr (m < MD) a3u[m][r] = v; else aset(b3u[m][r], v); }
+        else if constexpr (ID == S_VLX) { if constexpr (AREG) aset(vlx[m][r], v); else vlx[m][r] = v; }
+        else if constexpr (ID == S_VLU) { if constexpr (AREG) aset(vlu[m][r], v); else vlu[m][r] = v; }
         else if constexpr (ID == S_A1X) { if constexpr (m < MD) a1x[m][r] = v; else aset(b1x[m][r], v); }
         else if constexpr (ID == S_A2X) { if constexpr (m < MD) a2x[m][r] = v; else aset(b2x[m][r], v); }
         else if constexpr (ID == S_A1U) { if constexpr (m < MD) a1u[m][r] = v; else aset(b1u[m][r], v); }
@@ -341,9 +385,14 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
     kparam_ptr Pi = kparams();
     mf_for<0, NG>([&](auto mt) {
         float A1x[NX], A2x[NCX], Vbx[NX], Vcx[NVX], A1u[NU], A2u[NCU], Vbu[NU], Vcu[NVU];
+        float A3x[NLX], Vlx[NLX], A3u[NLU], Vlu[NLU];
         constexpr int m = decltype(mt)::value;
         const int kk = 4 * m + g;
         const bool xv = warm && kk < N, uv = warm && kk < N - 1;
+#pragma unroll
+        for (int r = 0; r < NLX; ++r) A3x[r] = 0.f, Vlx[r] = 0.f;
+#pragma unroll
+        for (int a = 0; a < NLU; ++a) A3u[a] = 0.f, Vlu[a] = 0.f;
         lds_f *c = cq + m * 4 * PLEN;
 #pragma unroll
         for (int r = 0; r < NX; ++r) A1x[r] = 0.f, Vbx[r] = 0.f;
@@ -367,6 +416,13 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
                 for (int r = 0; r < NX; ++r) Vcx[r] = pvc[r];
 #pragma unroll
                 for (int c2 = 0; c2 < CXQ; ++c2) A2x[c2] = pgc[CXA + c2];
+#pragma unroll
+                for (int c2 = 0; c2 < CXQ2; ++c2) A2x[CXQ + c2] = pgc[CXA2 + c2];
+            }
+            if constexpr (LX) {
+                const float *pgl = Pi->sgl + ox + m * 4 * NX, *pvl = Pi->svl + ox + m * 4 * NX;
+#pragma unroll
+                for (int r = 0; r < NX; ++r) A3x[r] = pgl[r], Vlx[r] = pvl[r];
             }
         }
         double dv[NU];
@@ -382,7 +438,22 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
                 for (int a = 0; a < NU; ++a) Vcu[a] = pzc[a];
 #pragma unroll
                 for (int c2 = 0; c2 < CUQ; ++c2) A2u[c2] = pyc[CUA + c2];
+#pragma unroll
+                for (int c2 = 0; c2 < CUQ2; ++c2) A2u[CUQ + c2] = pyc[CUA2 + c2];
             }
+            if constexpr (LU) {
+                const float *pyl = Pi->syl + ou + m * 4 * NU, *pzl = Pi->szl + ou + m * 4 * NU;
+#pragma unroll
+                for (int a = 0; a < NU; ++a) A3u[a] = pyl[a], Vlu[a] = pzl[a];
+            }
+        }
+        if constexpr (LX) {
+#pragma unroll
+            for (int r = 0; r < NX; ++r) ST(S_A3X, r, A3x[r]), ST(S_VLX, r, Vlx[r]);
+        }
+        if constexpr (LU) {
+#pragma unroll
+            for (int a = 0; a < NU; ++a) ST(S_A3U, a, A3u[a]), ST(S_VLU, a, Vlu[a]);
         }
 #pragma unroll
         for (int r = 0; r < NX; ++r) ST(S_A1X, r, A1x[r]), ST(S_VBX, r, Vbx[r]);
@@ -618,6 +689,27 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
             // has not hidden itself); its reference terms are needed only at the END of its arithmetic and are read at its
             // start — a group ahead they would be nine more registers across the group with the most live values.  Lanes
             // past the last knot read inside the allocation, unused
+            // linear-inequality rows (specialised units): coefficients, right-hand sides and |a|^2 through the scalar cache,
+            // read here and not at kernel entry — they are scalar registers of the sets phase only
+            float lax[MLX > 0 ? MLX : 1][NX], lbx[MLX > 0 ? MLX : 1], lnx[MLX > 0 ? MLX : 1];
+            float lau[MLU > 0 ? MLU : 1][NU], lbu[MLU > 0 ? MLU : 1], lnu[MLU > 0 ? MLU : 1];
+            if constexpr (LX || LU) {
+                typedef const float __attribute__((address_space(4))) *cfloat_ptr;
+                const cfloat_ptr lp = (cfloat_ptr)(reinterpret_cast<uintptr_t>(kparams()->lin));
+                constexpr int OU = MLX * (NX + 2);             // (the pack holds the enabled sides: solver.hip prepare_launch)
+#pragma unroll
+                for (int k = 0; k < MLX; ++k) {
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) lax[k][r] = lp[k * NX + r];
+                    lbx[k] = lp[MLX * NX + k], lnx[k] = lp[MLX * NX + MLX + k];
+                }
+#pragma unroll
+                for (int k = 0; k < MLU; ++k) {
+#pragma unroll
+                    for (int a = 0; a < NU; ++a) lau[k][a] = lp[OU + k * NU + a];
+                    lbu[k] = lp[OU + MLU * NU + k], lnu[k] = lp[OU + MLU * NU + MLU + k];
+                }
+            }
             float nx_[NX], nu_[NU];
             auto fetch = [&](int m) {
                 lds_f *c = cq + m * 4 * PLEN;
@@ -685,17 +777,50 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
                     for (int r = 0; r < NX; ++r) vc[r] = x[r];
 #pragma unroll
                     for (int c2 = 0; c2 < CXQ; ++c2) w2[c2] = x[CXA + c2] + LD(S_A2X, c2), vc[CXA + c2] = w2[c2];
+#pragma unroll
+                    for (int c2 = 0; c2 < CXQ2; ++c2) w2[CXQ + c2] = x[CXA2 + c2] + LD(S_A2X, CXQ + c2), vc[CXA2 + c2] = w2[CXQ + c2];
                     float sc, ax_new;
                     cone_scale(head_norm2(vc, CXA, CXQ), vc[CXA + CXQ - 1], mux, rmux, sc, ax_new);
 #pragma unroll
                     for (int c2 = 0; c2 < CXQ - 1; ++c2) vc[CXA + c2] *= sc;
                     vc[CXA + CXQ - 1] = ax_new;
+                    if constexpr (CXQ2 > 0) {
+                        cone_scale(head_norm2(vc, CXA2, CXQ2), vc[CXA2 + CXQ2 - 1], mux2, rmux2, sc, ax_new);
+#pragma unroll
+                        for (int c2 = 0; c2 < CXQ2 - 1; ++c2) vc[CXA2 + c2] *= sc;
+                        vc[CXA2 + CXQ2 - 1] = ax_new;
+                    }
 #pragma unroll
                     for (int c2 = 0; c2 < CXQ; ++c2) a2n[c2] = w2[c2] - vc[CXA + c2], ST(S_A2X, c2, a2n[c2]);
 #pragma unroll
+                    for (int c2 = 0; c2 < CXQ2; ++c2) a2n[CXQ + c2] = w2[CXQ + c2] - vc[CXA2 + c2], ST(S_A2X, CXQ + c2, a2n[CXQ + c2]);
+#pragma unroll
                     for (int r = 0; r < NX; ++r) {
-                        const bool in = r >= CXA && r < CXA + CXQ;
-                        sx[r] += in ? vc[r] - a2n[in ? r - CXA : 0] : x[r];
+                        const bool in1 = r >= CXA && r < CXA + CXQ, in2 = CXQ2 > 0 && r >= CXA2 && r < CXA2 + CXQ2;
+                        sx[r] += in1 ? vc[r] - a2n[in1 ? r - CXA : 0] : (in2 ? vc[r] - a2n[in2 ? CXQ + r - CXA2 : 0] : x[r]);
+                    }
+                }
+                float vl[NLX], zl[NLU];
+                if constexpr (LX) {
+                    // third set of the state rows: the knot's x + dual projected onto one half-space after the other
+                    // (bindings.cpp:414-450; restated in oracle/: project_halfspaces), all in this lane
+                    float w3[NX];
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) w3[r] = x[r] + LD(S_A3X, r), vl[r] = w3[r];
+#pragma unroll
+                    for (int k = 0; k < MLX; ++k) {
+                        float dot = 0.f;
+#pragma unroll
+                        for (int r = 0; r < NX; ++r) dot = fmaf(lax[k][r], vl[r], dot);
+                        const float t = (dot > lbx[k] && lnx[k] > 0.f) ? (dot - lbx[k]) / lnx[k] : 0.f;
+#pragma unroll
+                        for (int r = 0; r < NX; ++r) vl[r] -= t * lax[k][r];
+                    }
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) {
+                        const float an = w3[r] - vl[r];
+                        ST(S_A3X, r, an);
+                        sx[r] += vl[r] - an;
                     }
                 }
                 if constexpr (CUQ > 0) {
@@ -704,17 +829,47 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
                     for (int a = 0; a < NU; ++a) zc[a] = u[a];
 #pragma unroll
                     for (int c2 = 0; c2 < CUQ; ++c2) w2[c2] = u[CUA + c2] + LD(S_A2U, c2), zc[CUA + c2] = w2[c2];
+#pragma unroll
+                    for (int c2 = 0; c2 < CUQ2; ++c2) w2[CUQ + c2] = u[CUA2 + c2] + LD(S_A2U, CUQ + c2), zc[CUA2 + c2] = w2[CUQ + c2];
                     float sc, ax_new;
                     cone_scale(head_norm2(zc, CUA, CUQ), zc[CUA + CUQ - 1], muu, rmuu, sc, ax_new);
 #pragma unroll
                     for (int c2 = 0; c2 < CUQ - 1; ++c2) zc[CUA + c2] *= sc;
                     zc[CUA + CUQ - 1] = ax_new;
+                    if constexpr (CUQ2 > 0) {
+                        cone_scale(head_norm2(zc, CUA2, CUQ2), zc[CUA2 + CUQ2 - 1], muu2, rmuu2, sc, ax_new);
+#pragma unroll
+                        for (int c2 = 0; c2 < CUQ2 - 1; ++c2) zc[CUA2 + c2] *= sc;
+                        zc[CUA2 + CUQ2 - 1] = ax_new;
+                    }
 #pragma unroll
                     for (int c2 = 0; c2 < CUQ; ++c2) a2n[c2] = w2[c2] - zc[CUA + c2], ST(S_A2U, c2, a2n[c2]);
 #pragma unroll
+                    for (int c2 = 0; c2 < CUQ2; ++c2) a2n[CUQ + c2] = w2[CUQ + c2] - zc[CUA2 + c2], ST(S_A2U, CUQ + c2, a2n[CUQ + c2]);
+#pragma unroll
                     for (int a = 0; a < NU; ++a) {
-                        const bool in = a >= CUA && a < CUA + CUQ;
-                        su[a] += in ? zc[a] - a2n[in ? a - CUA : 0] : u[a];
+                        const bool in1 = a >= CUA && a < CUA + CUQ, in2 = CUQ2 > 0 && a >= CUA2 && a < CUA2 + CUQ2;
+                        su[a] += in1 ? zc[a] - a2n[in1 ? a - CUA : 0] : (in2 ? zc[a] - a2n[in2 ? CUQ + a - CUA2 : 0] : u[a]);
+                    }
+                }
+                if constexpr (LU) {
+                    float w3[NU];
+#pragma unroll
+                    for (int a = 0; a < NU; ++a) w3[a] = u[a] + LD(S_A3U, a), zl[a] = w3[a];
+#pragma unroll
+                    for (int k = 0; k < MLU; ++k) {
+                        float dot = 0.f;
+#pragma unroll
+                        for (int a = 0; a < NU; ++a) dot = fmaf(lau[k][a], zl[a], dot);
+                        const float t = (dot > lbu[k] && lnu[k] > 0.f) ? (dot - lbu[k]) / lnu[k] : 0.f;
+#pragma unroll
+                        for (int a = 0; a < NU; ++a) zl[a] -= t * lau[k][a];
+                    }
+#pragma unroll
+                    for (int a = 0; a < NU; ++a) {
+                        const float an = w3[a] - zl[a];
+                        ST(S_A3U, a, an);
+                        su[a] += zl[a] - an;
                     }
                 }
                 // what the backward sweep needs of a row is the linear-cost term (admm.cpp:77-80), not the sum itself:
@@ -738,8 +893,15 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
                     if constexpr (CXQ > 0) {
 #pragma unroll
                         for (int r = 0; r < NX; ++r) {
-                            if (r >= CXA && r < CXA + CXQ) gp = fmaxf(gp, fabsf(x[r] - vc[r]));
+                            if ((r >= CXA && r < CXA + CXQ) || (CXQ2 > 0 && r >= CXA2 && r < CXA2 + CXQ2)) gp = fmaxf(gp, fabsf(x[r] - vc[r]));
                             gd = fmaxf(gd, fabsf(LD(S_VCX, r) - vc[r]));
+                        }
+                    }
+                    if constexpr (LX) {
+#pragma unroll
+                        for (int r = 0; r < NX; ++r) {
+                            gp = fmaxf(gp, fabsf(x[r] - vl[r]));
+                            gd = fmaxf(gd, fabsf(LD(S_VLX, r) - vl[r]));
                         }
                     }
 #pragma unroll
@@ -750,8 +912,15 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
                     if constexpr (CUQ > 0) {
 #pragma unroll
                         for (int a = 0; a < NU; ++a) {
-                            if (a >= CUA && a < CUA + CUQ) hp = fmaxf(hp, fabsf(u[a] - zc[a]));
+                            if ((a >= CUA && a < CUA + CUQ) || (CUQ2 > 0 && a >= CUA2 && a < CUA2 + CUQ2)) hp = fmaxf(hp, fabsf(u[a] - zc[a]));
                             hd = fmaxf(hd, fabsf(LD(S_VCU, a) - zc[a]));
+                        }
+                    }
+                    if constexpr (LU) {
+#pragma unroll
+                        for (int a = 0; a < NU; ++a) {
+                            hp = fmaxf(hp, fabsf(u[a] - zl[a]));
+                            hd = fmaxf(hd, fabsf(LD(S_VLU, a) - zl[a]));
                         }
                     }
                     if (xv) pri_x = fmaxf(pri_x, gp), dua_x = fmaxf(dua_x, gd);
@@ -766,6 +935,11 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
 #pragma unroll
                             for (int r = 0; r < NX; ++r) pvc[r] = LD(S_VCX, r);
                         }
+                        if constexpr (LX) {
+                            float *pvl = Pk->svl + oxi + m * 4 * NX;
+#pragma unroll
+                            for (int r = 0; r < NX; ++r) pvl[r] = LD(S_VLX, r);
+                        }
                     }
                     if (park && active && uv && hp < ptol && hd * rho < dtol) {
                         kparam_ptr Pk = kparams();
@@ -776,6 +950,11 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
                             float *pzc = Pk->szc + oui + m * 4 * NU;
 #pragma unroll
                             for (int a = 0; a < NU; ++a) pzc[a] = LD(S_VCU, a);
+                        }
+                        if constexpr (LU) {
+                            float *pzl = Pk->szl + oui + m * 4 * NU;
+#pragma unroll
+                            for (int a = 0; a < NU; ++a) pzl[a] = LD(S_VLU, a);
                         }
                         // the feed-forward term this iteration's rollout used: d = -Kinf x - u (admm.cpp:29)
 #pragma unroll
@@ -793,11 +972,13 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
                     for (int r = 0; r < NX; ++r) {
                         ST(S_VBX, r, vn[r]);
                         if constexpr (CXQ > 0) ST(S_VCX, r, vc[r]);
+                        if constexpr (LX) ST(S_VLX, r, vl[r]);
                     }
 #pragma unroll
                     for (int a = 0; a < NU; ++a) {
                         ST(S_VBU, a, zn[a]);
                         if constexpr (CUQ > 0) ST(S_VCU, a, zc[a]);
+                        if constexpr (LU) ST(S_VLU, a, zl[a]);
                     }
                 }
             });
@@ -963,6 +1144,11 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
 #pragma unroll
                             for (int r = 0; r < NX; ++r) ST(S_VCX, r, pvc[r]);
                         }
+                        if constexpr (LX) {
+                            const float *pvl = Pe->svl + ox + m * 4 * NX;
+#pragma unroll
+                            for (int r = 0; r < NX; ++r) ST(S_VLX, r, pvl[r]);
+                        }
                     }
                     if (kk < N - 1) {
                         const float *pz = Pe->sz + ou + m * 4 * NU, *pd = Pe->sd + ou + m * 4 * NU;
@@ -972,6 +1158,11 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
                             const float *pzc = Pe->szc + ou + m * 4 * NU;
 #pragma unroll
                             for (int a = 0; a < NU; ++a) ST(S_VCU, a, pzc[a]);
+                        }
+                        if constexpr (LU) {
+                            const float *pzl = Pe->szl + ou + m * 4 * NU;
+#pragma unroll
+                            for (int a = 0; a < NU; ++a) ST(S_VLU, a, pzl[a]);
                         }
                         double dv[NU];
 #pragma unroll
@@ -1012,6 +1203,11 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
         for (int a = 0; a < NVU; ++a) Vcu[a] = LD(S_VCU, a);
 #pragma unroll
         for (int a = 0; a < NCU; ++a) A2u[a] = LD(S_A2U, a);
+        float A3x[NLX], Vlx[NLX], A3u[NLU], Vlu[NLU];
+#pragma unroll
+        for (int r = 0; r < NLX; ++r) A3x[r] = LX ? LD(S_A3X, r) : 0.f, Vlx[r] = LX ? LD(S_VLX, r) : 0.f;
+#pragma unroll
+        for (int a = 0; a < NLU; ++a) A3u[a] = LU ? LD(S_A3U, a) : 0.f, Vlu[a] = LU ? LD(S_VLU, a) : 0.f;
         constexpr int m = decltype(mt)::value;
         const int kk = 4 * m + g;
         lds_f *c = cq + m * 4 * PLEN;
@@ -1027,6 +1223,13 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
                     float *pgc = Pe->sgc + ox + m * 4 * NX;
 #pragma unroll
                     for (int c2 = 0; c2 < CXQ; ++c2) pgc[CXA + c2] = A2x[c2];
+#pragma unroll
+                    for (int c2 = 0; c2 < CXQ2; ++c2) pgc[CXA2 + c2] = A2x[CXQ + c2];
+                }
+                if constexpr (LX) {
+                    float *pgl = Pe->sgl + ox + m * 4 * NX;
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) pgl[r] = A3x[r];
                 }
                 if (!conv) {                                   // (a converged instance parked the slack of the iteration before)
                     float *pv = Pe->sv + ox + m * 4 * NX;
@@ -1036,6 +1239,11 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
                         float *pvc = Pe->svc + ox + m * 4 * NX;
 #pragma unroll
                         for (int r = 0; r < NX; ++r) pvc[r] = Vcx[r];
+                    }
+                    if constexpr (LX) {
+                        float *pvl = Pe->svl + ox + m * 4 * NX;
+#pragma unroll
+                        for (int r = 0; r < NX; ++r) pvl[r] = Vlx[r];
                     }
                 }
             }
@@ -1052,6 +1260,13 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
                     float *pyc = Pe->syc + ou + m * 4 * NU;
 #pragma unroll
                     for (int c2 = 0; c2 < CUQ; ++c2) pyc[CUA + c2] = A2u[c2];
+#pragma unroll
+                    for (int c2 = 0; c2 < CUQ2; ++c2) pyc[CUA2 + c2] = A2u[CUQ + c2];
+                }
+                if constexpr (LU) {
+                    float *pyl = Pe->syl + ou + m * 4 * NU;
+#pragma unroll
+                    for (int a = 0; a < NU; ++a) pyl[a] = A3u[a];
                 }
                 if (!conv) {
                     float *pz = Pe->sz + ou + m * 4 * NU, *pd = Pe->sd + ou + m * 4 * NU;
@@ -1061,6 +1276,11 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ>())) 
                         float *pzc = Pe->szc + ou + m * 4 * NU;
 #pragma unroll
                         for (int a = 0; a < NU; ++a) pzc[a] = Vcu[a];
+                    }
+                    if constexpr (LU) {
+                        float *pzl = Pe->szl + ou + m * 4 * NU;
+#pragma unroll
+                        for (int a = 0; a < NU; ++a) pzl[a] = Vlu[a];
                     }
                     double tv[NU];                             // d = Quu_inv t of the last backward sweep (admm.cpp:17)
 #pragma unroll

@@ -191,6 +191,7 @@ int tinympc_enable_linear(tinympc_solver *s, int en_state_linear, int en_input_l
     if (!s) return -1;
     s->s.st.en_state_linear = en_state_linear ? 1 : 0;
     s->s.st.en_input_linear = en_input_linear ? 1 : 0;
+    s->s.lin_dirty = true;   // the device pack holds the enabled sides only
     s->s.route_gen += 1;
     return 0;
 }

@@ -37,8 +37,9 @@ namespace tmpc {
 namespace {
 
 std::mutex g_mu;
-std::map<std::string, const KernelEntry *> g_units;   // unit name -> entry (nullptr: tried and failed, do not try again)
+std::map<std::string, const void *> g_units;   // unit name -> entry (nullptr: tried and failed, do not try again)
 std::vector<const KernelEntry *> g_quad, g_mfma;
+std::vector<const ConeEntry *> g_trans;
 
 bool file_exists(const std::string &p) {
     struct stat st;
@@ -58,8 +59,9 @@ std::string lib_dir() {   // .../tinympc-julia_amd/lib (where this library was l
 // FNV-1a over the kernel headers: the cache key of everything a unit is compiled from
 std::string source_hash(const std::string &csrc) {
     static const char *files[] = {"admm_params.h", "solver.h", "host_setup.h", "admm_quad.hip.h", "quad_entry.hip.h", "admm_mfma.hip.h",
-                                  "mfma_entry.hip.h"};
+                                  "mfma_entry.hip.h", "admm_mfmac.hip.h", "mfmac_entry.hip.h", "admm_mfmat.hip.h", "mfmat_entry.hip.h"};
     unsigned long long h = 1469598103934665603ull;
+    for (const char *c = "flags: -O3 -DTMPC_JIT_UNIT -DTMPC_MFMAT_HANDOVER=2 -amdgpu-mfma-vgpr-form"; *c; ++c) h = (h ^ (unsigned char)*c) * 1099511628211ull;
     for (const char *f : files) {
         std::ifstream in(csrc + "/" + f, std::ios::binary);
         if (!in) return "";
@@ -88,7 +90,7 @@ int run(const std::vector<std::string> &argv, const std::string &log) {
     return WIFEXITED(status) ? WEXITSTATUS(status) : -1;
 }
 
-const KernelEntry *build_unit(const std::string &unit, const std::string &source, int verbose) {
+const void *build_unit(const std::string &unit, const std::string &source, int verbose) {
     const std::string lib = lib_dir();
     if (lib.empty()) return nullptr;
     const std::string csrc = lib + "/../csrc";
@@ -111,8 +113,11 @@ const KernelEntry *build_unit(const std::string &unit, const std::string &source
             out << source;
         }
         const auto t0 = std::chrono::steady_clock::now();
+        // (-DTMPC_MFMAT_HANDOVER=2: the transposed-sets kernel's hand-over stores as one asm statement each — the default form's
+        // store order is held by an assembly test that only sees the built-in instantiations, tests/test_mfmat_asm.py)
         const int rc = run({hipcc, "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-fno-honor-nans", "-DTMPC_JIT_UNIT",
-                            "-mllvm", "-amdgpu-mfma-vgpr-form", "-I" + csrc, src, "-o", tmp, "-L" + lib, "-ltinympc_hip", "-Wl,-rpath," + lib},
+                            "-DTMPC_MFMAT_HANDOVER=2", "-mllvm", "-amdgpu-mfma-vgpr-form", "-I" + csrc, src, "-o", tmp, "-L" + lib, "-ltinympc_hip",
+                            "-Wl,-rpath," + lib},
                            cache + "/" + unit + ".log");
         const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (rc != 0 || ::rename(tmp.c_str(), so.c_str()) != 0) {
@@ -132,7 +137,7 @@ const KernelEntry *build_unit(const std::string &unit, const std::string &source
     }
     using Fn = const void *(*)();
     Fn fn = (Fn)dlsym(h, "tmpc_jit_entry");
-    return fn ? static_cast<const KernelEntry *>(fn()) : nullptr;
+    return fn ? fn() : nullptr;
 }
 
 }  // namespace
@@ -164,10 +169,72 @@ const KernelEntry *jit_kernel_for(int nx, int nu, int N, int verbose) {
     }
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_units.find(name.str());
-    if (it != g_units.end()) return it->second;
-    const KernelEntry *e = build_unit(name.str(), src.str(), verbose);
+    if (it != g_units.end()) return static_cast<const KernelEntry *>(it->second);
+    const KernelEntry *e = static_cast<const KernelEntry *>(build_unit(name.str(), src.str(), verbose));
     g_units[name.str()] = e;
     if (e) (mfma ? g_mfma : g_quad).push_back(e);
+    return e;
+}
+
+const ConeEntry *jit_trans_find(const Solver &sv) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (const ConeEntry *e : g_trans)
+        if (e->nx == sv.nx && e->nu == sv.nu && e->N == sv.N && e->supports(sv)) return e;
+    return nullptr;
+}
+
+// The transposed-sets matrix-core kernel (admm_mfmat.hip.h) for EXACTLY this solver's constraint layout: the affine term, up
+// to two disjoint cones per side (ascending rows), linear-inequality rows, its reference mode and bound kind — ONE kernel,
+// compiled / loaded once per process and layout.  The reference takes cone lists and row blocks at run time
+// (bindings.cpp:414-490); the built-in entries compile one cone per side and no rows.  nullptr: not a layout this kernel
+// takes (the stream / generic kernels do), or nothing could be compiled.
+const ConeEntry *jit_trans_for(const Solver &sv, int verbose) {
+    if (std::getenv("TINYMPC_HIP_NO_JIT")) return nullptr;
+    const int nx = sv.nx, nu = sv.nu, N = sv.N;
+    if (nx < 4 || nx > 8 || nu < 1 || nu > 4 || N < 3 || N > 64) return nullptr;
+    const int ncx = sv.st.en_state_soc ? sv.ncx : 0, ncu = sv.st.en_input_soc ? sv.ncu : 0;
+    const int mlx = sv.st.en_state_linear ? sv.mlx : 0, mlu = sv.st.en_input_linear ? sv.mlu : 0;
+    if (ncx > 2 || ncu > 2 || mlx > LIN_MAX_ROWS || mlu > LIN_MAX_ROWS) return nullptr;
+    if (mlx * (nx + 2) + mlu * (nu + 2) > 48) return nullptr;   // (the rows are scalar registers of the sets phase)
+    int c[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};                   // per side: first row, dimension of cone 1, of cone 2
+    for (int side = 0; side < 2; ++side) {
+        const int n = side ? ncu : ncx, rows = side ? nu : nx;
+        const int *A = side ? sv.Acu : sv.Acx, *q = side ? sv.qcu : sv.qcx;
+        int behind = 0;
+        for (int i = 0; i < n; ++i) {
+            if (q[i] < 2 || A[i] < behind || A[i] + q[i] > rows) return nullptr;   // ascending, disjoint, inside the side
+            c[side][2 * i] = A[i], c[side][2 * i + 1] = q[i];
+            behind = A[i] + q[i];
+        }
+    }
+    // registers of the sets layout (TransShape::state_regs; the last knot group may live in LDS): the 512-entry file must hold them
+    const int NG = (N + 3) / 4, qx = c[0][1] + c[0][3], qu = c[1][1] + c[1][3];
+    const int gr = (nx + qx + nu + qu) + (nx + (qx ? nx : 0) + nu + (qu ? nu : 0)) + (mlx ? 2 * nx : 0) + (mlu ? 2 * nu : 0);
+    int regs = NG * gr;
+    if (NG >= 2 && regs + 70 > 450) regs -= gr;
+    if (regs + 70 > 470) return nullptr;
+    const bool bv = sv.bounds_vary_by_knot();
+    const int refs = sv.refs_device_owned ? sv.ref_mode : (sv.xref_kind > sv.uref_kind ? sv.xref_kind : sv.uref_kind);   // (Solver::upload_refs)
+    const size_t cells = (size_t)16 * (nx + nu) * N * sizeof(float);
+    if ((refs == REF_PER_INSTANCE ? 2 : 1) * cells + (bv ? (size_t)2 * (nx + nu) * N * 4 : 0) > 150 * 1024) return nullptr;
+    std::ostringstream name, label, src;
+    name << "mfmat_" << nx << "_" << nu << "_" << N << "_r" << refs << (bv ? "_bv" : "") << "_cx" << c[0][0] << "_" << c[0][1] << "_" << c[0][2] << "_"
+         << c[0][3] << "_cu" << c[1][0] << "_" << c[1][1] << "_" << c[1][2] << "_" << c[1][3] << "_l" << mlx << "_" << mlu;
+    label << "mfmat<" << nx << "," << nu << "," << N << ">";
+    if (qx) label << " cx" << c[0][0] << ":" << c[0][1];
+    if (c[0][3]) label << "+" << c[0][2] << ":" << c[0][3];
+    if (qu) label << " cu" << c[1][0] << ":" << c[1][1];
+    if (c[1][3]) label << "+" << c[1][2] << ":" << c[1][3];
+    if (mlx || mlu) label << " lin" << mlx << "," << mlu;
+    src << "// specialised at setup by jit.cpp\n#include \"mfmat_entry.hip.h\"\nTMPC_DEFINE_MFMAT_JIT_ENTRY(\"" << label.str() << "\", " << nx << ", "
+        << nu << ", " << N << ", " << refs << ", " << c[0][0] << ", " << c[0][1] << ", " << c[1][0] << ", " << c[1][1] << ", " << (bv ? "true" : "false")
+        << ", " << c[0][2] << ", " << c[0][3] << ", " << c[1][2] << ", " << c[1][3] << ", " << mlx << ", " << mlu << ")\n";
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_units.find(name.str());
+    if (it != g_units.end()) return static_cast<const ConeEntry *>(it->second);
+    const ConeEntry *e = static_cast<const ConeEntry *>(build_unit(name.str(), src.str(), verbose));
+    g_units[name.str()] = e;
+    if (e) g_trans.push_back(e);
     return e;
 }
 

@@ -29,18 +29,7 @@ int mfmac_cone_rows(const Solver &sv) {
 }
 
 // do the enabled bounds depend on the knot?
-inline bool mfmac_bounds_vary(const Solver &sv) {
-    const int nx = sv.nx, nu = sv.nu, N = sv.N;
-    if (sv.st.en_state_bound)
-        for (int k = 1; k < N; ++k)
-            for (int r = 0; r < nx; ++r)
-                if (sv.x_min[r + (size_t)k * nx] != sv.x_min[r] || sv.x_max[r + (size_t)k * nx] != sv.x_max[r]) return true;
-    if (sv.st.en_input_bound)
-        for (int k = 1; k < N - 1; ++k)
-            for (int a = 0; a < nu; ++a)
-                if (sv.u_min[a + (size_t)k * nu] != sv.u_min[a] || sv.u_max[a + (size_t)k * nu] != sv.u_max[a]) return true;
-    return false;
-}
+inline bool mfmac_bounds_vary(const Solver &sv) { return sv.bounds_vary_by_knot(); }
 
 // operand doubles of every lane, [field][64], then Pinf row-major [NX][NX].  For the 16 x 4 A operand of K-slice s lane l
 // supplies tile row l % 16, tile column 4 s + l / 16; tile index t stands for x_t (t < 8) or u_{t-8} (8 <= t < 12).

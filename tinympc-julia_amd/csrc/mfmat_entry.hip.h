@@ -199,4 +199,54 @@ hipError_t launch_mfmat(const AdmmParams &P, bool ext, size_t lds, hipStream_t s
         return &e;                                                                                                               \
     }
 
+// ---- one kernel specialised at setup (jit.cpp): exactly the solver's constraint layout, reference mode and bound kind ----
+// (the built-in entries compile one cone per side; cone LISTS and linear rows — bindings.cpp:414-490 — come this way, and so
+// does the affine term / cone layout of a horizon the library was not built with)
+template <int NX, int NU, int N, int REFS, int CXA, int CXQ, int CUA, int CUQ, bool BV, class GX>
+bool mfmat_exact_supports(const Solver &sv) {
+    const int ncx = sv.st.en_state_soc ? sv.ncx : 0, ncu = sv.st.en_input_soc ? sv.ncu : 0;
+    if (ncx != (CXQ > 0) + (GX::CXQ2 > 0) || ncu != (CUQ > 0) + (GX::CUQ2 > 0)) return false;
+    if (CXQ > 0 && (sv.Acx[0] != CXA || sv.qcx[0] != CXQ)) return false;
+    if (GX::CXQ2 > 0 && (sv.Acx[1] != GX::CXA2 || sv.qcx[1] != GX::CXQ2)) return false;
+    if (CUQ > 0 && (sv.Acu[0] != CUA || sv.qcu[0] != CUQ)) return false;
+    if (GX::CUQ2 > 0 && (sv.Acu[1] != GX::CUA2 || sv.qcu[1] != GX::CUQ2)) return false;
+    if ((sv.st.en_state_linear ? sv.mlx : 0) != GX::MLX || (sv.st.en_input_linear ? sv.mlu : 0) != GX::MLU) return false;
+    // (the mode the next launch uploads the references in, Solver::upload_refs — ref_mode itself is the last launch's)
+    const int refs = sv.refs_device_owned ? sv.ref_mode : (sv.xref_kind > sv.uref_kind ? sv.xref_kind : sv.uref_kind);
+    return refs == REFS && mfmac_bounds_vary(sv) == BV;
+}
+template <int NX, int NU, int N, int REFS, int CXQ, int CUQ, bool BV, class GX>
+size_t mfmat_exact_lds_bytes(const Solver &) {
+    return TransShape<NX, NU, N>::lds_bytes(BV ? N : 1, CXQ + GX::CXQ2, CUQ + GX::CUQ2, REFS == REF_PER_INSTANCE, GX::MLX > 0, GX::MLU > 0);
+}
+template <int NX, int NU, int N, int REFS, int CXA, int CXQ, int CUA, int CUQ, bool BV, class GX>
+hipError_t launch_mfmat_exact(const AdmmParams &P, bool, size_t lds, hipStream_t stream) {
+    auto kfn = admm_mfmat_kernel<NX, NU, N, REFS, CXA, CXQ, CUA, CUQ, BV, GX>;
+    static std::atomic<int> per_cu_dev[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int per_cu = per_cu_dev[dev & 63].load(std::memory_order_relaxed);
+    if (per_cu <= 0) {
+        (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 64, lds) != hipSuccess || per_cu <= 0) per_cu = 1;
+        per_cu_dev[dev & 63].store(per_cu, std::memory_order_relaxed);
+    }
+    const int tiles = (P.batch + 15) / 16, slots = per_cu * device_cu_count();
+    hipLaunchKernelGGL(kfn, dim3(tiles < slots ? tiles : slots), dim3(64), lds, stream, P);
+    return hipGetLastError();
+}
+#define TMPC_DEFINE_MFMAT_JIT_ENTRY(NAME, NX, NU, N, REFS, CXA, CXQ, CUA, CUQ, BV, CXA2, CXQ2, CUA2, CUQ2, MLX, MLU)                  \
+    namespace tmpc {                                                                                                                \
+    using JitExtra = TransExtra<CXA2, CXQ2, CUA2, CUQ2, MLX, MLU>;                                                                   \
+    const ConeEntry *mfmat_jit_entry() {                                                                                            \
+        static const ConeEntry e = {NX, NU, N, &mfmat_exact_supports<NX, NU, N, REFS, CXA, CXQ, CUA, CUQ, BV, JitExtra>, true, NAME, \
+                                    &build_mfmat_coef<NX, NU, N>, &build_mfmac_bounds<NX, NU>,                                       \
+                                    &mfmat_exact_lds_bytes<NX, NU, N, REFS, CXQ, CUQ, BV, JitExtra>,                                 \
+                                    [](const Solver &s) { return mfmat_scratch_floats(s); }, &mfmac_bounds_vary,                    \
+                                    &launch_mfmat_exact<NX, NU, N, REFS, CXA, CXQ, CUA, CUQ, BV, JitExtra>, true};                   \
+        return &e;                                                                                                                  \
+    }                                                                                                                               \
+    }                                                                                                                               \
+    extern "C" const void *tmpc_jit_entry() { return tmpc::mfmat_jit_entry(); }
+
 }  // namespace tmpc

@@ -29,6 +29,11 @@ struct KernelEntry {
 // sources, the state does not fit, TINYMPC_HIP_NO_JIT)
 const KernelEntry *jit_kernel_for(int nx, int nu, int N, int verbose);
 const KernelEntry *jit_find(bool mfma, int nx, int nu, int N, int group);
+// ... and the transposed-sets matrix-core kernel for exactly a solver's constraint layout (two cones per side, linear rows, a
+// horizon the library was not built with): the unit already loaded that takes this solver / compile it now
+struct ConeEntry;
+const ConeEntry *jit_trans_find(const Solver &);
+const ConeEntry *jit_trans_for(const Solver &, int verbose);
 // group < 0: the shape's default group size; otherwise that exact variant (nullptr if not built)
 const KernelEntry *find_quad_kernel(int nx, int nu, int N, int group = -1);
 // the variant best suited to `batch` instances (nullptr: no specialised kernel for the shape)
@@ -87,7 +92,8 @@ struct Switches {
     bool strict_fp32 = false, no_quad = false, no_quad_adp = false, no_quad_adp1 = false, no_mfma = false, no_mfma_adp = false,
          mfma_oneshot_only = false, no_stream = false, no_stream_adp = false, no_mfmar = false, no_mfmac = false, mfmac_all = false,
          mfmac_wide = false, no_mfmat = false, mfmat_all = false, mfmat_ws_only = false, no_lean = false, no_refill = false,
-         no_uni = false, no_os = false, lean_one = false;   // lean_one: TINYMPC_HIP_LEAN_ONE — the lean kernel's 512-register variant at any batch
+         no_uni = false, no_os = false, lean_one = false,   // lean_one: TINYMPC_HIP_LEAN_ONE — the lean kernel's 512-register variant at any batch
+         no_jit = false;                                    // TINYMPC_HIP_NO_JIT: no unit specialised at setup, loaded or not
     int mfmac_debug = 0;    // timing probe builds only
 };
 Switches read_switches();
@@ -147,6 +153,7 @@ struct Solver {
     // Riccati caches and diag/rho scalars; runs on the stream kernel with per-lane coefficient columns
     bool hetero = false;
     bool no_specialise = false;   // init() does not compile an on-chip unit for the shape (jit.cpp)
+    bool layout_final = false;    // a constraint layout is specialised (jit_trans_for) from the first solve on, not while the setters run
     std::vector<double> het_A, het_B;
     std::vector<Cache> het_cache;
     float *d_het_aux = nullptr;
@@ -240,6 +247,7 @@ struct Solver {
     const ConeEntry *route_cone(bool rollout, bool have_quad, bool have_stream) const;
     const ConeEntry *route_trans(bool rollout, const ConeEntry *oneshot) const;
     std::vector<long> routing_key(bool rollout) const;
+    bool bounds_vary_by_knot() const;   // do the enabled box bounds depend on the knot?
     std::vector<long> routed_key;
     bool routed = false;
     unsigned route_gen = 0;                   // bumped by setters whose effect on routing the key's scalars do not show

@@ -341,6 +341,7 @@ Switches read_switches() {
     w.no_mfmac = on("TINYMPC_HIP_NO_MFMAC");
     w.mfmac_all = on("TINYMPC_HIP_MFMAC_ALL");
     w.mfmac_wide = on("TINYMPC_HIP_MFMAC_WIDE");
+    w.no_jit = on("TINYMPC_HIP_NO_JIT");
     w.no_mfmat = on("TINYMPC_HIP_NO_MFMAT");
     w.mfmat_all = on("TINYMPC_HIP_MFMAT_ALL");
     w.mfmat_ws_only = on("TINYMPC_HIP_MFMAT_WS_ONLY");
@@ -437,15 +438,32 @@ const ConeEntry *Solver::route_cone(bool rollout, bool have_quad, bool have_stre
 // loop) of a shape that has it, with the affine term / at most one cone per side (box-only problems where the entry says so)
 const ConeEntry *Solver::route_trans(bool rollout, const ConeEntry *oneshot) const {
     if (sw.no_mfmat || sw.no_mfma || sw.group) return nullptr;
-    const ConeEntry *ct = find_trans_kernel(nx, nu, N);
-    if (ct && ct->supports && !ct->supports(*this)) ct = nullptr;
-    if (!ct) return nullptr;
-    if (strict_fp32() || hetero || lin_active() || st.adaptive_rho || (refs_per_instance() && ref_seq_steps > 0) || st.max_iter < 1 ||
-        !(has_fdyn || cones_active() || ct->plain || sw.mfmat_all) || ct->lds_bytes(*this) > 160 * 1024 - 1024 ||
-        (double)batch * ex() >= 2.0e9)
+    if (strict_fp32() || hetero || st.adaptive_rho || (refs_per_instance() && ref_seq_steps > 0) || st.max_iter < 1 || (double)batch * ex() >= 2.0e9)
         return nullptr;
+    const ConeEntry *ct = find_trans_kernel(nx, nu, N);
+    if (ct && (lin_active() || (ct->supports && !ct->supports(*this)))) ct = nullptr;
+    if (ct && !(has_fdyn || cones_active() || ct->plain || sw.mfmat_all)) return nullptr;
+    // a layout the built-in entries do not have — two cones on a side, linear rows, a horizon the library was not built with:
+    // the unit specialised for exactly this layout (jit.cpp; compiled on first use, cached on disk)
+    if (!ct && extensions_active() && !sw.no_jit) {
+        ct = jit_trans_find(*this);
+        if (!ct && !no_specialise && layout_final) ct = jit_trans_for(*this, verbose);   // (not for every intermediate layout of a setter sequence)
+    }
+    if (!ct || ct->lds_bytes(*this) > 160 * 1024 - 1024) return nullptr;
     if (sw.mfmat_ws_only && !warm_start && chunk_iters == 0 && !rollout && oneshot) return nullptr;   // (tests hold the families against each other)
     return ct;
+}
+
+bool Solver::bounds_vary_by_knot() const {
+    if (st.en_state_bound)
+        for (int k = 1; k < N; ++k)
+            for (int r = 0; r < nx; ++r)
+                if (x_min[r + (size_t)k * nx] != x_min[r] || x_max[r + (size_t)k * nx] != x_max[r]) return true;
+    if (st.en_input_bound)
+        for (int k = 1; k < N - 1; ++k)
+            for (int a = 0; a < nu; ++a)
+                if (u_min[a + (size_t)k * nu] != u_min[a] || u_max[a + (size_t)k * nu] != u_max[a]) return true;
+    return false;
 }
 
 // everything the routes read, in one comparable value
@@ -453,7 +471,8 @@ std::vector<long> Solver::routing_key(bool rollout) const {
     return {nx, nu, N, batch, precision, warm_start, chunk_iters, has_fdyn, cones_active(), lin_active(), hetero, st.adaptive_rho,
             cache_overridden, refs_device_owned, xref_kind, uref_kind, ref_mode, adapt_pure, adapt_dirty, ref_seq_steps,
             st.max_iter < 1, st.en_state_soc, st.en_input_soc, ncx, ncu, Acx[0], qcx[0], Acu[0], qcu[0], mlx, mlu, rollout, strict_precision,
-            (long)route_gen};
+            (long)route_gen, Acx[1], qcx[1], Acu[1], qcu[1], st.en_state_linear, st.en_input_linear,
+            extensions_active() && bounds_vary_by_knot(), layout_final};   // (a unit specialised at setup is compiled for one bound kind)
 }
 
 int Solver::select_kernel(bool rollout) {
@@ -965,8 +984,10 @@ int Solver::ensure_extension_buffers() {
                 pk.push_back((float)n2);
             }
         };
-        put(lin_Ax, lin_bx, mlx, nx);
-        put(lin_Au, lin_bu, mlu, nu);
+        // (a side that has rows but is switched off — tinympc_enable_linear — is left out: the kernels find the input block
+        // behind P.mlx state rows)
+        put(lin_Ax, lin_bx, st.en_state_linear ? mlx : 0, nx);
+        put(lin_Au, lin_bu, st.en_input_linear ? mlu : 0, nu);
         if (pk.empty()) pk.push_back(0.f);
         if (dev_alloc(d_lin, pk.size())) return -1;
         HIP_TRY(hipMemcpy(d_lin, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -1009,6 +1030,7 @@ __global__ void residual_max_kernel(const float *res, long batch, uint32_t *gsta
 
 int Solver::solve_async(hipStream_t stream, int mpc_steps) {
     HIP_TRY(hipSetDevice(device));
+    layout_final = true;
     if (select_kernel(mpc_steps > 0) || ensure_extension_buffers()) return -1;
     const bool chunkable = chunk_iters > 0 && mpc_steps == 0 && !hetero && (ke || se || (ce && ce->ws)) && st.check_termination > 0 &&
                            st.abs_pri_tol > 0.0 && st.abs_dua_tol > 0.0 && st.max_iter > chunk_iters;
