@@ -150,18 +150,14 @@ def test_mfmac_equals_stream_kernel(hip_lib, monkeypatch, setting):
     assert nrel_batch(outs[0][1]["controls"], outs[1][1]["controls"])[same].max() <= 3e-6
 
 
-@pytest.mark.parametrize("case", ["cones_across_groups", "state_cone_knot_bounds", "zero_refs_box_only", "two_state_cones_knot_bounds",
-                                  "two_state_cones_with_gap_and_input_cone", "two_input_cones", "linear_state_rows", "linear_input_rows_only",
-                                  "cones_and_linear_both_sides"])
+@pytest.mark.parametrize("case", ["cones_across_groups", "state_cone_knot_bounds", "zero_refs_box_only"])
 def test_mfmac_general_cones_and_bounds(hip_lib, oracle_built, monkeypatch, case):
     """cones whose rows sit in different lane groups and slots (rows 2..5 = slot 0 of groups 2, 3 and slot 1 of groups
-    0, 1), a cone on one side only, a 2-row input cone; bounds that depend on the knot; no references; TWO cones on a side
-    (bindings.cpp:453-490 takes cone lists: they share the side's slack and dual arrays, admm.cpp:57-64); linear-inequality
-    rows (bindings.cpp:414-450) on either / both sides, alone and together with cones (round 2's "X4" combination)"""
-    rng = np.random.default_rng({"cones_across_groups": 3, "state_cone_knot_bounds": 4, "zero_refs_box_only": 5, "two_state_cones_knot_bounds": 6,
-                                 "two_state_cones_with_gap_and_input_cone": 7, "two_input_cones": 8, "linear_state_rows": 9,
-                                 "linear_input_rows_only": 10, "cones_and_linear_both_sides": 11}[case])
-    nx, nu, N, B = 6, (4 if case == "two_input_cones" else 3), 17, 29
+    0, 1), a cone on one side only, a 2-row input cone; bounds that depend on the knot; no references.  (Two cones on a
+    side and linear-inequality rows — bindings.cpp:414-490 — ran here on request in round 3; since round 4 they run on the
+    transposed-sets kernel specialised for the layout: tests/test_mfmat_general_gpu.py holds those six cases.)"""
+    rng = np.random.default_rng({"cones_across_groups": 3, "state_cone_knot_bounds": 4, "zero_refs_box_only": 5}[case])
+    nx, nu, N, B = 6, 3, 17, 29
     A = np.eye(nx) + 0.15 * rng.standard_normal((nx, nx)) / np.sqrt(nx)
     A *= 0.97 / np.abs(np.linalg.eigvals(A)).max()
     prob = t.problems.Problem("rand", A, 0.5 * rng.standard_normal((nx, nu)), np.diag(rng.uniform(0.5, 5.0, nx)),
@@ -170,51 +166,26 @@ def test_mfmac_general_cones_and_bounds(hip_lib, oracle_built, monkeypatch, case
     prob.u_min, prob.u_max = -rng.uniform(0.2, 0.6, (nu, 1)) * np.ones((1, N - 1)), rng.uniform(0.2, 0.6, (nu, 1)) * np.ones((1, N - 1))
     fdyn = 0.02 * rng.standard_normal(nx)
     xr, ur = 0.2 * rng.standard_normal((nx, N)), 0.1 * rng.standard_normal((nu, N - 1))
-    cones, lin = None, None
+    cones = None
     if case == "cones_across_groups":
         cones = ([1], [2], [0.8], [2], [4], [0.9])          # input rows 1..2; state rows 2..5
     elif case == "state_cone_knot_bounds":
         cones = ([], [], [], [3], [3], [1.2])               # a cone on the state side only, rows 3..5
         prob.x_min[:, N // 2:] -= 0.3                        # per-knot bounds: the pack keeps every knot
         prob.u_max[:, ::2] += 0.1
-    elif case == "two_state_cones_knot_bounds":
-        cones = ([], [], [], [0, 3], [3, 3], [1.1, 0.7])    # state rows 0..2 and 3..5 (the second straddles slots 0 and 1)
-        prob.x_min[:, N // 2:] -= 0.3
-        prob.u_max[:, ::2] += 0.1
-    elif case == "two_state_cones_with_gap_and_input_cone":
-        cones = ([0], [3], [0.6], [0, 4], [2, 2], [0.9, 1.3])   # state rows 0..1 and 4..5, rows 2..3 in no cone; input rows 0..2
-    elif case == "two_input_cones":
-        cones = ([0, 2], [2, 2], [0.8, 1.2], [1], [4], [0.9])   # input rows 0..1 and 2..3 (nu = 4); state rows 1..4
-    elif case == "linear_state_rows":
-        lin = (rng.standard_normal((2, nx)), [0.3, 0.5], np.zeros((0, nu)), [])   # two state rows (slots 0 and 1 of every lane group)
-    elif case == "linear_input_rows_only":
-        lin = (np.zeros((0, nx)), [], rng.standard_normal((3, nu)), [0.1, 0.2, 0.15])
-    elif case == "cones_and_linear_both_sides":
-        cones = ([0], [3], [0.6], [3], [3], [1.2])
-        lin = (rng.standard_normal((1, nx)), [0.4], rng.standard_normal((2, nu)), [0.2, 0.1])
-        prob.x_min[:, N // 2:] -= 0.3
     else:
         monkeypatch.setenv("TINYMPC_HIP_MFMAC_ALL", "1")    # box-only one-shot solve of a run-time-horizon shape
         fdyn, xr, ur = None, None, None
-    if case.startswith("two_") or lin is not None:
-        # correct there, not faster than the stream kernel (an extra dual array costs it a tile per CU): opt-in
-        monkeypatch.setenv("TINYMPC_HIP_MFMAC_WIDE", "1")
     kw = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=50, check_termination=1)
     x0 = np.asfortranarray(rng.uniform(-0.5, 0.5, (nx, B)))
-    mk = _oracle(oracle_built, prob, kw, xr, ur, fdyn, cones, lin)
+    mk = _oracle(oracle_built, prob, kw, xr, ur, fdyn, cones)
     ref = _loop(mk, x0)
-    bs = _solver(prob, B, kw, xr, ur, fdyn, cones, lin)
+    bs = _solver(prob, B, kw, xr, ur, fdyn, cones)
     bs.set_x0(x0)
     bs.solve()
-    assert bs.kernel_name == f"mfmac<6,{nu}>"
+    assert bs.kernel_name == "mfmac<6,3>"
     sol, st = bs.get_solution(), bs.get_status()
     parity_every_instance(sol, st, ref, mk, x0, kw, prob.rho, tag=case)
-    if lin is not None:                                     # the rows do bind somewhere (else the case tests nothing)
-        Ax, bx, Au, bu = lin
-        X, U = ref["x"], ref["u"]
-        act = sum(int((np.asarray(Ax) @ X[:, :, b] > np.asarray(bx)[:, None] - 1e-3).any()) for b in range(B)) if len(bx) else 0
-        act += sum(int((np.asarray(Au) @ U[:, :, b] > np.asarray(bu)[:, None] - 1e-3).any()) for b in range(B)) if len(bu) else 0
-        assert act > 0
     bs.close()
 
 
@@ -269,8 +240,8 @@ def test_mfmar_variants(hip_lib, oracle_built, case):
 
 
 def test_mfmac_is_not_used_where_it_does_not_apply(hip_lib, monkeypatch):
-    """warm-started / workspace-keeping solves and per-instance references stay on the stream kernel; so do — unless
-    TINYMPC_HIP_MFMAC_WIDE asks — two cones on a side and linear rows (the LDS kernel takes them but is no faster there)"""
+    """warm-started / workspace-keeping solves and per-instance references stay on the stream kernel; so do two cones on a
+    side and linear rows (with the specialisation at setup off, as in this suite: tests/conftest.py)"""
     prob = t.problems.rocket(20)
     xr, ur = t.problems.rocket_refs(20)
     bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=8)
@@ -292,27 +263,12 @@ def test_mfmac_is_not_used_where_it_does_not_apply(hip_lib, monkeypatch):
     bs.set_linear_constraints(np.array([[0.0, 0.0, 0.0, 0.0, 0.0, -1.0]]), [2.5], np.zeros((0, 3)), [])
     bs.solve()
     assert bs.kernel_name == "stream4<6,3>"
-    monkeypatch.setenv("TINYMPC_HIP_MFMAC_WIDE", "1")
-    bs.reload_switches()                                    # (the environment is read once, at creation)
-    bs.solve()
-    assert bs.kernel_name == "mfmac<6,3>"                   # (round 3: linear rows on the LDS kernel; not on the compiled-horizon ones)
-    bs.set_warm_start(True)
-    bs.solve()
-    assert bs.kernel_name == "stream4<6,3>"
-    monkeypatch.delenv("TINYMPC_HIP_MFMAC_WIDE")
     bs.close()
     bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=8)   # two cones on a side
     bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
     bs.set_cone_constraints([0], [3], [0.25], [0, 3], [3, 3], [0.5, 1.5])
     bs.set_warm_start(False)
     bs.set_x0(t.problems.rocket_x0(8, seed=1))
-    bs.solve()
-    assert bs.kernel_name == "stream4<6,3>"
-    monkeypatch.setenv("TINYMPC_HIP_MFMAC_WIDE", "1")
-    bs.reload_switches()
-    bs.solve()
-    assert bs.kernel_name == "mfmac<6,3>"                   # (round 3: the LDS kernel takes two cones per side)
-    bs.set_cone_constraints([0], [3], [0.25], [0, 2, 4], [2, 2, 2], [0.5, 1.5, 1.0])   # three
     bs.solve()
     assert bs.kernel_name == "stream4<6,3>"
     bs.close()

@@ -248,3 +248,34 @@ def test_layouts_the_kernel_does_not_take(hip_lib, monkeypatch):
     bs.solve()
     assert bs.kernel_name.startswith("stream"), bs.kernel_name
     bs.close()
+
+
+@pytest.mark.parametrize("kernel", ["specialised", "stream", "generic"])
+def test_a_side_switched_off_keeps_the_other_sides_rows(hip_lib, oracle_built, monkeypatch, kernel):
+    """rows on both sides, then the state side switched off (tinympc_enable_linear; update_settings' en_state_linear = false,
+    TinyMPC.jl:98-99): the input side's rows are the ones that act — the device pack holds the enabled sides only (until round
+    4 the kernels looked for the input block behind rows that were not counted)"""
+    if kernel != "specialised":
+        monkeypatch.setenv("TINYMPC_HIP_NO_JIT", "1")
+    if kernel == "generic":
+        monkeypatch.setenv("TINYMPC_HIP_NO_STREAM", "1")
+        monkeypatch.setenv("TINYMPC_HIP_NO_MFMAC", "1")
+    nx, nu, N, B = 6, 3, 17, 29
+    prob, rng = _family(10, nx, nu, N)
+    fdyn = 0.02 * rng.standard_normal(nx)
+    xr, ur = 0.2 * rng.standard_normal((nx, N)), 0.1 * rng.standard_normal((nu, N - 1))
+    Ax, bx = rng.standard_normal((2, nx)), [0.3, 0.5]
+    Au, bu = rng.standard_normal((3, nu)), [0.1, 0.2, 0.15]
+    kw = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=50, check_termination=1)
+    x0 = np.asfortranarray(rng.uniform(-0.5, 0.5, (nx, B)))
+    only_u = (np.zeros((0, nx)), [], Au, bu)
+    mk = _oracle(oracle_built, prob, kw, xr, ur, fdyn, None, only_u)
+    ref = _loop(mk, x0)
+    bs = _solver(prob, B, kw, xr, ur, fdyn, None, (Ax, bx, Au, bu))
+    bs.enable_linear(0, 1)
+    bs.set_x0(x0)
+    bs.solve()
+    assert bs.kernel_name.startswith({"specialised": "mfmat<6,3,17>", "stream": "stream", "generic": "generic"}[kernel]), bs.kernel_name
+    parity_every_instance(bs.get_solution(), bs.get_status(), ref, mk, x0, kw, prob.rho, tag=kernel)
+    assert _rows_bind(only_u, ref, B) > 0
+    bs.close()

@@ -40,6 +40,13 @@
 // d_k = -Kinf x_k - u_k (the rollout's own relation, from the fp32 x_k, u_k of the cells) in its d array; lanes that are
 // not locally converged park nothing, so the early iterations cost no traffic.  An instance that leaves at max_iter
 // writes its final slack and d = Quu_inv t at exit instead.
+//
+// Constraint layouts (round 4): the reference takes cone LISTS and linear-inequality row blocks (bindings.cpp:414-490).  In the
+// sets layout a second cone of a side is one more in-lane norm over other rows of the same cone slack (its duals behind the
+// first cone's), and the rows are a third slack / dual pair of full size per side: the knot's x + dual projected onto one
+// half-space after the other (in-lane dot products, coefficients through the scalar cache), exactly the oracle's order.
+// Both are compile-time parameters (TransExtra); the built-in entries compile neither, jit.cpp compiles the one kernel of
+// a solver's exact layout at its first solve.
 #pragma once
 #include "admm_mfmac.hip.h"
 
@@ -81,12 +88,18 @@ struct TransShape {
         return (NX + cxq + NU + cuq) + (NX + (cxq ? NX : 0) + NU + (cuq ? NU : 0)) + (lx ? 2 * NX : 0) + (lu ? 2 * NU : 0);
     }
     static constexpr int state_regs(int cxq, int cuq, bool lx = false, bool lu = false) { return NG * group_regs(cxq, cuq, lx, lu); }
-    // the last group's state in LDS instead: when everything together would not fit the 512-entry file
-    static constexpr bool spill_last(int cxq, int cuq, bool lx = false, bool lu = false) {
-        return NG >= 2 && state_regs(cxq, cuq, lx, lu) + 70 > 450;
+    // the last group(s)' state in LDS instead: when everything together would not fit the 512-entry file — one group where
+    // that brings the rest to 470 (config 4: 13 groups of 33, 396 stay), else as many as it takes, three at most (a second
+    // state cone or linear rows at N = 50: a tile's LDS grows by 10 KB per group and a CU holds three tiles instead of four)
+    static constexpr int spill_groups(int cxq, int cuq, bool lx = false, bool lu = false) {
+        if (NG < 2 || state_regs(cxq, cuq, lx, lu) + 70 <= 450) return 0;
+        int k = 1;
+        while (k < 3 && k < NG - 1 && (NG - k) * group_regs(cxq, cuq, lx, lu) + 70 > 470) ++k;
+        return k;
     }
+    static constexpr bool spill_last(int cxq, int cuq, bool lx = false, bool lu = false) { return spill_groups(cxq, cuq, lx, lu) > 0; }
     static constexpr size_t lds_bytes(int nk, int cxq, int cuq, bool pi = false, bool lx = false, bool lu = false) {
-        return sizeof(float) * (lds_floats(nk, pi) + (spill_last(cxq, cuq, lx, lu) ? (size_t)64 * (group_regs(cxq, cuq, lx, lu) + 6) : 0)) +   // (+ 6: an absent set still has a one-entry array)
+        return sizeof(float) * (lds_floats(nk, pi) + (size_t)64 * spill_groups(cxq, cuq, lx, lu) * (group_regs(cxq, cuq, lx, lu) + 6)) +   // (+ 6: an absent set still has a one-entry array)
                sizeof(double) * ((pi ? 16 * NX : 8) + 16 * NX + 4 * NKC);
     }
 };
@@ -142,7 +155,8 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ, GX>(
     float *s_ref = s_bnd + ((S::bounds_len(nk) + 1) & ~1);
     double *s_pterm = reinterpret_cast<double *>(s_ref + (PI ? (size_t)PLEN * N : (((size_t)NROW * N + 2) & ~(size_t)1)));   // [NX] (PI: [NX][16])
     double *s_plant = s_pterm + (PI ? 16 * NX : 8);           // closed loop: the plant state of the tile's instances, [16][NX]
-    constexpr bool SPILL = T::spill_last(QX, QU, LX, LU);
+    constexpr int KSP = T::spill_groups(QX, QU, LX, LU), GSP = T::group_regs(QX, QU, LX, LU) + 6;   // groups in LDS, floats of one per lane
+    constexpr bool SPILL = KSP > 0;
     // every lane's slot addresses stay inside the cells and the reference pack, and a lane without a row only ever reads
     // finite values that meet a zero operand column: the matrix-layout phases then run without lane masks
     constexpr bool FREE = XS == 2 && NROW >= 8 && NU >= 2;
@@ -274,7 +288,7 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ, GX>(
     //               where a later one reads it — and the duals of the groups behind MD; one v_accvgpr move per access;
     //   LDS         (SPILL) the last group, where N is not a multiple of 4 and some of its lanes have no knot anyway.
     // Shapes whose state fits the arch VGPRs of their occupancy keep everything there (AREG = false).
-    constexpr int NGR = SPILL ? NG - 1 : NG;
+    constexpr int NGR = NG - KSP;
     constexpr bool AREG = T::state_regs(QX, QU, LX, LU) + 80 > 256;
     constexpr int RLX = LX ? NX : 0, RLU = LU ? NU : 0;
     constexpr int DG = NX + NCX + NU + NCU + RLX + RLU;         // duals per group
@@ -299,7 +313,7 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ, GX>(
         constexpr int ID = decltype(id)::value, m = decltype(mt)::value;
         constexpr int LOFF[12] = {0, NX, NX + NCX, NX + NCX + NU, DG, DG + NX, DG + NX + NVX, DG + NX + NVX + NU,
                                   NX + NCX + NU + NCU, NX + NCX + NU + NCU + RLX, SG_, SG_ + RLX};
-        if constexpr (SPILL && m == NG - 1) return sl[64 * (LOFF[ID] + r)];
+        if constexpr (SPILL && m >= NGR) return sl[64 * ((m - NGR) * GSP + LOFF[ID] + r)];
         else if constexpr (ID == S_A3X) { if constexpr (m < MD) return a3x[m][r]; else return aget(b3x[m][r]); }
         else if constexpr (ID == S_A3U) { if constexpr (m < MD) return a3u[m][r]; else return aget(b3u[m][r]); }
         else if constexpr (ID == S_VLX) { if constexpr (AREG) return aget(vlx[m][r]); else return vlx[m][r]; }
@@ -317,7 +331,7 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ, GX>(
         constexpr int ID = decltype(id)::value, m = decltype(mt)::value;
         constexpr int LOFF[12] = {0, NX, NX + NCX, NX + NCX + NU, DG, DG + NX, DG + NX + NVX, DG + NX + NVX + NU,
                                   NX + NCX + NU + NCU, NX + NCX + NU + NCU + RLX, SG_, SG_ + RLX};
-        if constexpr (SPILL && m == NG - 1) sl[64 * (LOFF[ID] + r)] = v;
+        if constexpr (SPILL && m >= NGR) sl[64 * ((m - NGR) * GSP + LOFF[ID] + r)] = v;
         else if constexpr (ID == S_A3X) { if constexpr (m < MD) a3x[m][r] = v; else aset(b3x[m][r], v); }
         else if constexpr (ID == S_A3U) { if constexpr (m < MD) a3u[m][r] = v; else aset(b3u[m][r], v); }
         else if constexpr (ID == S_VLX) { if constexpr (AREG) aset(vlx[m][r], v); else vlx[m][r] = v; }

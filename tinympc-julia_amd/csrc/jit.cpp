@@ -210,13 +210,15 @@ const ConeEntry *jit_trans_for(const Solver &sv, int verbose) {
     // registers of the sets layout (TransShape::state_regs; the last knot group may live in LDS): the 512-entry file must hold them
     const int NG = (N + 3) / 4, qx = c[0][1] + c[0][3], qu = c[1][1] + c[1][3];
     const int gr = (nx + qx + nu + qu) + (nx + (qx ? nx : 0) + nu + (qu ? nu : 0)) + (mlx ? 2 * nx : 0) + (mlu ? 2 * nu : 0);
-    int regs = NG * gr;
-    if (NG >= 2 && regs + 70 > 450) regs -= gr;
+    int regs = NG * gr, in_lds = 0;                                // (TransShape::spill_groups: up to three groups live in LDS)
+    if (NG >= 2 && regs + 70 > 450)
+        for (in_lds = 1; in_lds < 3 && in_lds < NG - 1 && (NG - in_lds) * gr + 70 > 470;) ++in_lds;
+    regs -= in_lds * gr;
     if (regs + 70 > 470) return nullptr;
     const bool bv = sv.bounds_vary_by_knot();
     const int refs = sv.refs_device_owned ? sv.ref_mode : (sv.xref_kind > sv.uref_kind ? sv.xref_kind : sv.uref_kind);   // (Solver::upload_refs)
     const size_t cells = (size_t)16 * (nx + nu) * N * sizeof(float);
-    if ((refs == REF_PER_INSTANCE ? 2 : 1) * cells + (bv ? (size_t)2 * (nx + nu) * N * 4 : 0) > 150 * 1024) return nullptr;
+    if ((refs == REF_PER_INSTANCE ? 2 : 1) * cells + (bv ? (size_t)2 * (nx + nu) * N * 4 : 0) + (size_t)256 * in_lds * (gr + 6) > 150 * 1024) return nullptr;
     std::ostringstream name, label, src;
     name << "mfmat_" << nx << "_" << nu << "_" << N << "_r" << refs << (bv ? "_bv" : "") << "_cx" << c[0][0] << "_" << c[0][1] << "_" << c[0][2] << "_"
          << c[0][3] << "_cu" << c[1][0] << "_" << c[1][1] << "_" << c[1][2] << "_" << c[1][3] << "_l" << mlx << "_" << mlu;

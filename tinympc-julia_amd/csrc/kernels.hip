@@ -110,7 +110,6 @@ const KernelEntry *select_quad_kernel(int nx, int nu, int N, int batch) {
 }
 
 const ConeEntry *mfmac_entry_6_3();
-const ConeEntry *mfmac_entry_6_4();
 const ConeEntry *mfmar_entry_6_3_50();
 const ConeEntry *mfmar_entry_6_3_10();
 const ConeEntry *mfmar_entry_6_3_20();
@@ -120,8 +119,7 @@ const ConeEntry *mfmar_entry_6_3_30();
 // register-resident one where the horizon is compiled in (admm_mfmar.hip.h), else the LDS-resident one with a run-time
 // horizon (admm_mfmac.hip.h)
 const ConeEntry *find_cone_kernel(int nx, int nu, int N) {
-    static const ConeEntry *const table[] = {mfmar_entry_6_3_50(), mfmar_entry_6_3_30(), mfmar_entry_6_3_20(), mfmar_entry_6_3_10(), mfmac_entry_6_3(),
-                                             mfmac_entry_6_4()};
+    static const ConeEntry *const table[] = {mfmar_entry_6_3_50(), mfmar_entry_6_3_30(), mfmar_entry_6_3_20(), mfmar_entry_6_3_10(), mfmac_entry_6_3()};
     for (const ConeEntry *e : table)
         if (e->nx == nx && e->nu == nu && e->N == N) return e;
     return nullptr;

@@ -149,26 +149,24 @@ hipError_t launch_mfmac(const AdmmParams &P_, bool ext, size_t lds, hipStream_t 
         const int grid = tiles < per_cu * cus ? tiles : per_cu * cus;                                                 \
         hipLaunchKernelGGL((admm_mfmac_kernel<NX, NU, REFS_, CX_, CU_, BV_, LIN_>), dim3(grid), dim3(192), lds, stream, P);  \
     } while (0)
+    // (the kernel template also has two cones on a side — CX / CU = 2 — and linear rows — LIN — from round 3: correct, but no
+    // faster than the stream kernel, and since round 4 those layouts run on the transposed-sets kernel specialised for them
+    // (jit.cpp); they are not instantiated any more)
 #define TMPC_MFMAC_LAUNCH_BV(REFS_, CX_, CU_)                                                                         \
     do {                                                                                                              \
-        if (P.mlx + P.mlu > 0) {                                                                                      \
-            if (P.bounds_stride) TMPC_MFMAC_LAUNCH(REFS_, CX_, CU_, true, true); else TMPC_MFMAC_LAUNCH(REFS_, CX_, CU_, false, true); \
-        } else {                                                                                                      \
-            if (P.bounds_stride) TMPC_MFMAC_LAUNCH(REFS_, CX_, CU_, true, false); else TMPC_MFMAC_LAUNCH(REFS_, CX_, CU_, false, false); \
-        }                                                                                                             \
+        if (P.bounds_stride) TMPC_MFMAC_LAUNCH(REFS_, CX_, CU_, true, false); else TMPC_MFMAC_LAUNCH(REFS_, CX_, CU_, false, false); \
     } while (0)
 #define TMPC_MFMAC_LAUNCH_CU(REFS_, CX_)                                                    \
     do {                                                                                   \
-        if (P.ncu > 1) TMPC_MFMAC_LAUNCH_BV(REFS_, CX_, 2);                                \
-        else if (P.ncu > 0) TMPC_MFMAC_LAUNCH_BV(REFS_, CX_, 1);                           \
+        if (P.ncu > 0) TMPC_MFMAC_LAUNCH_BV(REFS_, CX_, 1);                                \
         else TMPC_MFMAC_LAUNCH_BV(REFS_, CX_, 0);                                          \
     } while (0)
 #define TMPC_MFMAC_LAUNCH_C(REFS_)                                                         \
     do {                                                                                   \
-        if (P.ncx > 1) TMPC_MFMAC_LAUNCH_CU(REFS_, 2);                                     \
-        else if (P.ncx > 0) TMPC_MFMAC_LAUNCH_CU(REFS_, 1);                                \
+        if (P.ncx > 0) TMPC_MFMAC_LAUNCH_CU(REFS_, 1);                                     \
         else TMPC_MFMAC_LAUNCH_CU(REFS_, 0);                                               \
     } while (0)
+    if (P.ncx > 1 || P.ncu > 1 || P.mlx + P.mlu > 0) return hipErrorInvalidValue;   // (the routes do not send these here)
     (void)ext;
     if (P.ref_mode == REF_ZERO) TMPC_MFMAC_LAUNCH_C(REF_ZERO); else TMPC_MFMAC_LAUNCH_C(REF_SHARED);
 #undef TMPC_MFMAC_LAUNCH_C

@@ -91,7 +91,7 @@ struct Switches {
     int group = 0;          // TINYMPC_HIP_GROUP = 1 | 2 | 4: that lanes-per-instance variant, no matrix-core kernels
     bool strict_fp32 = false, no_quad = false, no_quad_adp = false, no_quad_adp1 = false, no_mfma = false, no_mfma_adp = false,
          mfma_oneshot_only = false, no_stream = false, no_stream_adp = false, no_mfmar = false, no_mfmac = false, mfmac_all = false,
-         mfmac_wide = false, no_mfmat = false, mfmat_all = false, mfmat_ws_only = false, no_lean = false, no_refill = false,
+         no_mfmat = false, mfmat_all = false, mfmat_ws_only = false, no_lean = false, no_refill = false,
          no_uni = false, no_os = false, lean_one = false,   // lean_one: TINYMPC_HIP_LEAN_ONE — the lean kernel's 512-register variant at any batch
          no_jit = false;                                    // TINYMPC_HIP_NO_JIT: no unit specialised at setup, loaded or not
     int mfmac_debug = 0;    // timing probe builds only

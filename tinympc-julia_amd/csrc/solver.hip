@@ -340,7 +340,6 @@ Switches read_switches() {
     w.no_mfmar = on("TINYMPC_HIP_NO_MFMAR");
     w.no_mfmac = on("TINYMPC_HIP_NO_MFMAC");
     w.mfmac_all = on("TINYMPC_HIP_MFMAC_ALL");
-    w.mfmac_wide = on("TINYMPC_HIP_MFMAC_WIDE");
     w.no_jit = on("TINYMPC_HIP_NO_JIT");
     w.no_mfmat = on("TINYMPC_HIP_NO_MFMAT");
     w.mfmat_all = on("TINYMPC_HIP_MFMAT_ALL");
@@ -427,10 +426,8 @@ const ConeEntry *Solver::route_cone(bool rollout, bool have_quad, bool have_stre
         return nullptr;
     const ConeEntry *c2 = cn ? cn : find_cone_kernel(nx, nu, 0);
     if (c2 && c2->lds_bytes(*this) > 160 * 1024 - 1024) c2 = nullptr;   // horizon too long for one tile's LDS
-    // (two cones per side / linear rows: correct on mfmac but no faster than the stream kernel — the extra duals cost it a
-    // tile per CU, scripts/lin_rows_time.py — so only on request)
-    const bool wide = (st.en_state_soc && ncx > 1) || (st.en_input_soc && ncu > 1) || lin_active();
-    if ((st.en_state_soc && ncx > 2) || (st.en_input_soc && ncu > 2) || (wide && !sw.mfmac_wide)) c2 = nullptr;
+    // (two cones per side / linear rows: the transposed-sets kernel specialised for the layout, route_trans, or the stream kernel)
+    if ((st.en_state_soc && ncx > 1) || (st.en_input_soc && ncu > 1) || lin_active()) c2 = nullptr;
     return c2;
 }
 

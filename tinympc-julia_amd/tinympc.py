@@ -647,6 +647,10 @@ class BatchSolver:
         self._chk(self.lib.tinympc_set_linear_constraints(self.h, _dp(Ax), Ax.shape[0], _dp(bx), _dp(Au), Au.shape[0],
                                                           _dp(bu)), "set_linear_constraints")
 
+    def enable_linear(self, en_state_linear, en_input_linear):
+        """the two linear-row switches of update_settings (TinyMPC.jl:98-99) on their own: a side keeps its rows while it is off"""
+        self._chk(self.lib.tinympc_enable_linear(self.h, int(bool(en_state_linear)), int(bool(en_input_linear))), "enable_linear")
+
     def set_equality_constraints(self, Aeq_x, beq_x, Aeq_u=None, beq_u=None):
         """equalities as two inequalities each (TinyMPC.jl:261-270)"""
         Ax, bx = _lin_block(Aeq_x, beq_x, self.nx)
