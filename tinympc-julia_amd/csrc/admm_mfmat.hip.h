@@ -98,8 +98,14 @@ struct TransShape {
         return k;
     }
     static constexpr bool spill_last(int cxq, int cuq, bool lx = false, bool lu = false) { return spill_groups(cxq, cuq, lx, lu) > 0; }
+    // floats of one such group per lane: its registers, + one entry for each cone array of a side without a cone (the
+    // kernel's arrays have at least one entry).  Exactly group_regs for config 4 — whose tile is 592 bytes short of the 40 KB
+    // that four tiles per CU allow: six floats more per lane and a CU holds three (4.65 ms instead of 3.14)
+    static constexpr int spill_stride(int cxq, int cuq, bool lx = false, bool lu = false) {
+        return group_regs(cxq, cuq, lx, lu) + (cxq ? 0 : 2) + (cuq ? 0 : 2);
+    }
     static constexpr size_t lds_bytes(int nk, int cxq, int cuq, bool pi = false, bool lx = false, bool lu = false) {
-        return sizeof(float) * (lds_floats(nk, pi) + (size_t)64 * spill_groups(cxq, cuq, lx, lu) * (group_regs(cxq, cuq, lx, lu) + 6)) +   // (+ 6: an absent set still has a one-entry array)
+        return sizeof(float) * (lds_floats(nk, pi) + (size_t)64 * spill_groups(cxq, cuq, lx, lu) * spill_stride(cxq, cuq, lx, lu)) +
                sizeof(double) * ((pi ? 16 * NX : 8) + 16 * NX + 4 * NKC);
     }
 };
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ, GX>(
     float *s_ref = s_bnd + ((S::bounds_len(nk) + 1) & ~1);
     double *s_pterm = reinterpret_cast<double *>(s_ref + (PI ? (size_t)PLEN * N : (((size_t)NROW * N + 2) & ~(size_t)1)));   // [NX] (PI: [NX][16])
     double *s_plant = s_pterm + (PI ? 16 * NX : 8);           // closed loop: the plant state of the tile's instances, [16][NX]
-    constexpr int KSP = T::spill_groups(QX, QU, LX, LU), GSP = T::group_regs(QX, QU, LX, LU) + 6;   // groups in LDS, floats of one per lane
+    constexpr int KSP = T::spill_groups(QX, QU, LX, LU), GSP = T::spill_stride(QX, QU, LX, LU);   // groups in LDS, floats of one per lane
     constexpr bool SPILL = KSP > 0;
     // every lane's slot addresses stay inside the cells and the reference pack, and a lane without a row only ever reads
     // finite values that meet a zero operand column: the matrix-layout phases then run without lane masks
@@ -309,6 +315,7 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ, GX>(
     // value r of array ID of group m, wherever it lives (r a compile-time constant after unrolling)
     enum { S_A1X, S_A2X, S_A1U, S_A2U, S_VBX, S_VCX, S_VBU, S_VCU, S_A3X, S_A3U, S_VLX, S_VLU };
     constexpr int SG_ = DG + NX + NVX + NU + NVU;              // (the four linear-row arrays behind everything else)
+    static_assert(SG_ + RLX + RLU == GSP, "a group's LDS image is what TransShape::spill_stride sizes it as");
     auto sld = [&](auto id, auto mt, int r) -> float {
         constexpr int ID = decltype(id)::value, m = decltype(mt)::value;
         constexpr int LOFF[12] = {0, NX, NX + NCX, NX + NCX + NU, DG, DG + NX, DG + NX + NVX, DG + NX + NVX + NU,
