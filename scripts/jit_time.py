@@ -19,7 +19,11 @@ for label, make in (("quadrotor N=10 (built in)", lambda: (t.problems.quadrotor(
                     ("(8,2) N=25", lambda: fam(8, 2, 25)),
                     ("(8,2) N=10", lambda: fam(8, 2, 10)),
                     ("(5,2) N=18", lambda: fam(5, 2, 18)),
-                    ("cartpole N=12", lambda: (t.problems.cartpole(12, u_bound=0.5), t.problems.cartpole_x0(65536, 0)))):
+                    ("cartpole N=10 (built in)", lambda: (t.problems.cartpole(10, u_bound=0.5), t.problems.cartpole_x0(65536, 0))),
+                    ("cartpole N=12", lambda: (t.problems.cartpole(12, u_bound=0.5), t.problems.cartpole_x0(65536, 0))),
+                    ("cartpole N=15 (built in)", lambda: (t.problems.cartpole(15, u_bound=0.5), t.problems.cartpole_x0(65536, 0))),
+                    ("cartpole N=30 (quad built in)", lambda: (t.problems.cartpole(30, u_bound=0.5), t.problems.cartpole_x0(65536, 0))),
+                    ("(3,2) N=16", lambda: fam(3, 2, 16))):
     prob, x0 = make()
     t0 = time.perf_counter()
     bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=65536)

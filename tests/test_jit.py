@@ -150,3 +150,91 @@ def test_constraint_layout_units_compile(unit, tmp_path):
     import re
     spills = [int(m) for m in re.findall(r"\.vgpr_spill_count:\s+(\d+)", asm)]
     assert spills and max(spills) <= 160, spills             # (the built-in N = 20 kernels spill 110 under their two-waves cap)
+
+
+LEAN_UNITS = {
+    # name: (nx, nu, N, LIVE, UBK, ONE, XB, REFS)
+    "cartpole_N12_two_wavefronts": (4, 1, 12, "false", "true", "false", "false", "tmpc::REF_ZERO"),
+    "cartpole_N30_live_state_bound_refs": (4, 1, 30, "true", "true", "true", "true", "tmpc::REF_SHARED"),
+    "three_states_two_inputs": (3, 2, 16, "false", "false", "true", "false", "tmpc::REF_SHARED"),
+}
+
+
+@pytest.mark.parametrize("unit", list(LEAN_UNITS))
+def test_lean_variant_units_compile(unit, tmp_path):
+    """what csrc/jit.cpp::jit_lean_for writes — ONE variant of the headline kernel for a shape without a built-in lean
+    instantiation — compiles for gfx950 with its flags (device code only) and stays (nearly) spill-free"""
+    import re
+    import subprocess
+    p = LEAN_UNITS[unit]
+    csrc = os.path.join(os.path.dirname(os.path.abspath(t.__file__)), "csrc")
+    src = tmp_path / "unit.hip"
+    src.write_text('#include "lean_entry.hip.h"\nTMPC_DEFINE_LEAN_JIT_ENTRY("lean<test>", ' + ", ".join(str(v) for v in p) + ")\n")
+    out = tmp_path / "unit.s"
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-honor-nans", "-DTMPC_JIT_UNIT",
+                    "-fno-slp-vectorize", "-I" + csrc, "-S", "--cuda-device-only", str(src), "-o", str(out)], check=True, capture_output=True, timeout=600)
+    asm = out.read_text()
+    assert "admm_lean_kernel" in asm
+    spills = [int(m) for m in re.findall(r"\.vgpr_spill_count:\s+(\d+)", asm)]
+    assert spills and max(spills) <= 48, spills
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["cartpole_N12", "cartpole_N30", "family_3_2_16", "family_2_1_8"])
+def test_lean_variants_specialised_at_the_first_solve(hip_lib, oracle_built, jit_on, shape):
+    """one-shot solves of a cartpole-class shape WITHOUT a built-in lean instantiation run on the headline kernel all the same:
+    the variant a launch needs is compiled at that launch (seconds, cached).  Every instance against the fp64 oracle in the
+    calling patterns the built-in lean kernels are tested with: fixed iterations, tolerance-terminated, a finite state bound,
+    shared references, input bounds that depend on the knot; other patterns (warm start) stay on the shape's quad kernel."""
+    B = 20480                                                   # (from here on one lane per instance is the batch's variant)
+    if shape.startswith("cartpole"):
+        N = int(shape.split("N")[1])
+        prob, x0 = t.problems.cartpole(N, u_bound=0.5), t.problems.cartpole_x0(B, seed=3)
+        nx, nu = 4, 1
+    else:
+        nx, nu, N = (3, 2, 16) if shape == "family_3_2_16" else (2, 1, 8)
+        prob, rng = _random_family(nx, nu, N, 14 + nx)
+        x0 = np.asfortranarray(rng.uniform(-0.5, 0.5, (nx, B)))
+    rng = np.random.default_rng(5)
+    xr, ur = 0.1 * rng.standard_normal((nx, N)), 0.05 * rng.standard_normal((nu, N - 1))
+    bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+    cases = [("fixed", dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=60, check_termination=10), False, False, False),
+             ("tol", dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1), False, False, False),
+             ("state bound + refs", dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=80, check_termination=5), True, True, False),
+             ("knot bounds + refs", dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=50, check_termination=0), False, True, True)]
+    for tag, kw, xb, refs, knot in cases:
+        x_min, x_max = prob.x_min.copy(), prob.x_max.copy()
+        u_min, u_max = prob.u_min.copy(), prob.u_max.copy()
+        if xb:
+            x_max[0, :] = np.abs(x0[0]).max() * 0.6             # binds for the instances that start beyond it
+            x_min[0, :] = -np.abs(x0[0]).max() * 0.6
+        if knot:
+            u_max[:, ::2] *= 0.8
+        bs.update_settings(**kw)
+        bs.set_bound_constraints(x_min, x_max, u_min, u_max)
+        bs.set_warm_start(False)
+        if refs:
+            bs.set_x_ref(xr)
+            bs.set_u_ref(ur)
+        bs.set_x0(x0)
+        bs.solve()
+        assert bs.last_launch_name == f"lean<{nx},{nu},{N}>", (tag, bs.last_launch_name, bs.kernel_name)
+        sol, st = bs.get_solution(), bs.get_status()
+        import copy
+        pb = copy.copy(prob)
+        pb.x_min, pb.x_max, pb.u_min, pb.u_max = x_min, x_max, u_min, u_max
+        ref = oracle_built.solve_batch("orc64", pb, x0, xref=xr if refs else None, uref=ur if refs else None, nthreads=16, **kw)
+
+        def mk(b=None, pb=pb, kw=kw, refs=refs):
+            o = oracle_built.CpuSolver("orc64", pb.A, pb.B, pb.Q, pb.R, pb.rho, pb.N)
+            o.update_settings(**kw)
+            o.set_bound_constraints(pb.x_min, pb.x_max, pb.u_min, pb.u_max)
+            if refs:
+                o.set_x_ref(xr)
+                o.set_u_ref(ur)
+            return o
+        parity_every_instance(sol, st, ref, mk, x0, kw, prob.rho, min_same=0.95, tag=f"{shape} {tag}")
+    bs.set_warm_start(True)                                     # the workspace is kept: not the lean kernel's pattern
+    bs.solve()
+    assert not bs.last_launch_name.startswith("lean<")
+    bs.close()

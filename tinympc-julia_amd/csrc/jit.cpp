@@ -59,7 +59,8 @@ std::string lib_dir() {   // .../tinympc-julia_amd/lib (where this library was l
 // FNV-1a over the kernel headers: the cache key of everything a unit is compiled from
 std::string source_hash(const std::string &csrc) {
     static const char *files[] = {"admm_params.h", "solver.h", "host_setup.h", "admm_quad.hip.h", "quad_entry.hip.h", "admm_mfma.hip.h",
-                                  "mfma_entry.hip.h", "admm_mfmac.hip.h", "mfmac_entry.hip.h", "admm_mfmat.hip.h", "mfmat_entry.hip.h"};
+                                  "mfma_entry.hip.h", "admm_mfmac.hip.h", "mfmac_entry.hip.h", "admm_mfmat.hip.h", "mfmat_entry.hip.h",
+                                  "admm_lean.hip.h", "lean_entry.hip.h"};
     unsigned long long h = 1469598103934665603ull;
     for (const char *c = "flags: -O3 -DTMPC_JIT_UNIT -DTMPC_MFMAT_HANDOVER=2 -amdgpu-mfma-vgpr-form"; *c; ++c) h = (h ^ (unsigned char)*c) * 1099511628211ull;
     for (const char *f : files) {
@@ -90,7 +91,7 @@ int run(const std::vector<std::string> &argv, const std::string &log) {
     return WIFEXITED(status) ? WEXITSTATUS(status) : -1;
 }
 
-const void *build_unit(const std::string &unit, const std::string &source, int verbose) {
+const void *build_unit(const std::string &unit, const std::string &source, int verbose, const char *extra_flag = nullptr) {
     const std::string lib = lib_dir();
     if (lib.empty()) return nullptr;
     const std::string csrc = lib + "/../csrc";
@@ -115,10 +116,11 @@ const void *build_unit(const std::string &unit, const std::string &source, int v
         const auto t0 = std::chrono::steady_clock::now();
         // (-DTMPC_MFMAT_HANDOVER=2: the transposed-sets kernel's hand-over stores as one asm statement each — the default form's
         // store order is held by an assembly test that only sees the built-in instantiations, tests/test_mfmat_asm.py)
-        const int rc = run({hipcc, "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-fno-honor-nans", "-DTMPC_JIT_UNIT",
-                            "-DTMPC_MFMAT_HANDOVER=2", "-mllvm", "-amdgpu-mfma-vgpr-form", "-I" + csrc, src, "-o", tmp, "-L" + lib, "-ltinympc_hip",
-                            "-Wl,-rpath," + lib},
-                           cache + "/" + unit + ".log");
+        std::vector<std::string> cmd = {hipcc, "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-fno-honor-nans", "-DTMPC_JIT_UNIT",
+                                        "-DTMPC_MFMAT_HANDOVER=2", "-mllvm", "-amdgpu-mfma-vgpr-form", "-I" + csrc, src, "-o", tmp, "-L" + lib, "-ltinympc_hip",
+                                        "-Wl,-rpath," + lib};
+        if (extra_flag) cmd.push_back(extra_flag);
+        const int rc = run(cmd, cache + "/" + unit + ".log");
         const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (rc != 0 || ::rename(tmp.c_str(), so.c_str()) != 0) {
             ::unlink(tmp.c_str());
@@ -237,6 +239,31 @@ const ConeEntry *jit_trans_for(const Solver &sv, int verbose) {
     const ConeEntry *e = static_cast<const ConeEntry *>(build_unit(name.str(), src.str(), verbose));
     g_units[name.str()] = e;
     if (e) g_trans.push_back(e);
+    return e;
+}
+
+// One variant of the lean kernel (admm_lean.hip.h, the headline's) for a shape without a built-in lean instantiation, compiled at
+// the first launch that needs it.  variant bits: LV_LIVE tolerance-terminated, LV_UBK the input bounds do not depend on the
+// knot, LV_ONE the 512-register form, LV_XB a finite state bound, LV_SHARED shared references.  The kernel holds one lane's
+// whole solve in registers and its coefficients in scalar registers: 32 coefficient doubles and ~490 registers at most —
+// cartpole-class systems ((4,1) to N = 36, (3,2), (2,x)); anything else: nullptr, the quad / stream kernels as before.
+const LeanEntry *jit_lean_for(int nx, int nu, int N, int variant, int verbose) {
+    if (std::getenv("TINYMPC_HIP_NO_JIT")) return nullptr;
+    if (nx < 1 || nu < 1 || N < 3 || lean_layout(nx, nu).padded > 32) return nullptr;
+    const bool one = (variant & LV_ONE) != 0;
+    if (2 * N * nx + (one ? 4 : 3) * N * nu + 50 > (one ? 490 : 250)) return nullptr;
+    std::ostringstream name, src;
+    name << "lean_" << nx << "_" << nu << "_" << N << "_v" << variant;
+    auto tf = [&](int bit) { return (variant & bit) ? "true" : "false"; };
+    src << "// specialised at the first solve by jit.cpp\n#include \"lean_entry.hip.h\"\nTMPC_DEFINE_LEAN_JIT_ENTRY(\"lean<" << nx << "," << nu << "," << N
+        << ">\", " << nx << ", " << nu << ", " << N << ", " << tf(LV_LIVE) << ", " << tf(LV_UBK) << ", " << tf(LV_ONE) << ", " << tf(LV_XB) << ", "
+        << ((variant & LV_SHARED) ? "tmpc::REF_SHARED" : "tmpc::REF_ZERO") << ")\n";
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_units.find(name.str());
+    if (it != g_units.end()) return static_cast<const LeanEntry *>(it->second);
+    // (-fno-slp-vectorize: the vectoriser's <2 x double> tuples are what makes this kernel spill, csrc/Makefile)
+    const LeanEntry *e = static_cast<const LeanEntry *>(build_unit(name.str(), src.str(), verbose, "-fno-slp-vectorize"));
+    g_units[name.str()] = e;
     return e;
 }
 

@@ -38,6 +38,24 @@ hipError_t launch_lean(const AdmmParams &P, bool live, bool knot_bounds, bool st
                         : launch_lean_v<NX, NU, N, false, REF_ZERO>(P, live, knot_bounds, stream);
 }
 
+// ---- one variant specialised at the first solve that needs it (jit.cpp: jit_lean_for) ----
+// The headline kernel for a shape the library has no lean instantiation of (cartpole at another horizon, a smaller system):
+// the reference accepts any (nx, nu, N) at run time (tiny_api.cpp:21-71).  A whole entry is 24 kernels and 45-90 s of compiler;
+// one variant — the (LIVE, UBK, ONE, XB, REFS) the launch in hand needs — is a few seconds, so a unit carries exactly one.
+template <int NX, int NU, int N, bool LIVE, bool UBK, bool ONE, bool XB, int REFS>
+hipError_t launch_lean_exact(const AdmmParams &P, bool, bool, bool, hipStream_t stream) {
+    hipLaunchKernelGGL((admm_lean_kernel<NX, NU, N, LIVE, UBK, ONE, XB, REFS>), dim3((P.batch + 255) / 256), dim3(256), 0, stream, P);
+    return hipGetLastError();
+}
+#define TMPC_DEFINE_LEAN_JIT_ENTRY(NAME, NX, NU, NN, LIVE, UBK, ONE, XB, REFS)                                        \
+    namespace tmpc {                                                                                                \
+    const LeanEntry *lean_jit_entry() {                                                                             \
+        static const LeanEntry e = {NX, NU, NN, NAME, &launch_lean_exact<NX, NU, NN, LIVE, UBK, ONE, XB, REFS>};    \
+        return &e;                                                                                                  \
+    }                                                                                                               \
+    }                                                                                                               \
+    extern "C" const void *tmpc_jit_entry() { return tmpc::lean_jit_entry(); }
+
 #define TMPC_DEFINE_LEAN_ENTRY(NX, NU, NN)                                                          \
     const LeanEntry *lean_entry_##NX##_##NU##_##NN() {                                              \
         static const LeanEntry e = {NX, NU, NN, "lean<" #NX "," #NU "," #NN ">", &launch_lean<NX, NU, NN>}; \

@@ -48,6 +48,9 @@ struct LeanEntry {
     hipError_t (*launch)(const AdmmParams &, bool live, bool knot_bounds, bool state_bounds, hipStream_t);
 };
 const LeanEntry *find_lean_kernel(int nx, int nu, int N);
+// ... or ONE variant of it specialised at the first launch that needs it (jit.cpp; nullptr: the shape does not fit the kernel)
+enum { LV_LIVE = 1, LV_UBK = 2, LV_ONE = 4, LV_XB = 8, LV_SHARED = 16, LV_COUNT = 32 };
+const LeanEntry *jit_lean_for(int nx, int nu, int N, int variant, int verbose);
 // the lean kernel's fp64 pack (lean_layout); false when the family does not qualify (cache.AmBKt is not (A - B Kinf)')
 bool build_lean_pack(const Solver &, std::vector<double> &);
 // One (nx, nu) instantiation of the run-time-horizon stream kernel (admm_streamg.hip.h).
@@ -176,6 +179,9 @@ struct Solver {
     // the lean kernel of the shape (admm_lean.hip.h): takes the one-lane-per-instance quad entry's one-shot solves without an
     // active state bound (launch_pass decides per launch); its pack, and whether the family qualifies (build_lean_pack)
     const LeanEntry *le = nullptr;
+    bool lean_jit = false;                // no built-in lean instantiation: single variants specialised at the launches that need them
+    const LeanEntry *le_var[LV_COUNT] = {};
+    bool le_var_tried[LV_COUNT] = {};
     double *d_lean = nullptr;
     bool lean_ok = false, lean_knot_bounds = false;
     bool lean_enabled = true;             // TINYMPC_HIP_NO_LEAN, read once at creation

@@ -656,10 +656,38 @@ int Solver::upload_packs() {
     HIP_TRY(hipMemcpy(d_bounds, bnd.data(), bnd.size() * sizeof(float), hipMemcpyHostToDevice));
     // the lean kernel's own pack where the selected entry has one lane per instance and the shape a lean instantiation
     le = (ke && ke->G == 1 && lean_enabled) ? find_lean_kernel(nx, nu, N) : nullptr;
+    // (a shape without one — cartpole at another horizon, a unit specialised at setup with four lanes per instance: where one
+    // lane per instance is the batch's variant, launch_pass specialises the variant it needs, jit_lean_for)
+    lean_jit = !le && ke && lean_enabled && !sw.no_jit && !no_specialise && (ke->G == 1 || (ke->jit && ke->G < 16 && batch >= 20480));
     lean_ok = false;
-    if (le) {
+    if (le || lean_jit) {
         std::vector<double> lp;
         if (build_lean_pack(*this, lp)) {
+            if (!le && ke->G != 1) {
+                // the lean kernel reads the one-lane-per-instance bound pack — [knot][x_min x_max u_min u_max], then diag(Q) + rho,
+                // diag(R) + rho (quad_entry.hip.h: build_quad_bounds with G = 1); the selected entry's pack is four lanes per
+                // instance: the lean one rides behind the coefficient doubles (launch_pass points P.bounds there)
+                constexpr float kInf = std::numeric_limits<float>::infinity();
+                const int BW = 2 * nx + 2 * nu;
+                std::vector<float> lb((size_t)N * BW + nx + nu + 1, 0.f);
+                for (int k = 0; k < N; ++k) {
+                    float *p = lb.data() + (size_t)k * BW;
+                    for (int r = 0; r < nx; ++r) {
+                        p[r] = st.en_state_bound ? (float)x_min[r + (size_t)k * nx] : -kInf;
+                        p[nx + r] = st.en_state_bound ? (float)x_max[r + (size_t)k * nx] : kInf;
+                    }
+                    for (int a = 0; a < nu; ++a) {
+                        const bool on = st.en_input_bound && k < N - 1;
+                        p[2 * nx + a] = on ? (float)u_min[a + (size_t)k * nu] : -kInf;
+                        p[2 * nx + nu + a] = on ? (float)u_max[a + (size_t)k * nu] : kInf;
+                    }
+                }
+                for (int r = 0; r < nx; ++r) lb[(size_t)N * BW + r] = (float)cache.Qd[r];
+                for (int a = 0; a < nu; ++a) lb[(size_t)N * BW + nx + a] = (float)cache.Rd[a];
+                const size_t at = lp.size();
+                lp.resize(at + (lb.size() + 1) / 2, 0.0);
+                std::memcpy(lp.data() + at, lb.data(), lb.size() * sizeof(float));
+            }
             if (dev_alloc(d_lean, lp.size())) return -1;
             HIP_TRY(hipMemcpy(d_lean, lp.data(), lp.size() * sizeof(double), hipMemcpyHostToDevice));
             lean_ok = true;
@@ -1203,16 +1231,29 @@ int Solver::launch_pass(hipStream_t stream, int mpc_steps, const int *idx, int n
     const bool carry_g = state_bounds_active || (ke && ke->G == 16 && g_maybe_nonzero);
     // one-shot solves (cold start, nothing of the workspace kept) of a one-lane-per-instance entry, zero or shared references,
     // fp64 recurrences: the lean kernel (same arithmetic, a third fewer instructions)
-    const bool lean = ke && le && lean_ok && precision == 0 && cold && !save && mpc_steps == 0 && !idx &&
-                      ref_mode != REF_PER_INSTANCE && !st.adaptive_rho && max_iter_pass >= 1;
+    const bool lean_call = ke && lean_ok && precision == 0 && cold && !save && mpc_steps == 0 && !idx &&
+                           ref_mode != REF_PER_INSTANCE && !st.adaptive_rho && max_iter_pass >= 1;
+    const bool lean_live = st.abs_pri_tol > 0.0 && st.abs_dua_tol > 0.0;
+    const LeanEntry *lk = lean_call ? le : nullptr;
+    if (lean_call && !le && lean_jit) {
+        // the one variant this launch needs (lean_entry.hip.h: launch_lean_v's choices), compiled on first use
+        bool one = (P.batch + 255) / 256 <= device_cu_count() || lean_live || sw.lean_one;
+        if (2 * N * nx + 3 * N * nu + 50 > 250) one = true;   // (the 256-register form does not hold this horizon)
+        const int v = (lean_live ? LV_LIVE : 0) | (lean_knot_bounds ? 0 : LV_UBK) | (one ? LV_ONE : 0) | (state_bounds_active ? LV_XB : 0) |
+                      (ref_mode == REF_SHARED ? LV_SHARED : 0);
+        if (!le_var_tried[v]) le_var[v] = jit_lean_for(nx, nu, N, v, verbose), le_var_tried[v] = true;
+        lk = le_var[v];
+    }
+    const bool lean = lk != nullptr;
+    if (lean && !le && ke->G != 1) P.bounds = reinterpret_cast<const float *>(d_lean + lean_layout(nx, nu).total);   // (upload_packs)
     P.lean = d_lean;
     P.ws64 = d_ws64;
     P.abs_pri_tol64 = st.abs_pri_tol;
     P.abs_dua_tol64 = st.abs_dua_tol;
     P.host_flags = (sw.no_refill ? HF_NO_REFILL : 0) | (sw.no_uni ? HF_NO_UNI : 0) | (sw.no_os ? HF_NO_OS : 0) | (sw.lean_one ? HF_LEAN_ONE : 0);
-    last_launch_name = lean ? le->name : kernel_name;
+    last_launch_name = lean ? lk->name : kernel_name;
     if (lean) {
-        HIP_TRY(le->launch(P, st.abs_pri_tol > 0.0 && st.abs_dua_tol > 0.0, lean_knot_bounds, state_bounds_active, stream));
+        HIP_TRY(lk->launch(P, lean_live, lean_knot_bounds, state_bounds_active, stream));
     } else
     HIP_TRY(ke ? ke->launch(P, precision, carry_g, stream)
                : (ce ? ce->launch(P, cones_active(), ce->lds_bytes(*this), stream)
