@@ -2,6 +2,8 @@
 mildly unstable A, random B, Q, R, rho — at the instantiated horizons, random input bounds (constant or per knot), finite state
 bounds on random rows or none, zero or shared references, fixed-iteration / tolerance-terminated settings with random check
 intervals, ragged batches of one lane per instance.  Every instance by solution at 1e-5 (tests/util.parity_every_instance).
+PRECISION=2: the same sweep on the kernel's fp64-state form (precision 2; specialised on request, csrc/jit.cpp), x0 / bounds /
+references rounded to fp32 on both sides, every instance at 1e-6 and iteration counts exactly.
 Usage: python scripts/fuzz_lean.py [first_seed] [n_cases]"""
 import os, sys
 import numpy as np
@@ -9,6 +11,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tinympc_julia_amd as t
 from oracle import cpu_oracle
 from tests.util import parity_every_instance, FP32_TOL
+P2 = os.environ.get("PRECISION") == "2"
+if P2:
+    os.environ.pop("TINYMPC_HIP_NO_JIT", None)
+    os.environ.setdefault("TINYMPC_HIP_CACHE", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "jit_cache"))
+f32 = lambda a: np.asfortranarray(np.asarray(a, dtype=np.float32).astype(np.float64))
 
 
 def one(seed):
@@ -38,6 +45,10 @@ def one(seed):
     kw = [dict(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=int(rng.integers(1, 120)), check_termination=int(rng.choice([0, 1, 3, 7]))),
           dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=int(rng.integers(20, 120)), check_termination=int(rng.choice([1, 2, 5, 10])))][int(rng.integers(0, 2))]
     x0 = np.asfortranarray(rng.uniform(-0.5, 0.5, (nx, B)))
+    if P2:                                                      # (the library takes x0, bounds and references as fp32 arrays)
+        x0, xr, ur = f32(x0), (f32(xr) if refs else None), (f32(ur) if refs else None)
+        fb = lambda a: np.where(np.abs(a) >= 1e16, a, f32(a))     # (+-1e17 = "no bound" stays what it is: rounded to fp32 it would read as a finite bound)
+        prob.x_min, prob.x_max, prob.u_min, prob.u_max = fb(prob.x_min), fb(prob.x_max), fb(prob.u_min), fb(prob.u_max)
     tag = f"seed {seed} N={N} B={B} xb={xb} refs={refs} {kw}"
 
     def mk(b=None):
@@ -53,14 +64,27 @@ def one(seed):
         bs.update_settings(**kw)
         bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
         if xr is not None: bs.set_x_ref(xr); bs.set_u_ref(ur)
+        if P2: bs.set_precision(2)
         bs.set_warm_start(False); bs.set_x0(x0); bs.solve()
         name = bs.last_launch_name
-        assert name == f"lean<4,1,{N}>", name
-        parity_every_instance(bs.get_solution(), bs.get_status(), ref, mk, x0, kw, prob.rho, tol=FP32_TOL, min_same=0.9, tag=tag)
+        if P2 and xb and N > 17:                                # fp64 slack AND dual of every state row: the registers hold N <= 17
+            assert name == "generic<f64>", name
+        else:
+            assert name == (f"lean<4,1,{N};f64>" if P2 else f"lean<4,1,{N}>"), name
+        if P2:
+            from tests.util import nrel_batch
+            sol, st = bs.get_solution(), bs.get_status()
+            assert np.array_equal(st["iter"], ref["iter"]) and np.array_equal(st["solved"], ref["solved"]), "iteration counts differ"
+            ex, eu = nrel_batch(sol["states"], ref["x"]).max(), nrel_batch(sol["controls"], ref["u"]).max()
+            assert ex <= 1e-6 and eu <= 1e-6, f"x {ex:.2e} u {eu:.2e}"
+        else:
+            parity_every_instance(bs.get_solution(), bs.get_status(), ref, mk, x0, kw, prob.rho, tol=FP32_TOL, min_same=0.9, tag=tag)
         bs.close()
     except AssertionError as e:
         ok = False
         print("FAIL", tag, str(e)[:300], flush=True)
+        if P2:
+            return (N, xb, refs, kw["abs_pri_tol"] > 0), ok
         # the same case on the quad kernel this calling pattern ran on before (fp32 state slack): is the miss the family's or the kernel's?
         os.environ["TINYMPC_HIP_NO_LEAN"] = "1"
         try:

@@ -10,7 +10,7 @@ subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-
                 "-I" + os.path.join(ROOT, "tinympc-julia_amd/csrc"), "-S", os.path.join(ROOT, "tinympc-julia_amd/csrc/linst_4_1_20.hip"), "-o", asm], check=True,
                stderr=subprocess.DEVNULL)
 lines = open(asm).read().splitlines()
-want = "_ZN4tmpc16admm_lean_kernelILi4ELi1ELi20ELb0ELb1ELb1ELb0ELi0EEEvNS_10AdmmParamsE:"
+want = "_ZN4tmpc16admm_lean_kernelILi4ELi1ELi20ELb0ELb1ELb1ELb0ELi0EfEEvNS_10AdmmParamsE:"
 start = next(i for i, l in enumerate(lines) if l.startswith(want))
 end = next(i for i in range(start + 1, len(lines)) if lines[i].startswith(".Lfunc_end"))
 body = lines[start:end]

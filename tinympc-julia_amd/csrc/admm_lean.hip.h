@@ -59,14 +59,24 @@ struct LeanPack {
 
 // clamp(t, lo, hi) as one v_med3_f32 (lo <= hi; +-inf for "no bound")
 __device__ __forceinline__ float clamp3(float t, float lo, float hi) { return __builtin_amdgcn_fmed3f(t, lo, hi); }
+__device__ __forceinline__ double clamp3(double t, double lo, double hi) { return fmin(fmax(t, lo), hi); }
+__device__ __forceinline__ float lean_max(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double lean_max(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ float lean_abs(float a) { return fabsf(a); }
+__device__ __forceinline__ double lean_abs(double a) { return fabs(a); }
 
 // ONE: the launch has at most one wavefront per SIMD (batch <= 256 x CUs), so the kernel may take the whole register file:
 // the feed-forward term d is then kept in fp64 too (nu (N-1) more registers, two conversions per knot fewer: 3.5 % of the
 // instructions).  Otherwise (fixed-iteration solves of larger batches) the kernel is held to 256 registers and two wavefronts
 // share a SIMD: within 3 % of 512-register wavefronts taking turns without a state bound, 12 % better with one; the
 // tolerance-terminated (LIVE) kernels spill at 256 registers and are only built in the ONE form (lean_entry.hip.h).
-template <int NX, int NU, int N, bool LIVE, bool UBK, bool ONE, bool XB = false, int REFS = REF_ZERO>
+// ST: the type of the slack / dual state.  float: the library's precision 0 (fp64 recurrences, fp32 state).  double: the
+// reference's own arithmetic end to end (types.hpp:15) — precision 2 for one-shot solves of the shapes this kernel holds, at
+// this kernel's speed instead of the generic kernel's; only ever specialised on request (jit.cpp), in the ONE form.
+template <int NX, int NU, int N, bool LIVE, bool UBK, bool ONE, bool XB = false, int REFS = REF_ZERO, class ST = float>
 __global__ __launch_bounds__(256, (ONE ? 1 : 2)) void admm_lean_kernel(const AdmmParams P) {
+    constexpr bool F64 = std::is_same<ST, double>::value;
+    static_assert(!F64 || ONE, "fp64 state: the 512-register form");
     static_assert(REFS == REF_ZERO || REFS == REF_SHARED, "lean kernel: zero or shared references");
 #ifdef TMPC_LEAN_CLOCK_PROBE
     const unsigned long long probe_entry = __builtin_amdgcn_s_memrealtime();
@@ -110,15 +120,15 @@ __global__ __launch_bounds__(256, (ONE ? 1 : 2)) void admm_lean_kernel(const Adm
     const SBlock<double, L::NLOADS> blk(P.lean);
     const auto cM = blk.at(L::O_M), cK = blk.at(L::O_K), cB = blk.at(L::O_B), cC = blk.at(L::O_C);
 
-    float lo[NU], hi[NU];
+    ST lo[NU], hi[NU];
 #pragma unroll
-    for (int a = 0; a < NU; ++a) lo[a] = P.bounds[2 * NX + a], hi[a] = P.bounds[2 * NX + NU + a];
+    for (int a = 0; a < NU; ++a) lo[a] = (ST)P.bounds[2 * NX + a], hi[a] = (ST)P.bounds[2 * NX + NU + a];
 
     // ---- the iterated state: x (= v = vnew) in fp64 — or, with an active state bound, the state dual g and q~ = vnew - g in
     // fp32 beside a running x — and input dual / slack / feed-forward in fp32 ----
     double X[XB ? 1 : N][NX];           // XB: X[0] is the plant state x0 only
-    float G[XB ? N : 1][NX], QT[XB ? N : 1][NX];
-    float Y[N - 1][NU], Z[N - 1][NU];
+    ST G[XB ? N : 1][NX], QT[XB ? N : 1][NX];
+    ST Y[N - 1][NU], Z[N - 1][NU];
     using DT = std::conditional_t<ONE, double, float>;
     DT D[N - 1][NU];
 #pragma unroll
@@ -130,35 +140,36 @@ __global__ __launch_bounds__(256, (ONE ? 1 : 2)) void admm_lean_kernel(const Adm
 #pragma unroll
     for (int k = 0; k < (XB ? N : 1); ++k)
 #pragma unroll
-        for (int m = 0; m < NX; ++m) G[k][m] = 0.f, QT[k][m] = 0.f;
+        for (int m = 0; m < NX; ++m) G[k][m] = (ST)0, QT[k][m] = (ST)0;
 #pragma unroll
     for (int k = 0; k < N - 1; ++k)
 #pragma unroll
-        for (int a = 0; a < NU; ++a) Y[k][a] = 0.f, Z[k][a] = 0.f, D[k][a] = (DT)0;
+        for (int a = 0; a < NU; ++a) Y[k][a] = (ST)0, Z[k][a] = (ST)0, D[k][a] = (DT)0;
 
 #ifdef TMPC_LEAN_CLOCK_PROBE
     const unsigned long long probe_t0 = __builtin_amdgcn_s_memtime(), probe_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     int it = 0, conv = 0;
-    float res0 = 0.f, res1 = 0.f, res2 = 0.f, res3 = 0.f;
+    ST res0 = 0, res1 = 0, res2 = 0, res3 = 0;
     const int ct = P.check_termination;
     const int last_check_it = ct > 0 ? (P.max_iter / ct) * ct : 0;
-    const float rho = P.rho;
+    const ST rho = F64 ? (ST)P.rho_family : (ST)P.rho;
+    const ST ptol = F64 ? (ST)P.abs_pri_tol64 : (ST)P.abs_pri_tol, dtol = F64 ? (ST)P.abs_dua_tol64 : (ST)P.abs_dua_tol;
     double dua_x = 0.0;
-    float pri_u = 0.f, dua_u = 0.f, pri_xf = 0.f, dua_xf = 0.f;                  // (XB: the state residuals in fp32, like the slack they compare)
+    ST pri_u = 0, dua_u = 0, pri_xf = 0, dua_xf = 0;                             // (XB: the state residuals in the slack's own type)
     // XB: knot k's state slack / dual from the rollout's x_k  (admm.cpp:46, 55-58, 68; q~ for :79-80)
     auto state_sets = [&](auto res_tag, auto kk, const double (&x)[NX]) {
         constexpr bool RES = decltype(res_tag)::value;
         constexpr int k = decltype(kk)::value;
 #pragma unroll
         for (int m = 0; m < NX; ++m) {
-            const float xf = (float)x[m];
-            const float t = xf + G[k][m];                                       // vnew = x + g
-            const float vn = clamp3(t, s_xb[k * 2 * NX + m], s_xb[k * 2 * NX + NX + m]);
-            const float gn = t - vn;                                            // g = g + x - vnew
+            const ST xf = (ST)x[m];
+            const ST t = xf + G[k][m];                                          // vnew = x + g
+            const ST vn = clamp3(t, (ST)s_xb[k * 2 * NX + m], (ST)s_xb[k * 2 * NX + NX + m]);
+            const ST gn = t - vn;                                               // g = g + x - vnew
             if constexpr (RES) {
-                pri_xf = fmaxf(pri_xf, fabsf(xf - vn));
-                dua_xf = fmaxf(dua_xf, fabsf((QT[k][m] + G[k][m]) - vn));       // v = the previous vnew = q~ + g
+                pri_xf = lean_max(pri_xf, lean_abs(xf - vn));
+                dua_xf = lean_max(dua_xf, lean_abs((QT[k][m] + G[k][m]) - vn)); // v = the previous vnew = q~ + g
             }
             G[k][m] = gn;
             QT[k][m] = vn - gn;
@@ -170,7 +181,7 @@ __global__ __launch_bounds__(256, (ONE ? 1 : 2)) void admm_lean_kernel(const Adm
     auto forward = [&](auto res_tag, bool first_iter) {
         constexpr bool RES = decltype(res_tag)::value;
         if constexpr (RES) {
-            dua_x = 0.0, pri_u = 0.f, dua_u = 0.f, pri_xf = 0.f, dua_xf = 0.f;
+            dua_x = 0.0, pri_u = 0, dua_u = 0, pri_xf = 0, dua_xf = 0;
             if constexpr (!XB)
                 if (first_iter) {   // cold start: the previous state slack is the zero workspace at knot 0 too, where vnew is x0 (admm.cpp:94)
 #pragma unroll
@@ -220,15 +231,15 @@ __global__ __launch_bounds__(256, (ONE ? 1 : 2)) void admm_lean_kernel(const Adm
             }
 #pragma unroll
             for (int a = 0; a < NU; ++a) {
-                const float uf = (float)u[a];
-                const float t = uf + Y[k][a];                                   // znew = u + y  (admm.cpp:45)
-                float l_ = lo[a], h_ = hi[a];
-                if constexpr (!UBK) l_ = s_bnd[k * 2 * NU + a], h_ = s_bnd[k * 2 * NU + NU + a];
-                const float zn = clamp3(t, l_, h_);                             //   clamped to [u_min, u_max]  (:50-52)
+                const ST uf = (ST)u[a];
+                const ST t = uf + Y[k][a];                                      // znew = u + y  (admm.cpp:45)
+                ST l_ = lo[a], h_ = hi[a];
+                if constexpr (!UBK) l_ = (ST)s_bnd[k * 2 * NU + a], h_ = (ST)s_bnd[k * 2 * NU + NU + a];
+                const ST zn = clamp3(t, l_, h_);                                //   clamped to [u_min, u_max]  (:50-52)
                 Y[k][a] = t - zn;                                               // y = y + u - znew  (:67)
                 if constexpr (RES) {
-                    pri_u = fmaxf(pri_u, fabsf(uf - zn));                       // (:95)
-                    dua_u = fmaxf(dua_u, fabsf(Z[k][a] - zn));                  // (:96), times rho at the check
+                    pri_u = lean_max(pri_u, lean_abs(uf - zn));                 // (:95)
+                    dua_u = lean_max(dua_u, lean_abs(Z[k][a] - zn));            // (:96), times rho at the check
                 }
                 Z[k][a] = zn;
             }
@@ -312,7 +323,7 @@ __global__ __launch_bounds__(256, (ONE ? 1 : 2)) void admm_lean_kernel(const Adm
     // to (fp32 rounding of the sum can leave them by an ulp)
     auto vnew_at = [&](auto kk, auto mm) -> float {
         constexpr int k = decltype(kk)::value, m = decltype(mm)::value;
-        if constexpr (XB) return clamp3(QT[k][m] + G[k][m], s_xb[k * 2 * NX + m], s_xb[k * 2 * NX + NX + m]);
+        if constexpr (XB) return (float)clamp3(QT[k][m] + G[k][m], (ST)s_xb[k * 2 * NX + m], (ST)s_xb[k * 2 * NX + NX + m]);
         else return (float)X[XB ? 0 : k][m];
     };
     auto store = [&](bool solved_flag) {
@@ -328,13 +339,13 @@ __global__ __launch_bounds__(256, (ONE ? 1 : 2)) void admm_lean_kernel(const Adm
 #pragma unroll
         for (int k = 0; k < N - 1; ++k)
 #pragma unroll
-            for (int a = 0; a < NU; ++a) uo[k * NU + a] = Z[k][a];
+            for (int a = 0; a < NU; ++a) uo[k * NU + a] = (float)Z[k][a];
         P.iter[b] = P.iter_offset + it;
         P.solved[b] = solved_flag ? 1 : 0;
-        ro[0] = res0;
-        ro[1] = res1;
-        ro[2] = res2;
-        ro[3] = res3;
+        ro[0] = (float)res0;
+        ro[1] = (float)res1;
+        ro[2] = (float)res2;
+        ro[3] = (float)res3;
     };
 
     // Iterations whose termination check can matter carry the residual arithmetic (every check when the tolerances are
@@ -362,14 +373,13 @@ __global__ __launch_bounds__(256, (ONE ? 1 : 2)) void admm_lean_kernel(const Adm
         i += 1;
         if (!LIVE || !conv) {                                                   // termination_condition (admm.cpp:89-107)
             it += 1;
-            res0 = XB ? pri_xf : 0.f;                                           // (no active state bound: x - vnew = 0)
-            res1 = (XB ? dua_xf : (float)dua_x) * rho;
+            res0 = XB ? pri_xf : (ST)0;                                         // (no active state bound: x - vnew = 0)
+            res1 = (XB ? dua_xf : (ST)dua_x) * rho;
             res2 = pri_u;
             res3 = dua_u * rho;
         }
         if constexpr (LIVE) {
-            const bool now = active && !conv && res0 < P.abs_pri_tol && res2 < P.abs_pri_tol && res1 < P.abs_dua_tol &&
-                             res3 < P.abs_dua_tol;
+            const bool now = active && !conv && res0 < ptol && res2 < ptol && res1 < dtol && res3 < dtol;
             if (now) {                                                          // returns before v = vnew and the backward pass (:181-193)
                 store(true);
                 conv = 1;
@@ -389,12 +399,12 @@ __global__ __launch_bounds__(256, (ONE ? 1 : 2)) void admm_lean_kernel(const Adm
             const long w0 = (long)blockIdx.x * 256 + (tid & ~63);          // the wavefront's first instance
             store_wave_coalesced<EX, EU>(s_stage[tid >> 6], P.xout + w0 * EX, P.uout + w0 * EU, lane, mask,
                                          [&](auto ee) { constexpr int e = decltype(ee)::value; return vnew_at(std::integral_constant<int, e / NX>{}, std::integral_constant<int, e % NX>{}); },
-                                         [&](auto ee) { constexpr int e = decltype(ee)::value; return Z[e / NU][e % NU]; });
+                                         [&](auto ee) { constexpr int e = decltype(ee)::value; return (float)Z[e / NU][e % NU]; });
             if (mine) {
                 float *ro = P.res + b * 4;
                 P.iter[b] = P.iter_offset + it;
                 P.solved[b] = 0;
-                ro[0] = res0, ro[1] = res1, ro[2] = res2, ro[3] = res3;
+                ro[0] = (float)res0, ro[1] = (float)res1, ro[2] = (float)res2, ro[3] = (float)res3;
 #ifdef TMPC_LEAN_CLOCK_PROBE
                 ro[0] = (float)(__builtin_amdgcn_s_memtime() - probe_t0);          // core clocks of the iteration loop (+ store issue)
                 ro[1] = (float)(__builtin_amdgcn_s_memrealtime() - probe_r0);      // ... in 100 MHz ticks
@@ -405,7 +415,7 @@ __global__ __launch_bounds__(256, (ONE ? 1 : 2)) void admm_lean_kernel(const Adm
     }
 
     {   // global status block: wavefront max of the residuals, count of unsolved instances
-        float m0 = active ? res0 : 0.f, m1 = active ? res1 : 0.f, m2 = active ? res2 : 0.f, m3 = active ? res3 : 0.f;
+        float m0 = active ? (float)res0 : 0.f, m1 = active ? (float)res1 : 0.f, m2 = active ? (float)res2 : 0.f, m3 = active ? (float)res3 : 0.f;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             m0 = fmaxf(m0, __shfl_xor(m0, o, 64));

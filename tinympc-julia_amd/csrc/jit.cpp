@@ -244,20 +244,23 @@ const ConeEntry *jit_trans_for(const Solver &sv, int verbose) {
 
 // One variant of the lean kernel (admm_lean.hip.h, the headline's) for a shape without a built-in lean instantiation, compiled at
 // the first launch that needs it.  variant bits: LV_LIVE tolerance-terminated, LV_UBK the input bounds do not depend on the
-// knot, LV_ONE the 512-register form, LV_XB a finite state bound, LV_SHARED shared references.  The kernel holds one lane's
+// knot, LV_ONE the 512-register form, LV_XB a finite state bound, LV_SHARED shared references, LV_F64 slack / dual state in
+// fp64 (precision 2: the reference's arithmetic end to end at this kernel's speed).  The kernel holds one lane's
 // whole solve in registers and its coefficients in scalar registers: 32 coefficient doubles and ~490 registers at most —
 // cartpole-class systems ((4,1) to N = 36, (3,2), (2,x)); anything else: nullptr, the quad / stream kernels as before.
 const LeanEntry *jit_lean_for(int nx, int nu, int N, int variant, int verbose) {
     if (std::getenv("TINYMPC_HIP_NO_JIT")) return nullptr;
     if (nx < 1 || nu < 1 || N < 3 || lean_layout(nx, nu).padded > 32) return nullptr;
-    const bool one = (variant & LV_ONE) != 0;
-    if (2 * N * nx + (one ? 4 : 3) * N * nu + 50 > (one ? 490 : 250)) return nullptr;
+    const bool one = (variant & LV_ONE) != 0, f64 = (variant & LV_F64) != 0, xb = (variant & LV_XB) != 0;
+    if (f64 && !one) return nullptr;
+    const int regs = f64 ? (xb ? 4 : 2) * N * nx + 6 * N * nu + 50 : 2 * N * nx + (one ? 4 : 3) * N * nu + 50;
+    if (regs > (f64 ? 450 : (one ? 490 : 250))) return nullptr;   // (fp64 state with a state bound at N = 20: 490 values, 463 of them spilled)
     std::ostringstream name, src;
     name << "lean_" << nx << "_" << nu << "_" << N << "_v" << variant;
     auto tf = [&](int bit) { return (variant & bit) ? "true" : "false"; };
     src << "// specialised at the first solve by jit.cpp\n#include \"lean_entry.hip.h\"\nTMPC_DEFINE_LEAN_JIT_ENTRY(\"lean<" << nx << "," << nu << "," << N
-        << ">\", " << nx << ", " << nu << ", " << N << ", " << tf(LV_LIVE) << ", " << tf(LV_UBK) << ", " << tf(LV_ONE) << ", " << tf(LV_XB) << ", "
-        << ((variant & LV_SHARED) ? "tmpc::REF_SHARED" : "tmpc::REF_ZERO") << ")\n";
+        << (f64 ? ";f64" : "") << ">\", " << nx << ", " << nu << ", " << N << ", " << tf(LV_LIVE) << ", " << tf(LV_UBK) << ", " << tf(LV_ONE) << ", " << tf(LV_XB)
+        << ", " << ((variant & LV_SHARED) ? "tmpc::REF_SHARED" : "tmpc::REF_ZERO") << ", " << (f64 ? "double" : "float") << ")\n";
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_units.find(name.str());
     if (it != g_units.end()) return static_cast<const LeanEntry *>(it->second);

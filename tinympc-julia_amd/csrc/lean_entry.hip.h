@@ -42,15 +42,16 @@ hipError_t launch_lean(const AdmmParams &P, bool live, bool knot_bounds, bool st
 // The headline kernel for a shape the library has no lean instantiation of (cartpole at another horizon, a smaller system):
 // the reference accepts any (nx, nu, N) at run time (tiny_api.cpp:21-71).  A whole entry is 24 kernels and 45-90 s of compiler;
 // one variant — the (LIVE, UBK, ONE, XB, REFS) the launch in hand needs — is a few seconds, so a unit carries exactly one.
-template <int NX, int NU, int N, bool LIVE, bool UBK, bool ONE, bool XB, int REFS>
+// (ST = double: the fp64-state form, precision 2 — only ever built this way)
+template <int NX, int NU, int N, bool LIVE, bool UBK, bool ONE, bool XB, int REFS, class ST>
 hipError_t launch_lean_exact(const AdmmParams &P, bool, bool, bool, hipStream_t stream) {
-    hipLaunchKernelGGL((admm_lean_kernel<NX, NU, N, LIVE, UBK, ONE, XB, REFS>), dim3((P.batch + 255) / 256), dim3(256), 0, stream, P);
+    hipLaunchKernelGGL((admm_lean_kernel<NX, NU, N, LIVE, UBK, ONE, XB, REFS, ST>), dim3((P.batch + 255) / 256), dim3(256), 0, stream, P);
     return hipGetLastError();
 }
-#define TMPC_DEFINE_LEAN_JIT_ENTRY(NAME, NX, NU, NN, LIVE, UBK, ONE, XB, REFS)                                        \
+#define TMPC_DEFINE_LEAN_JIT_ENTRY(NAME, NX, NU, NN, LIVE, UBK, ONE, XB, REFS, ST)                                    \
     namespace tmpc {                                                                                                \
     const LeanEntry *lean_jit_entry() {                                                                             \
-        static const LeanEntry e = {NX, NU, NN, NAME, &launch_lean_exact<NX, NU, NN, LIVE, UBK, ONE, XB, REFS>};    \
+        static const LeanEntry e = {NX, NU, NN, NAME, &launch_lean_exact<NX, NU, NN, LIVE, UBK, ONE, XB, REFS, ST>}; \
         return &e;                                                                                                  \
     }                                                                                                               \
     }                                                                                                               \

@@ -49,7 +49,7 @@ struct LeanEntry {
 };
 const LeanEntry *find_lean_kernel(int nx, int nu, int N);
 // ... or ONE variant of it specialised at the first launch that needs it (jit.cpp; nullptr: the shape does not fit the kernel)
-enum { LV_LIVE = 1, LV_UBK = 2, LV_ONE = 4, LV_XB = 8, LV_SHARED = 16, LV_COUNT = 32 };
+enum { LV_LIVE = 1, LV_UBK = 2, LV_ONE = 4, LV_XB = 8, LV_SHARED = 16, LV_F64 = 32, LV_COUNT = 64 };
 const LeanEntry *jit_lean_for(int nx, int nu, int N, int variant, int verbose);
 // the lean kernel's fp64 pack (lean_layout); false when the family does not qualify (cache.AmBKt is not (A - B Kinf)')
 bool build_lean_pack(const Solver &, std::vector<double> &);

@@ -659,11 +659,15 @@ int Solver::upload_packs() {
     // (a shape without one — cartpole at another horizon, a unit specialised at setup with four lanes per instance: where one
     // lane per instance is the batch's variant, launch_pass specialises the variant it needs, jit_lean_for)
     lean_jit = !le && ke && lean_enabled && !sw.no_jit && !no_specialise && (ke->G == 1 || (ke->jit && ke->G < 16 && batch >= 20480));
+    // precision 2 (the generic kernel's fp64-state form, one lane per instance like this one): one-shot solves of a shape the lean
+    // kernel holds run on ITS fp64-state form, specialised on request — the reference's digits at the headline kernel's speed
+    if (precision == 2 && !ke && !se && !ce && !hetero && !extensions_active() && lean_enabled && !sw.no_jit && !no_specialise) lean_jit = true;
+    std::fill(le_var_tried, le_var_tried + LV_COUNT, false);
     lean_ok = false;
     if (le || lean_jit) {
         std::vector<double> lp;
         if (build_lean_pack(*this, lp)) {
-            if (!le && ke->G != 1) {
+            if (!le && (!ke || ke->G != 1)) {
                 // the lean kernel reads the one-lane-per-instance bound pack — [knot][x_min x_max u_min u_max], then diag(Q) + rho,
                 // diag(R) + rho (quad_entry.hip.h: build_quad_bounds with G = 1); the selected entry's pack is four lanes per
                 // instance: the lean one rides behind the coefficient doubles (launch_pass points P.bounds there)
@@ -1231,21 +1235,22 @@ int Solver::launch_pass(hipStream_t stream, int mpc_steps, const int *idx, int n
     const bool carry_g = state_bounds_active || (ke && ke->G == 16 && g_maybe_nonzero);
     // one-shot solves (cold start, nothing of the workspace kept) of a one-lane-per-instance entry, zero or shared references,
     // fp64 recurrences: the lean kernel (same arithmetic, a third fewer instructions)
-    const bool lean_call = ke && lean_ok && precision == 0 && cold && !save && mpc_steps == 0 && !idx &&
+    const bool lean_f64 = precision == 2 && !ke && lean_jit;
+    const bool lean_call = (ke ? precision == 0 : lean_f64) && lean_ok && cold && !save && mpc_steps == 0 && !idx &&
                            ref_mode != REF_PER_INSTANCE && !st.adaptive_rho && max_iter_pass >= 1;
     const bool lean_live = st.abs_pri_tol > 0.0 && st.abs_dua_tol > 0.0;
     const LeanEntry *lk = lean_call ? le : nullptr;
     if (lean_call && !le && lean_jit) {
         // the one variant this launch needs (lean_entry.hip.h: launch_lean_v's choices), compiled on first use
-        bool one = (P.batch + 255) / 256 <= device_cu_count() || lean_live || sw.lean_one;
+        bool one = (P.batch + 255) / 256 <= device_cu_count() || lean_live || sw.lean_one || lean_f64;
         if (2 * N * nx + 3 * N * nu + 50 > 250) one = true;   // (the 256-register form does not hold this horizon)
         const int v = (lean_live ? LV_LIVE : 0) | (lean_knot_bounds ? 0 : LV_UBK) | (one ? LV_ONE : 0) | (state_bounds_active ? LV_XB : 0) |
-                      (ref_mode == REF_SHARED ? LV_SHARED : 0);
+                      (ref_mode == REF_SHARED ? LV_SHARED : 0) | (lean_f64 ? LV_F64 : 0);
         if (!le_var_tried[v]) le_var[v] = jit_lean_for(nx, nu, N, v, verbose), le_var_tried[v] = true;
         lk = le_var[v];
     }
     const bool lean = lk != nullptr;
-    if (lean && !le && ke->G != 1) P.bounds = reinterpret_cast<const float *>(d_lean + lean_layout(nx, nu).total);   // (upload_packs)
+    if (lean && !le && (!ke || ke->G != 1)) P.bounds = reinterpret_cast<const float *>(d_lean + lean_layout(nx, nu).total);   // (upload_packs)
     P.lean = d_lean;
     P.ws64 = d_ws64;
     P.abs_pri_tol64 = st.abs_pri_tol;
