@@ -263,7 +263,10 @@ double tinympc_kernel_elapsed_mean_ms(tinympc_solver *s, int last_n);
  * comparisons and the workspace kept between solves in fp64, on the generic kernel (any shape and option set of the
  * single-family solvers; no fused closed loop); x0 / references / bounds go in and the solution comes out as the fp32
  * device arrays.  It is the mode for callers who need the reference's digits rather than the 1e-5 of the fp32-state
- * kernels (families whose duals lose digits to fp32 rounding miss 1e-5 there); it is the slowest path of the library.
+ * kernels (families whose duals lose digits to fp32 rounding miss 1e-5 there); it is the slowest path of the library —
+ * except cold one-shot solves of cartpole-class shapes ((4,1) to N = 30, (3,2), (2,x)), which are launched on the headline
+ * kernel's fp64-state variant, compiled on request (csrc/jit.cpp; tinympc_last_launch_name: "lean<...;f64>"): the same
+ * digits at that kernel's speed.
  * Switching to or from precision 2 restarts the workspace cold.
  * precision = 1 is a request to save time and does NOT meet the 1e-5 parity target on every instance (3 of the 65 536
  * benchmark cartpole instances miss it, worst 1.6e-5).  Where a shape has a matrix-core kernel that kernel is faster than the
