@@ -418,6 +418,77 @@ def time_config(t, torch, dev, stream, name, batch, seed, iters=100, tol=0.0, ch
         bs.close()
 
 
+def time_specialised(t, torch, dev, stream, steps=5, warmup=2):
+    """What the library compiles on request (csrc/jit.cpp) for solvers its built-in kernels do not fit, each timed beside the
+    same solver with the specialisation off (TINYMPC_HIP_NO_JIT=1, read when a solver is created): a shape without a built-in
+    instantiation, a constraint layout (cone lists / linear rows, bindings.cpp:414-490) the built-in entries do not compile,
+    precision 2 on the headline shape.  Compile times are one-off (cached on disk) and outside the timed region."""
+    import numpy as np
+    P = t.problems
+    os.environ.setdefault("TINYMPC_HIP_CACHE", os.path.join(ROOT, "gpurun_out", "jit_cache"))
+
+    def rocket20():
+        prob = P.rocket(20)
+        def cfg(bs):
+            bs.set_fdyn(prob.fdyn)
+            bs.set_cone_constraints([0], [3], [0.25], [0, 3], [3, 3], [0.5, 1.5])
+            bs.set_linear_constraints(np.array([[0.0, 0.0, -1.0, 0.0, 0.0, 0.3]]), [0.5], np.zeros((0, 3)), [])
+        return prob, P.rocket_x0(32768, seed=2), P.rocket_refs(20), cfg, 0
+
+    cases = {
+        "cartpole_N12_65536": lambda: (P.cartpole(12, u_bound=0.5), P.cartpole_x0(65536, seed=0), None, None, 0),
+        "quadrotor_N12_65536": lambda: (P.quadrotor(12, u_bound=0.5), P.quadrotor_x0(65536, seed=1), None, None, 0),
+        "rocket_N20_two_state_cones_thrust_cone_one_row_32768": rocket20,
+        "cartpole_65536_precision2": lambda: (P.cartpole(20, u_bound=0.5), P.cartpole_x0(65536, seed=0), None, None, 2),
+    }
+    out = {}
+    for key, make in cases.items():
+        entry = {}
+        for mode in ("specialised", "without"):
+            if mode == "without":
+                os.environ["TINYMPC_HIP_NO_JIT"] = "1"
+            try:
+                prob, x0, refs, cfg, precision = make()
+                t0 = time.perf_counter()
+                bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=x0.shape[1], device=dev.index)
+                bs.update_settings(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=100, check_termination=1)
+                bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+                if cfg is not None:
+                    cfg(bs)
+                bs.set_precision(precision)
+                bs.set_warm_start(False)
+                bs.set_x0(x0)
+                if refs is not None:
+                    bs.set_x_ref(refs[0])
+                    bs.set_u_ref(refs[1])
+                bs.set_profiling(True)
+                bs.solve_async(stream.cuda_stream)          # (first solve: where a layout / variant is compiled)
+                torch.cuda.synchronize(dev)
+                setup_s = time.perf_counter() - t0
+                for _ in range(warmup):
+                    bs.solve_async(stream.cuda_stream)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for _ in range(steps):
+                    bs.solve_async(stream.cuda_stream)
+                torch.cuda.synchronize(dev)
+                ms = 1e3 * (time.perf_counter() - t1) / steps
+                st = bs.get_status()
+                assert int(st["iter"].min()) == 100 == int(st["iter"].max()), "work skipped"
+                rec = {"kernel": bs.last_launch_name, "kernel_family": bs.kernel_name, "ms_per_step": ms, "kernel_ms": bs.kernel_elapsed_ms(steps),
+                       "solves_per_sec": x0.shape[1] / (ms * 1e-3), "setup_and_first_solve_s": round(setup_s, 2)}
+                bs.close()
+            finally:
+                os.environ.pop("TINYMPC_HIP_NO_JIT", None)
+            if mode == "specialised":
+                entry.update(rec)
+                entry["workload"] = f"{key}: 100 fixed ADMM iterations, cold one-shot" + (", precision 2 (fp64 state end to end)" if precision == 2 else "")
+            else:
+                entry["without_specialisation"] = rec
+        out[key] = entry
+    return out
+
+
 def run_mpc_mode(args, bs, prob, x0, dev, torch):
     """Extra (not the headline): the closed-loop regime of SURVEY 8(f) — warm-started solves, max_iter 10,
     tol 1e-3 — as K launches of one step (workspace round-trips through HBM every step) and as one fused
@@ -748,6 +819,11 @@ def main():
         # ... and the shape the reference's adaptive rho is built for (its tables are the quadrotor's, tiny_api.cpp:269-329)
         ex["quadrotor_65536_adaptive_rho"] = time_config(t, torch, dev, stream, "quadrotor", 65536, 1, adaptive=True)
         out["configs"] = ex
+        if not os.environ.get("TINYMPC_HIP_NO_JIT"):
+            try:
+                out["specialised"] = time_specialised(t, torch, dev, stream)
+            except Exception as e:   # (never the headline's problem: a box without a compiler runs the fallbacks, anything else is reported)
+                out["specialised"] = {"error": str(e)[:300]}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist_on:

@@ -12,6 +12,13 @@
 // header is a new directory.  No compiler, no sources, a failed compile (a shape whose state does not fit the chip), or
 // TINYMPC_HIP_NO_JIT=1: the solver runs on the stream / generic kernels as before.  Adaptive-rho and fp32-recurrence
 // variants are not part of such a unit (-DTMPC_JIT_UNIT: a third of the compile time); the routes know (KernelEntry::jit).
+//
+// Three kinds of unit, all through build_unit():
+//   jit_kernel_for   at setup: the quad / mfma entry of a SHAPE the library has no on-chip kernel for;
+//   jit_trans_for    at a solver's first solve: ONE admm_mfmat_kernel for exactly its CONSTRAINT LAYOUT — cone lists, linear
+//                    rows, other cone rows, another horizon (bindings.cpp:414-490 takes them at run time);
+//   jit_lean_for     at the launch that needs it: ONE variant of the lean kernel (the headline's) for a cartpole-class shape
+//                    without a built-in lean instantiation, and its fp64-state form for precision 2.
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <spawn.h>

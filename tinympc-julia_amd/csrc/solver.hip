@@ -369,7 +369,8 @@ const KernelEntry *Solver::route_quad(bool rollout) const {
     if (!st.adaptive_rho) {
         const KernelEntry *k = sw.group ? find_quad_kernel(nx, nu, N, sw.group) : nullptr;
         if (!k) k = select_quad_kernel(nx, nu, N, batch);
-        return (k && k->jit && precision != 0) ? nullptr : k;   // (a unit specialised at setup carries fp64 recurrences only)
+        // (a unit specialised at setup carries fp64 recurrences only; TINYMPC_HIP_NO_JIT on this solver: not a unit another one loaded either)
+        return (k && k->jit && (precision != 0 || sw.no_jit)) ? nullptr : k;
     }
     // adaptive rho: the ADP variant where the shape has one (4 lanes per instance, coefficient rows in registers: the
     // cartpole shapes) ...
@@ -392,7 +393,7 @@ const KernelEntry *Solver::route_quad(bool rollout) const {
 const KernelEntry *Solver::route_mfma(bool rollout, const KernelEntry *quad) const {
     if (strict_fp32() || sw.group || sw.no_mfma || sw.no_quad) return nullptr;
     const KernelEntry *m = find_mfma_kernel(nx, nu, N);
-    if (!m) return nullptr;
+    if (!m || (m->jit && sw.no_jit)) return nullptr;
     if (st.adaptive_rho)
         return (!quad && m->adp && !extensions_active() && chunk_iters == 0 && !rollout && !cache_overridden &&
                 (adapt_pure || adapt_dirty) && !sw.no_mfma_adp) ? m : nullptr;
