@@ -148,6 +148,14 @@ def test_constraint_layout_units_compile(unit, tmp_path):
     asm = out.read_text()
     assert "admm_mfmat_kernel" in asm and "v_mfma_f64_16x16x4" in asm
     import re
+    # every hand-over of the rollout (N - 1 steps, every iteration's sweep is one unrolled sequence) is ONE asm statement of
+    # two or three LDS stores: between #ASMSTART / #ASMEND the compiler moves nothing
+    blocks = re.findall(r"#ASMSTART\n(.*?)#ASMEND", asm, flags=re.S)
+    stores = [b.count("ds_write_b32") for b in blocks if "ds_write_b32" in b]
+    if p[0] > 4 and p[1] >= 2 and p[0] + p[1] >= 8:           # (the mask-free stores: narrower shapes store under lane masks, owners only)
+        assert len(stores) >= p[2] - 1 and set(stores) <= {2, 3}, (len(stores), set(stores))
+    else:
+        assert not stores
     spills = [int(m) for m in re.findall(r"\.vgpr_spill_count:\s+(\d+)", asm)]
     assert spills and max(spills) <= 160, spills             # (the built-in N = 20 kernels spill 110 under their two-waves cap)
 

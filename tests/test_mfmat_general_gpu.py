@@ -248,6 +248,13 @@ def test_layouts_the_kernel_does_not_take(hip_lib, monkeypatch):
     bs.solve()
     assert bs.kernel_name.startswith("stream"), bs.kernel_name
     bs.close()
+    monkeypatch.delenv("TINYMPC_HIP_NO_JIT")
+    monkeypatch.setenv("TINYMPC_HIP_HIPCC", "/nonexistent/hipcc")     # no compiler on the machine: the same fallback, no error
+    bs = _solver(prob, B, kw, None, None, None, ([], [], [], [0, 2], [2, 3], [1.0, 1.0]), None)   # (a layout no other test compiles)
+    bs.set_x0(x0)
+    bs.solve()
+    assert bs.kernel_name.startswith("stream"), bs.kernel_name
+    bs.close()
 
 
 @pytest.mark.parametrize("kernel", ["specialised", "stream", "generic"])
