@@ -286,3 +286,28 @@ def test_a_side_switched_off_keeps_the_other_sides_rows(hip_lib, oracle_built, m
     parity_every_instance(bs.get_solution(), bs.get_status(), ref, mk, x0, kw, prob.rho, tag=kernel)
     assert _rows_bind(only_u, ref, B) > 0
     bs.close()
+
+
+@pytest.mark.parametrize("shape", [(5, 2, 9), (4, 2, 11), (8, 2, 12), (7, 1, 10), (5, 3, 14), (8, 4, 8), (7, 4, 9), (8, 3, 10), (4, 4, 12)])
+def test_other_shapes_on_the_specialised_kernel(hip_lib, oracle_built, shape):
+    """the kernel template beyond the rocket's (6,3): fewer than eight rows or one input row (hand-over stores under lane masks),
+    a full second state slot (nx = 8), three and four inputs on the VALU columns ((8,3), (7,4), (8,4): more per-lane-group
+    constants than a wavefront has lanes — loaded in one pass until this test found it), four inputs in slot 1 — affine term, a state cone, an
+    input cone where two rows exist, one state row; one-shot, tolerance-terminated, every instance against the oracle"""
+    nx, nu, N = shape
+    B = 45
+    prob, rng = _family(40 + nx * 4 + nu, nx, nu, N)
+    fdyn = 0.02 * rng.standard_normal(nx)
+    xr, ur = 0.2 * rng.standard_normal((nx, N)), 0.1 * rng.standard_normal((nu, N - 1))
+    cones = ([0], [2], [0.8], [1], [3], [0.9]) if nu >= 2 else ([], [], [], [1], [3], [0.9])
+    lin = (rng.standard_normal((1, nx)), [0.4], np.zeros((0, nu)), [])
+    kw = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=60, check_termination=1)
+    x0 = np.asfortranarray(rng.uniform(-0.5, 0.5, (nx, B)))
+    mk = _oracle(oracle_built, prob, kw, xr, ur, fdyn, cones, lin)
+    ref = _loop(mk, x0)
+    bs = _solver(prob, B, kw, xr, ur, fdyn, cones, lin)
+    bs.set_x0(x0)
+    bs.solve()
+    assert bs.kernel_name.startswith(f"mfmat<{nx},{nu},{N}>"), bs.kernel_name
+    parity_every_instance(bs.get_solution(), bs.get_status(), ref, mk, x0, kw, prob.rho, tag=str(shape))
+    bs.close()

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(64, (mfmat_waves_per_simd<NX, NU, N, CXQ, CUQ, GX>(
     double cf[T::NLF];
 #pragma unroll
     for (int f = 0; f < T::NLF; ++f) cf[f] = gc64[f * 64 + l];
-    if (l < 4 * T::NKC) s_kc[l] = gc64[T::O_KC + l];
+    for (int i = l; i < 4 * T::NKC; i += 64) s_kc[i] = gc64[T::O_KC + i];   // (three or four VALU input columns: more than 64 constants)
     constexpr int NXH = T::NXH, MU = T::MU, VU = T::VU, VUA = T::VUA;
     // this lane's input components: cA (row g of u, what the accumulator's slot 2 starts from / returns), cB (the matrix-core
     // component behind the state rows of slot 1, lanes g >= NXH), and the VU components of the VALU columns; as cell rows
