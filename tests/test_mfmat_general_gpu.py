@@ -311,3 +311,37 @@ def test_other_shapes_on_the_specialised_kernel(hip_lib, oracle_built, shape):
     assert bs.kernel_name.startswith(f"mfmat<{nx},{nu},{N}>"), bs.kernel_name
     parity_every_instance(bs.get_solution(), bs.get_status(), ref, mk, x0, kw, prob.rho, tag=str(shape))
     bs.close()
+
+
+def test_general_layout_through_the_dropin_api(hip_lib, oracle_built):
+    """the reference-named process-global entry points a Julia host binds (setup with fdyn and a batch, set_bound_constraints,
+    set_cone_constraints with a cone LIST, set_linear_constraints, set_x_ref / set_u_ref, set_x0, solve): the layout is
+    specialised at the first solve_mpc and the results are the handle API's, bit for bit, and the oracle's"""
+    N, B = 14, 70
+    prob = t.problems.rocket(N)
+    x0 = t.problems.rocket_x0(B, seed=12)
+    xr, ur = t.problems.rocket_refs(N)
+    cones, lin = ROCKET_GENERAL["cones"], ROCKET_GENERAL["lin"]
+    kw = dict(abs_pri_tol=2e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1)
+    bs = _solver(prob, B, kw, xr, ur, prob.fdyn, cones, lin)
+    bs.set_x0(x0)
+    bs.solve()
+    want_name, ref_sol, ref_st = bs.kernel_name, bs.get_solution(), bs.get_status()
+    bs.close()
+    s = t.TinyMPCSolver()
+    t.setup(s, prob.A, prob.B, prob.fdyn, prob.Q, prob.R, prob.rho, 6, 3, N, batch=B, max_iter=100, abs_pri_tol=2e-3, abs_dua_tol=1e-3)
+    t.set_bound_constraints(s, prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+    t.set_cone_constraints(s, *cones)
+    t.set_linear_constraints(s, *lin)
+    t.set_warm_start(s, False)
+    t.set_x_ref(s, xr)
+    t.set_u_ref(s, ur)
+    t.set_x0(s, x0)
+    t.solve(s)
+    assert t.kernel_name() == want_name and want_name.startswith("mfmat<6,3,14> cx0:3+3:2 cu0:3 lin1,1"), (t.kernel_name(), want_name)
+    got, st = t.get_solution(s), t.get_status(s)
+    assert np.array_equal(got["states"], ref_sol["states"]) and np.array_equal(got["controls"], ref_sol["controls"])
+    assert np.array_equal(st["iter"], ref_st["iter"]) and np.array_equal(st["solved"], ref_st["solved"])
+    t.cleanup()
+    mk = _oracle(oracle_built, prob, kw, xr, ur, prob.fdyn, cones, lin)
+    parity_every_instance(ref_sol, ref_st, _loop(mk, x0), mk, x0, kw, prob.rho, tag="drop-in")
