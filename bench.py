@@ -104,6 +104,8 @@ def parse(argv=None):
                          "e.g. 0,0, rehearses the multi-shard path on a one-GPU box (host status fold)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo only with --dry")
     ap.add_argument("--dry", action="store_true", help="no GPU, no solver: rehearse launch, sharding and status fold")
+    ap.add_argument("--specialised-only", action="store_true",
+                    help="print the `specialised` block alone (what the default run starts as a child process)")
     return ap.parse_args(argv)
 
 
@@ -600,6 +602,13 @@ def main():
     args = parse()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.specialised_only:
+        import torch
+        import tinympc_julia_amd as t
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        print(json.dumps(time_specialised(t, torch, dev, torch.cuda.Stream(device=dev))), flush=True)
+        return 0
     if args.sharded_capi:
         if args.dry:
             raise SystemExit("--sharded-capi has no dry mode: rehearse it on one GPU with --gpus 2 --devices 0,0")
@@ -820,9 +829,13 @@ def main():
         ex["quadrotor_65536_adaptive_rho"] = time_config(t, torch, dev, stream, "quadrotor", 65536, 1, adaptive=True)
         out["configs"] = ex
         if not os.environ.get("TINYMPC_HIP_NO_JIT"):
+            # in a child process: kernels compiled minutes ago on this very box must not be able to take the headline line
+            # down with them (a child is not an exec of this GPU-initialised process)
             try:
-                out["specialised"] = time_specialised(t, torch, dev, stream)
-            except Exception as e:   # (never the headline's problem: a box without a compiler runs the fallbacks, anything else is reported)
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--specialised-only"], capture_output=True, text=True, timeout=600)
+                line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                out["specialised"] = json.loads(line[-1]) if r.returncode == 0 and line else {"error": (r.stderr or r.stdout)[-300:]}
+            except Exception as e:
                 out["specialised"] = {"error": str(e)[:300]}
     if rank == 0:
         print(json.dumps(out), flush=True)
