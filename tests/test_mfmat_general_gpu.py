@@ -345,3 +345,51 @@ def test_general_layout_through_the_dropin_api(hip_lib, oracle_built):
     t.cleanup()
     mk = _oracle(oracle_built, prob, kw, xr, ur, prob.fdyn, cones, lin)
     parity_every_instance(ref_sol, ref_st, _loop(mk, x0), mk, x0, kw, prob.rho, tag="drop-in")
+
+
+def test_general_layout_full_size_properties(hip_lib, oracle_built):
+    """32 768 rocket instances (config 4's batch) at N = 20 with two state cones, the thrust cone and a row on both sides, on the
+    unit specialised for the layout — through properties that do not need the oracle at that size: two launches agree bit for
+    bit; the returned slack respects the box bounds exactly; where an instance converged (primal residuals below the
+    tolerance) its cones and rows hold to within that tolerance; every 128th instance against the oracle"""
+    N, B = 20, 32768
+    prob = t.problems.rocket(N)
+    x0 = t.problems.rocket_x0(B, seed=2)
+    xr, ur = t.problems.rocket_refs(N)
+    cones, lin = ROCKET_GENERAL["cones"], ROCKET_GENERAL["lin"]
+    tol = 2e-3
+    kw = dict(abs_pri_tol=tol, abs_dua_tol=1e-3, max_iter=150, check_termination=1)
+    bs = _solver(prob, B, kw, xr, ur, prob.fdyn, cones, lin)
+    bs.set_x0(x0)
+    bs.solve()
+    assert bs.kernel_name.startswith("mfmat<6,3,20> cx0:3+3:2 cu0:3 lin1,1"), bs.kernel_name
+    sol, st = bs.get_solution(), bs.get_status()
+    bs.solve()
+    sol2, st2 = bs.get_solution(), bs.get_status()
+    assert np.array_equal(sol["states"], sol2["states"]) and np.array_equal(sol["controls"], sol2["controls"]) and np.array_equal(st["iter"], st2["iter"])
+    X, U = sol["states"], sol["controls"]
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    assert (X >= f32(prob.x_min)[:, :, None]).all() and (X <= f32(prob.x_max)[:, :, None]).all()
+    assert (U >= f32(prob.u_min)[:, :, None]).all() and (U <= f32(prob.u_max)[:, :, None]).all()
+    done = st["solved"] == 1
+    assert done.sum() >= 0.2 * B                             # (the hard instances run into max_iter: the rows bind for them)
+    Xc, Uc = X[:, :, done], U[:, :, done]
+    # the box slack is within the primal tolerance of x, and x within it of every other set's slack (admm.cpp:93-96)
+    slackx, slacku = 2 * tol * np.abs(X).max(), 2 * tol * np.abs(U).max()
+    Acu, qcu, mu_u, Acx, qcx, mu_x = cones
+    for a0, q, mu in zip(Acx, qcx, mu_x):
+        head, axis = Xc[a0:a0 + q - 1], Xc[a0 + q - 1]
+        assert (np.sqrt((head ** 2).sum(axis=0)) <= mu * axis + (1 + mu) * slackx).all()
+    for a0, q, mu in zip(Acu, qcu, mu_u):
+        head, axis = Uc[a0:a0 + q - 1], Uc[a0 + q - 1]
+        assert (np.sqrt((head ** 2).sum(axis=0)) <= mu * axis + (1 + mu) * slacku).all()
+    Ax, bx, Au, bu = lin
+    assert (np.einsum("rk,knb->rnb", np.asarray(Ax), Xc) <= np.asarray(bx)[:, None, None] + np.abs(Ax).sum() * slackx).all()
+    assert (np.einsum("rk,knb->rnb", np.asarray(Au), Uc) <= np.asarray(bu)[:, None, None] + np.abs(Au).sum() * slacku).all()
+    pick = np.arange(0, B, 128)
+    mk = _oracle(oracle_built, prob, kw, xr, ur, prob.fdyn, cones, lin)
+    ref = _loop(mk, x0[:, pick])
+    sub = dict(states=X[:, :, pick], controls=U[:, :, pick])
+    sst = dict(iter=st["iter"][pick], solved=st["solved"][pick], residuals=st["residuals"][pick])
+    parity_every_instance(sub, sst, ref, mk, x0[:, pick], kw, prob.rho, min_same=0.9, tag="full-size sample")
+    bs.close()
