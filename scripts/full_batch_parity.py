@@ -4,6 +4,7 @@ randomised x0: every one of the 32 768 distinct) on the on-chip kernel.  Prints 
 import os, sys, json, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+os.environ.setdefault("TINYMPC_HIP_CACHE", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "jit_cache"))
 import tinympc_julia_amd as t
 from oracle import cpu_oracle
 
@@ -19,10 +20,11 @@ for fam in ("cartpole", "quadrotor"):
         prob, x0 = t.problems.cartpole(20, u_bound=0.5), t.problems.cartpole_x0(B, seed=0)
     else:
         prob, x0 = t.problems.quadrotor(30), t.problems.quadrotor_x0(B, seed=1)
+    x0 = np.asfortranarray(x0.astype(np.float32).astype(np.float64))   # (the library takes x0 as an fp32 array: the oracle gets the same numbers)
     t0 = time.time()
     ref = cpu_oracle.solve_batch("orc64", prob, x0, abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=100, nthreads=cores)
     t_cpu = time.time() - t0
-    for prec in (0, 1):
+    for prec in (0, 1, 2):   # (2: fp64 state end to end — the lean kernel's fp64-state variant specialised on request for cartpole, generic<f64> for the quadrotor)
         bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
         bs.update_settings(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=100, check_termination=1)
         bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
@@ -31,11 +33,12 @@ for fam in ("cartpole", "quadrotor"):
         bs.solve()
         sol = bs.get_solution()
         ex, eu = nrel_batch(sol["states"], ref["x"]), nrel_batch(sol["controls"], ref["u"])
-        key = f"{fam}_{'f64rec' if prec == 0 else 'f32'}"
+        key = f"{fam}_{('f64rec', 'f32', 'f64state')[prec]}"
         out[key] = dict(kernel=bs.last_launch_name, batch=B, x_max=float(ex.max()), u_max=float(eu.max()),
                         x_p999=float(np.quantile(ex, 0.999)), u_p999=float(np.quantile(eu, 0.999)),
                         x_median=float(np.median(ex)), u_median=float(np.median(eu)),
-                        n_over_1e5=int(((ex > 1e-5) | (eu > 1e-5)).sum()), oracle_seconds=t_cpu, oracle_threads=cores)
+                        n_over_1e5=int(((ex > 1e-5) | (eu > 1e-5)).sum()), n_over_1e6=int(((ex > 1e-6) | (eu > 1e-6)).sum()),
+                        oracle_seconds=t_cpu, oracle_threads=cores)
         print(key, json.dumps(out[key]), flush=True)
         bs.close()
 
