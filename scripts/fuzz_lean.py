@@ -4,6 +4,8 @@ bounds on random rows or none, zero or shared references, fixed-iteration / tole
 intervals, ragged batches of one lane per instance.  Every instance by solution at 1e-5 (tests/util.parity_every_instance).
 PRECISION=2: the same sweep on the kernel's fp64-state form (precision 2; specialised on request, csrc/jit.cpp), x0 / bounds /
 references rounded to fp32 on both sides, every instance at 1e-6 and iteration counts exactly.
+SHAPE=nx,nu and / or HORIZONS=n1,n2,...: other shapes / horizons than the built-in (4,1,{5,10,15,20}) — the variants specialised
+at the launch that needs them (csrc/jit.cpp: jit_lean_for); per-knot state bounds are then constant (one row pair).
 Usage: python scripts/fuzz_lean.py [first_seed] [n_cases]"""
 import os, sys
 import numpy as np
@@ -12,7 +14,9 @@ import tinympc_julia_amd as t
 from oracle import cpu_oracle
 from tests.util import parity_every_instance, FP32_TOL
 P2 = os.environ.get("PRECISION") == "2"
-if P2:
+SHAPE = tuple(int(v) for v in os.environ.get("SHAPE", "4,1").split(","))
+HORIZONS = [int(v) for v in os.environ.get("HORIZONS", "5,10,15,20").split(",")]
+if P2 or "SHAPE" in os.environ or "HORIZONS" in os.environ:
     os.environ.pop("TINYMPC_HIP_NO_JIT", None)
     os.environ.setdefault("TINYMPC_HIP_CACHE", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "jit_cache"))
 f32 = lambda a: np.asfortranarray(np.asarray(a, dtype=np.float32).astype(np.float64))
@@ -20,8 +24,8 @@ f32 = lambda a: np.asfortranarray(np.asarray(a, dtype=np.float32).astype(np.floa
 
 def one(seed):
     rng = np.random.default_rng(seed)
-    nx, nu = 4, 1
-    N = int(rng.choice([5, 10, 15, 20]))
+    nx, nu = SHAPE
+    N = int(rng.choice(HORIZONS))
     B = int(20480 + rng.integers(0, 6000))
     A = np.eye(nx) + 0.25 * rng.standard_normal((nx, nx)) / np.sqrt(nx)
     A *= rng.uniform(0.9, 1.03) / np.abs(np.linalg.eigvals(A)).max()
@@ -67,10 +71,10 @@ def one(seed):
         if P2: bs.set_precision(2)
         bs.set_warm_start(False); bs.set_x0(x0); bs.solve()
         name = bs.last_launch_name
-        if P2 and xb and N > 17:                                # fp64 slack AND dual of every state row: the registers hold N <= 17
+        if P2 and (4 if xb else 2) * N * nx + 6 * N * nu + 50 > 450:   # (jit.cpp's register rule: fp64 slack AND dual of every state row with a state bound)
             assert name == "generic<f64>", name
         else:
-            assert name == (f"lean<4,1,{N};f64>" if P2 else f"lean<4,1,{N}>"), name
+            assert name == (f"lean<{nx},{nu},{N};f64>" if P2 else f"lean<{nx},{nu},{N}>"), name
         if P2:
             from tests.util import nrel_batch
             sol, st = bs.get_solution(), bs.get_status()
