@@ -275,55 +275,115 @@ struct SBlock {
 // 300 us launch: 26 MB at 0.5 TB/s).  `so`: the wavefront's staging, at least max(64 x 17, 64 x (EU | 1)) floats; xo / uo:
 // the arrays at the wavefront's first instance; mask: the lanes whose instance is stored; getx(e) / getu(e): element e of
 // this lane's instance (compile-time e: the callers' trajectories are register arrays).
-template <int EX, int EU, class FX, class FU>
-__device__ __forceinline__ void store_wave_coalesced(float *so, float *__restrict__ xo, float *__restrict__ uo, int lane,
-                                                     unsigned long long mask, FX &&getx, FU &&getu) {
+// (the state part and the input part on their own: the workspace arrays go the same way, five of them)
+template <int EX, bool FULL, class FX>
+__device__ __forceinline__ void store_wave_x(float *so, float *__restrict__ xo, int lane, unsigned long long mask, FX &&getx) {
     const int sub = lane >> 4, off = lane & 15;
     constexpr int NCH = (EX + 15) / 16;
-    auto put_all = [&](auto full_tag) {   // every instance of the wavefront stores (the usual case): no predicates
-        constexpr bool FULL = decltype(full_tag)::value;
-        sfor<0, NCH>([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            sfor<0, 16>([&](auto jj) {
-                constexpr int j = decltype(jj)::value;
-                if constexpr (c * 16 + j < EX) so[lane * 17 + j] = getx(std::integral_constant<int, c * 16 + j>{});
-            });
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            float v[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = so[(4 * j + sub) * 17 + off];   // piece j: instances 4 j .. 4 j + 3, 16 floats each
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int inst = 4 * j + sub;
-                const bool ok = (EX % 16 == 0 || c * 16 + off < EX) && (FULL || ((mask >> inst) & 1ull));
-                if (ok) xo[inst * EX + c * 16 + off] = v[j];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        });
-        sfor<0, EU>([&](auto ee) {
-            constexpr int e = decltype(ee)::value;
-            so[lane * (EU | 1) + e] = getu(std::integral_constant<int, e>{});
+    sfor<0, NCH>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        sfor<0, 16>([&](auto jj) {
+            constexpr int j = decltype(jj)::value;
+            if constexpr (c * 16 + j < EX) so[lane * 17 + j] = getx(std::integral_constant<int, c * 16 + j>{});
         });
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        float w[EU];
+        float v[16];
 #pragma unroll
-        for (int j = 0; j < EU; ++j) {                             // flat element f of the wavefront's 64 x EU controls
-            const int f = j * 64 + lane;
-            w[j] = so[(f / EU) * (EU | 1) + f % EU];
-        }
+        for (int j = 0; j < 16; ++j) v[j] = so[(4 * j + sub) * 17 + off];   // piece j: instances 4 j .. 4 j + 3, 16 floats each
 #pragma unroll
-        for (int j = 0; j < EU; ++j) {
-            const int f = j * 64 + lane;
-            if (FULL || ((mask >> (f / EU)) & 1ull)) uo[f] = w[j];
+        for (int j = 0; j < 16; ++j) {
+            const int inst = 4 * j + sub;
+            const bool ok = (EX % 16 == 0 || c * 16 + off < EX) && (FULL || ((mask >> inst) & 1ull));
+            if (ok) xo[inst * EX + c * 16 + off] = v[j];
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-    };
-    if (mask == ~0ull) put_all(std::true_type{});
-    else put_all(std::false_type{});
+    });
+}
+template <int EU, bool FULL, class FU>
+__device__ __forceinline__ void store_wave_u(float *so, float *__restrict__ uo, int lane, unsigned long long mask, FU &&getu) {
+    sfor<0, EU>([&](auto ee) {
+        constexpr int e = decltype(ee)::value;
+        so[lane * (EU | 1) + e] = getu(std::integral_constant<int, e>{});
+    });
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float w[EU];
+#pragma unroll
+    for (int j = 0; j < EU; ++j) {                             // flat element f of the wavefront's 64 x EU controls
+        const int f = j * 64 + lane;
+        w[j] = so[(f / EU) * (EU | 1) + f % EU];
+    }
+#pragma unroll
+    for (int j = 0; j < EU; ++j) {
+        const int f = j * 64 + lane;
+        if (FULL || ((mask >> (f / EU)) & 1ull)) uo[f] = w[j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+template <int EX, int EU, class FX, class FU>
+__device__ __forceinline__ void store_wave_coalesced(float *so, float *__restrict__ xo, float *__restrict__ uo, int lane,
+                                                     unsigned long long mask, FX &&getx, FU &&getu) {
+    if (mask == ~0ull) {   // every instance of the wavefront stores (the usual case): no predicates
+        store_wave_x<EX, true>(so, xo, lane, mask, getx);
+        store_wave_u<EU, true>(so, uo, lane, mask, getu);
+    } else {
+        store_wave_x<EX, false>(so, xo, lane, mask, getx);
+        store_wave_u<EU, false>(so, uo, lane, mask, getu);
+    }
+}
+// ... and the way in: a wavefront's instances' arrays from HBM — a load instruction reads whole 64-byte pieces / contiguous
+// 256 bytes — through LDS into the registers of the lane that owns the instance (the kept workspace at the start of a solve:
+// read in per-lane strides it cost as much again as the strided stores).  setx(e, value) / setu(e, value): element e of this
+// lane's instance; lanes outside `mask` receive zeros.
+template <int EX, class FX>
+__device__ __forceinline__ void load_wave_x(float *so, const float *__restrict__ xi, int lane, unsigned long long mask, FX &&setx) {
+    const int sub = lane >> 4, off = lane & 15;
+    constexpr int NCH = (EX + 15) / 16;
+    sfor<0, NCH>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int inst = 4 * j + sub;
+            const bool ok = (EX % 16 == 0 || c * 16 + off < EX) && ((mask >> inst) & 1ull);
+            v[j] = ok ? xi[inst * EX + c * 16 + off] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) so[(4 * j + sub) * 17 + off] = v[j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        sfor<0, 16>([&](auto jj) {
+            constexpr int j = decltype(jj)::value;
+            if constexpr (c * 16 + j < EX) setx(std::integral_constant<int, c * 16 + j>{}, so[lane * 17 + j]);
+        });
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    });
+}
+template <int EU, class FU>
+__device__ __forceinline__ void load_wave_u(float *so, const float *__restrict__ ui, int lane, unsigned long long mask, FU &&setu) {
+    float w[EU];
+#pragma unroll
+    for (int j = 0; j < EU; ++j) {
+        const int f = j * 64 + lane;
+        w[j] = ((mask >> (f / EU)) & 1ull) ? ui[f] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < EU; ++j) {
+        const int f = j * 64 + lane;
+        so[(f / EU) * (EU | 1) + f % EU] = w[j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    sfor<0, EU>([&](auto ee) {
+        constexpr int e = decltype(ee)::value;
+        setu(std::integral_constant<int, e>{}, so[lane * (EU | 1) + e]);
+    });
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 constexpr int wave_stage_floats(int EU) { return 64 * 17 > 64 * (EU | 1) ? 64 * 17 : 64 * (EU | 1); }
 
@@ -411,6 +471,9 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
     // results are bit-identical: x + 0 and (0 + x) - x are exact).
     constexpr bool NOG = OS && !XB;
     constexpr auto PL = S::template place<RT, REFS, OS, NOG>();
+    // one lane per instance and LDS free: solution and workspace cross a wavefront's LDS staging on their way to / from HBM
+    constexpr bool CO_STORE = G == 1 && PL.lds_floats == 0;
+    __shared__ float s_stage[CO_STORE ? 4 : 1][CO_STORE ? wave_stage_floats(S::NU * (S::N - 1)) : 1];
     constexpr int STATE_LEN = PL.lds_floats > 0 ? PL.lds_floats * S::THREADS : 1;
     constexpr int T = S::THREADS;
     constexpr bool UREP = S::UREP;
@@ -633,7 +696,23 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
             z_set(k, m, 0.f);
             if constexpr (REFS == REF_PER_INSTANCE) ur[k][m] = 0.f;
         }
-    if (warm) {
+    bool warm_loaded = false;
+    if constexpr (CO_STORE) {
+        if (!P.cold_start && !P.idx) {   // (uniform: the whole wavefront takes this path)
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(active);
+            const long w0 = (long)blockIdx.x * S::INST_PER_BLOCK + (tid & ~63);
+            float *so = s_stage[tid >> 6];
+            if (mask) {
+                load_wave_x<EX>(so, P.sg + w0 * EX, tid & 63, mask, [&](auto ee, float val) { constexpr int e = decltype(ee)::value; g_set(e / NX, e % NX, val); });
+                load_wave_x<EX>(so, P.sv + w0 * EX, tid & 63, mask, [&](auto ee, float val) { constexpr int e = decltype(ee)::value; v_set(e / NX, e % NX, val); });
+                load_wave_u<EU>(so, P.sy + w0 * EU, tid & 63, mask, [&](auto ee, float val) { constexpr int e = decltype(ee)::value; y_set(e / NU, e % NU, val); });
+                load_wave_u<EU>(so, P.sz + w0 * EU, tid & 63, mask, [&](auto ee, float val) { constexpr int e = decltype(ee)::value; z_set(e / NU, e % NU, val); });
+                load_wave_u<EU>(so, P.sd + w0 * EU, tid & 63, mask, [&](auto ee, float val) { constexpr int e = decltype(ee)::value; d_set(e / NU, e % NU, val); });
+            }
+            warm_loaded = true;
+        }
+    }
+    if (warm && !warm_loaded) {
 #pragma unroll
         for (int m = 0; m < RX; ++m) {
             const int row = q * RX + m;
@@ -1174,16 +1253,26 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
 
     // ================= epilogue: solution, status, warm-start state =================
     // solution = projected slack of the last executed iteration (admm.cpp:187-188,204-205)
-    constexpr bool CO_STORE = G == 1 && PL.lds_floats == 0;   // one lane per instance, LDS free: the coalesced form
     if constexpr (CO_STORE) {
-        __shared__ float s_stage[CO_STORE ? 4 : 1][CO_STORE ? wave_stage_floats(EU) : 1];
         if (!P.idx) {   // (with an index list a wavefront's instances are not neighbours in the arrays)
             const unsigned long long mask = __builtin_amdgcn_ballot_w64(active);
             const long w0 = (long)blockIdx.x * S::INST_PER_BLOCK + (tid & ~63);
-            if (mask)
+            if (mask) {
                 store_wave_coalesced<EX, EU>(s_stage[tid >> 6], P.xout + w0 * EX, P.uout + w0 * EU, tid & 63, mask,
                                              [&](auto ee) { constexpr int e = decltype(ee)::value; return w_get(e / NX, e % NX); },
                                              [&](auto ee) { constexpr int e = decltype(ee)::value; return zw_get(e / NU, e % NU); });
+                if (P.save_state) {   // the workspace the same way (0.42 ms per 65 536 kept-workspace cartpole solves: 80 us of it were these arrays in per-lane strides)
+                    float *so = s_stage[tid >> 6];
+                    store_wave_coalesced<EX, EU>(so, P.sg + w0 * EX, P.sy + w0 * EU, tid & 63, mask,
+                                                 [&](auto ee) { constexpr int e = decltype(ee)::value; return g_get(e / NX, e % NX); },
+                                                 [&](auto ee) { constexpr int e = decltype(ee)::value; return y_get(e / NU, e % NU); });
+                    store_wave_coalesced<EX, EU>(so, P.sv + w0 * EX, P.sz + w0 * EU, tid & 63, mask,
+                                                 [&](auto ee) { constexpr int e = decltype(ee)::value; return v_get(e / NX, e % NX); },
+                                                 [&](auto ee) { constexpr int e = decltype(ee)::value; return z_get(e / NU, e % NU); });
+                    store_wave_u<EU, false>(so, P.sd + w0 * EU, tid & 63, mask,
+                                            [&](auto ee) { constexpr int e = decltype(ee)::value; return d_get(e / NU, e % NU); });
+                }
+            }
         }
     }
     if (active) {
@@ -1234,7 +1323,7 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
             P.res[b * 4 + 2] = res2;
             P.res[b * 4 + 3] = res3;
         }
-        if (P.save_state) {
+        if (P.save_state && (!CO_STORE || P.idx)) {
 #pragma unroll
             for (int m = 0; m < RX; ++m) {
                 const int row = q * RX + m;
