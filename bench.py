@@ -818,8 +818,11 @@ def main():
         ex["cartpole_65536_state_bound"] = time_config(t, torch, dev, stream, "cartpole", 65536, 0, state_bound=0.45)
         # ... and in the reference's default calling pattern: the workspace kept between solves (admm.cpp:111-115), 100 fixed
         # iterations and warm-started to tolerance 1e-3 with a check every 10 (steady state: 10 iterations per solve)
-        ex["cartpole_65536_workspace_kept"] = time_config(t, torch, dev, stream, "cartpole", 65536, 0, keep_workspace=True)
-        ex["cartpole_65536_workspace_kept_tol"] = time_config(t, torch, dev, stream, "cartpole", 65536, 0, tol=1e-3, check=10, keep_workspace=True)
+        # (eight untimed solves first: from a zero workspace the warm-started solves need 68, 57, 54, 48, 23 iterations before
+        # they settle at 10)
+        ex["cartpole_65536_workspace_kept"] = time_config(t, torch, dev, stream, "cartpole", 65536, 0, keep_workspace=True, warmup=8)
+        ex["cartpole_65536_workspace_kept_tol"] = time_config(t, torch, dev, stream, "cartpole", 65536, 0, tol=1e-3, check=10, keep_workspace=True,
+                                                              warmup=8)
         ex["quadrotor_65536"] = time_config(t, torch, dev, stream, "quadrotor", 65536, 1)
         ex["rocket_soc_32768"] = time_config(t, torch, dev, stream, "rocket_soc", 32768, 2)
         ex["rocket_soc_32768_workspace_kept"] = time_config(t, torch, dev, stream, "rocket_soc", 32768, 2, keep_workspace=True)
