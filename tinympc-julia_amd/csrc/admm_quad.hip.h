@@ -697,7 +697,7 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
             if constexpr (REFS == REF_PER_INSTANCE) ur[k][m] = 0.f;
         }
     bool warm_loaded = false;
-    if constexpr (CO_STORE) {
+    if constexpr (CO_STORE && !OS) {   // (the one-shot variants are never launched on a kept workspace: quad_entry.hip.h)
         if (!P.cold_start && !P.idx) {   // (uniform: the whole wavefront takes this path)
             const unsigned long long mask = __builtin_amdgcn_ballot_w64(active);
             const long w0 = (long)blockIdx.x * S::INST_PER_BLOCK + (tid & ~63);
@@ -1261,6 +1261,7 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
                 store_wave_coalesced<EX, EU>(s_stage[tid >> 6], P.xout + w0 * EX, P.uout + w0 * EU, tid & 63, mask,
                                              [&](auto ee) { constexpr int e = decltype(ee)::value; return w_get(e / NX, e % NX); },
                                              [&](auto ee) { constexpr int e = decltype(ee)::value; return zw_get(e / NU, e % NU); });
+                if constexpr (!OS)
                 if (P.save_state) {   // the workspace the same way (0.42 ms per 65 536 kept-workspace cartpole solves: 80 us of it were these arrays in per-lane strides)
                     float *so = s_stage[tid >> 6];
                     store_wave_coalesced<EX, EU>(so, P.sg + w0 * EX, P.sy + w0 * EU, tid & 63, mask,
@@ -1323,7 +1324,7 @@ __global__ __launch_bounds__(256) void admm_quad_kernel(const AdmmParams P) {
             P.res[b * 4 + 2] = res2;
             P.res[b * 4 + 3] = res3;
         }
-        if (P.save_state && (!CO_STORE || P.idx)) {
+        if (P.save_state && (!CO_STORE || OS || P.idx)) {
 #pragma unroll
             for (int m = 0; m < RX; ++m) {
                 const int row = q * RX + m;
