@@ -297,3 +297,21 @@ def test_precision_2_runs_on_the_lean_kernel(hip_lib, oracle_built, jit_on, case
     bs.solve()
     assert bs.last_launch_name == f"lean<4,1,{N}>"
     bs.close()
+
+
+def test_concurrent_specialisation_of_one_unit(hip_lib, tmp_path, monkeypatch):
+    """one process per GPU is the deployment model: four processes ask for the same new unit at the same moment (a fresh
+    cache) — every one of them gets it, and what is left behind is one object and no half-written files"""
+    import glob
+    import subprocess
+    import sys
+    monkeypatch.delenv("TINYMPC_HIP_NO_JIT", raising=False)
+    env = dict(os.environ, TINYMPC_HIP_CACHE=str(tmp_path))
+    env.pop("TINYMPC_HIP_NO_JIT", None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"import sys; sys.path.insert(0, {root!r}); import tinympc_julia_amd as t; print('RESULT', t.specialise(3, 1, 7))"
+    procs = [subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(4)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all("RESULT True" in o for o, _ in outs), outs
+    assert len(glob.glob(os.path.join(str(tmp_path), "*", "quad_3_1_7_g4.so"))) == 1
+    assert not glob.glob(os.path.join(str(tmp_path), "*", "*.tmp.*"))

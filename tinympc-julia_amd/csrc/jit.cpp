@@ -115,7 +115,10 @@ const void *build_unit(const std::string &unit, const std::string &source, int v
     mkdirs(cache);
     const std::string so = cache + "/" + unit + ".so";
     if (!file_exists(so)) {
-        const std::string src = cache + "/" + unit + ".hip", tmp = so + ".tmp." + std::to_string((long)getpid());
+        // one process per GPU is the deployment model: eight ranks may specialise the same unit at the same moment — source, log
+        // and object of a compile carry the pid, and only the finished object is renamed into place (atomic)
+        const std::string pid = std::to_string((long)getpid());
+        const std::string src = cache + "/" + unit + "." + pid + ".hip", tmp = so + ".tmp." + pid;
         {
             std::ofstream out(src);
             out << source;
@@ -127,14 +130,16 @@ const void *build_unit(const std::string &unit, const std::string &source, int v
                                         "-DTMPC_MFMAT_HANDOVER=2", "-mllvm", "-amdgpu-mfma-vgpr-form", "-I" + csrc, src, "-o", tmp, "-L" + lib, "-ltinympc_hip",
                                         "-Wl,-rpath," + lib};
         if (extra_flag) cmd.push_back(extra_flag);
-        const int rc = run(cmd, cache + "/" + unit + ".log");
+        const int rc = run(cmd, cache + "/" + unit + "." + pid + ".log");
         const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (rc != 0 || ::rename(tmp.c_str(), so.c_str()) != 0) {
             ::unlink(tmp.c_str());
-            std::fprintf(stderr, "tinympc_hip: specialising %s failed after %.1f s (log: %s/%s.log); the run-time-shape kernels take this solver\n",
-                         unit.c_str(), secs, cache.c_str(), unit.c_str());
+            std::fprintf(stderr, "tinympc_hip: specialising %s failed after %.1f s (log: %s/%s.%s.log); the run-time-shape kernels take this solver\n",
+                         unit.c_str(), secs, cache.c_str(), unit.c_str(), pid.c_str());
             return nullptr;
         }
+        (void)::rename(src.c_str(), (cache + "/" + unit + ".hip").c_str());                       // (kept for reference)
+        (void)::rename((cache + "/" + unit + "." + pid + ".log").c_str(), (cache + "/" + unit + ".log").c_str());
         std::fprintf(stderr, "tinympc_hip: specialised %s in %.1f s (one-off; cached at %s)\n", unit.c_str(), secs, so.c_str());
     } else if (verbose) {
         std::fprintf(stderr, "tinympc_hip: %s from the cache (%s)\n", unit.c_str(), so.c_str());
