@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 
 import tinympc_julia_amd as t
-from tests.util import FP32_TOL, nrel_batch, parity_every_instance
+from tests.util import FP32_TOL, nrel, nrel_batch, parity_every_instance
 
 pytestmark = pytest.mark.gpu
 
@@ -301,3 +301,63 @@ def test_lean_beyond_one_wavefront_per_simd(hip_lib, oracle_built, case):
     assert bs.last_launch_name == "lean<4,1,20>"
     parity_every_instance(bs.get_solution(), bs.get_status(), ref, make, x0, kw, prob.rho, min_same=0.97, tag=f"lean 70 000 {case}")
     bs.close()
+
+
+@pytest.mark.parametrize("state_bound", [False, True])
+def test_kept_workspace_one_lane_per_instance(hip_lib, oracle_built, monkeypatch, state_bound):
+    """the reference's default calling pattern (the workspace persists, admm.cpp:111-115) on the one-lane-per-instance quad
+    kernel, whose workspace crosses the wavefront's LDS staging in both directions (admm_quad.hip.h: load_wave_x / _u,
+    store_wave_x / _u): a ragged batch (the last wavefront has 33 instances), three warm-started solves of a host-stepped
+    closed loop, tolerance-terminated — against persistent oracles on a sample that includes the ragged wavefront, the
+    workspace arrays themselves included, and against the four-lanes-per-instance variant (plain strided loads / stores) on
+    every instance"""
+    N, B = 20, 20480 + 33
+    prob = t.problems.cartpole(N, u_bound=0.5)
+    if state_bound:
+        prob.x_min, prob.x_max = prob.x_min.copy(), prob.x_max.copy()
+        prob.x_min[0, :], prob.x_max[0, :] = -0.3, 0.3
+    kw = dict(abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=100, check_termination=1)
+    x0 = t.problems.cartpole_x0(B, seed=21)
+    pick = np.r_[0:16, 4090:4100, 20480:20480 + 33]
+    runs = {}
+    for which in ("g1", "g4"):
+        if which == "g4":
+            monkeypatch.setenv("TINYMPC_HIP_GROUP", "4")
+        bs = t.BatchSolver(prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N, batch=B)
+        bs.update_settings(**kw)
+        bs.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        x, out = x0.copy(), []
+        for k in range(3):
+            bs.set_x0(x)
+            bs.solve()
+            assert bs.last_launch_name == f"quad<4,1,20,{which}>", bs.last_launch_name
+            sol, st, ws = bs.get_solution(), bs.get_status(), bs.get_workspace()
+            out.append((sol, st, ws, x.copy()))
+            x = np.asfortranarray(prob.A @ x + prob.B @ sol["controls"][:, 0, :])
+        runs[which] = out
+        bs.close()
+    for k in range(3):
+        (sa, ta, wa, _), (sb, tb, wb, _) = runs["g1"][k], runs["g4"][k]
+        same = ta["iter"] == tb["iter"]
+        assert same.mean() >= 0.999
+        assert nrel_batch(sa["states"], sb["states"])[same].max() <= FP32_TOL and nrel_batch(sa["controls"], sb["controls"])[same].max() <= FP32_TOL
+        for key in ("d", "y", "z", "g", "v"):
+            scale = max(np.abs(wb[key]).max(), 1e-2)
+            assert np.abs(wa[key] - wb[key])[:, :, same].max() <= 2e-5 * scale, (k, key)
+    for b in pick:
+        o = oracle_built.CpuSolver("orc64", prob.A, prob.B, prob.Q, prob.R, prob.rho, prob.N)
+        o.update_settings(**kw)
+        o.set_bound_constraints(prob.x_min, prob.x_max, prob.u_min, prob.u_max)
+        for k in range(3):
+            sol, st, ws, xk = runs["g1"][k]
+            o.set_x0(xk[:, b])
+            o.solve()
+            r, sv = o.get_solution(), o.get_state()
+            if r["iter"] != int(st["iter"][b]):
+                break                                       # (a residual within rounding of the tolerance: the workspaces part ways)
+            assert nrel(sol["states"][:, :, b], r["x"]) <= FP32_TOL and nrel(sol["controls"][:, :, b], r["u"]) <= FP32_TOL, (b, k)
+            for key in ("d", "y", "z", "g", "v"):
+                scale = max(np.abs(sv[key]).max(), 1e-2)
+                lim = 4e-5 if key in ("g", "y") else 2e-5      # (the duals integrate the trajectory's per-iteration fp32 rounding: tests/test_mfmat_gpu.py)
+                assert np.abs(ws[key][:, :, b] - sv[key]).max() <= lim * scale, (b, k, key)
+        o.close()
